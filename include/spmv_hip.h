@@ -1,0 +1,171 @@
+/*
+ * spmv_hip.h -- C ABI of the MI355X (gfx950) SpMV engine.
+ *
+ * This is the drop-in boundary for ONE path of jamtrott/spmv-cache-trace: the
+ * `y += A*x` kernels behind its `Kernel::run()` plug-in interface
+ * (reference src/kernels/kernel.hpp:18-45).  Each entry point names the
+ * reference function it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C types only; opaque handles; int32 indices and fp64 values exactly
+ *     as the reference stores them (src/matrix/csr-matrix.hpp:15-17)
+ *   - every function returns 0 (SPMV_HIP_OK) or a negative SPMV_HIP_ERR_* code;
+ *     nothing throws across this boundary; spmv_hip_last_error() gives the
+ *     detail string of the calling thread's last failure
+ *   - all kernels ACCUMULATE: y += A*x (csr-matrix-spmv.cpp:32,
+ *     coo-matrix.cpp:268, ell-matrix.cpp:257); y is never zeroed here
+ *   - "host" pointers are borrowed for the duration of the call; "device"
+ *     pointers must be 16-byte aligned hipMalloc'ed (or torch) memory on the
+ *     current device
+ *   - there is NO CPU fallback: without a usable GPU every compute entry point
+ *     fails with SPMV_HIP_ERR_NO_DEVICE / SPMV_HIP_ERR_HIP
+ *   - a ctx / plan is not thread-safe; call it from one thread (the reference's
+ *     harness calls run() from every OpenMP thread, src/profile-kernel.cpp:160:
+ *     the adapters in host/ funnel that to the master thread)
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMV_HIP_VERSION 100 /* 1.0.0 */
+
+/* ---- error codes ---------------------------------------------------------- */
+#define SPMV_HIP_OK 0
+#define SPMV_HIP_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, bad row_ptr) */
+#define SPMV_HIP_ERR_NO_DEVICE (-2) /* no HIP device visible */
+#define SPMV_HIP_ERR_HIP (-3)       /* a HIP runtime call failed; see spmv_hip_last_error() */
+#define SPMV_HIP_ERR_ALLOC (-4)     /* host or device allocation failed */
+#define SPMV_HIP_ERR_STATE (-5)     /* call order: no matrix uploaded, wrong format, ... */
+#define SPMV_HIP_ERR_OVERFLOW (-6)  /* rows*row_length does not fit int32 (ell-matrix.cpp:199-205) */
+#define SPMV_HIP_ERR_ALIGN (-7)     /* device pointer not 16-byte aligned */
+
+/* ---- CSR algorithms --------------------------------------------------------- */
+#define SPMV_HIP_CSR_AUTO 0     /* pick from the row-length statistics of the matrix */
+#define SPMV_HIP_CSR_SCALAR 1   /* one lane per row; sums in the reference's order: bit-exact */
+#define SPMV_HIP_CSR_VECTOR 2   /* 2..64 lanes per row + DPP/ds_swizzle wave reduce */
+#define SPMV_HIP_CSR_ADAPTIVE 3 /* row blocks: coalesced stream of col/val -> products in LDS ->
+                                   per-row sums (reference order when a row gets one lane);
+                                   rows longer than a tile get a whole workgroup */
+
+/* plan / ctx flags */
+#define SPMV_HIP_FLAG_NO_XCD_REMAP 0x1u /* keep blockIdx order (A/B switch for the XCD-aware mapping) */
+#define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
+
+typedef struct spmv_hip_ctx spmv_hip_ctx;
+typedef struct spmv_hip_plan spmv_hip_plan;
+
+/* ---- library ------------------------------------------------------------------ */
+int spmv_hip_version(void);
+const char *spmv_hip_strerror(int code);
+const char *spmv_hip_last_error(void);
+/* Number of visible HIP devices (0 and SPMV_HIP_OK when there are none). */
+int spmv_hip_device_count(int *count);
+
+/* =================================================================================
+ * Level 1 -- context API: host arrays in, host arrays out.
+ * Bound by the hip_{csr,coo,ell}_spmv_kernel adapters (host/hip-spmv-kernels.cpp),
+ * which stand where the reference's csr_spmv_kernel / coo_spmv_kernel /
+ * ell_spmv_kernel stand (src/kernels/{csr,coo,ell}-spmv.cpp).
+ * ============================================================================== */
+
+/* Create a context on `device` with its own stream.  Replaces nothing in the
+ * reference (it has no device); called from Kernel::init. */
+int spmv_hip_create(spmv_hip_ctx **ctx, int device, unsigned flags);
+void spmv_hip_destroy(spmv_hip_ctx *ctx);
+
+/* CSR algorithm for later uploads (default SPMV_HIP_CSR_AUTO);
+ * lanes_per_row: 0 = choose, else 2,4,...,64 for SPMV_HIP_CSR_VECTOR. */
+int spmv_hip_set_csr_algorithm(spmv_hip_ctx *ctx, int algorithm, int lanes_per_row);
+
+/* Copy a CSR matrix to the device and build its launch plan.
+ * Takes what csr_matrix::Matrix holds (src/matrix/csr-matrix.hpp:58-64):
+ * row_ptr[rows+1], column_index[row_ptr[rows]], value[row_ptr[rows]].
+ * `nnz` is row_ptr[rows] (padding entries of a row-aligned matrix included). */
+int spmv_hip_upload_csr(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t nnz,
+                        const int32_t *row_ptr, const int32_t *column_index,
+                        const double *value);
+
+/* COO in file order (src/matrix/coo-matrix.hpp:65-70). */
+int spmv_hip_upload_coo(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t nnz,
+                        const int32_t *row_index, const int32_t *column_index,
+                        const double *value);
+
+/* ELLPACK in the reference's ROW-MAJOR padded layout, k = i*row_length + l
+ * (src/matrix/ell-matrix.cpp:253-256); transposed to column-major on the device. */
+int spmv_hip_upload_ell(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t row_length,
+                        const int32_t *column_index, const double *value);
+
+/* x has `cols` doubles, y has `rows` doubles (src/kernels/csr-spmv.cpp:35-36). */
+int spmv_hip_set_x(spmv_hip_ctx *ctx, const double *x);
+int spmv_hip_set_y(spmv_hip_ctx *ctx, const double *y);
+int spmv_hip_get_y(spmv_hip_ctx *ctx, double *y);
+
+/* Enqueue one y += A*x on the context's stream.  Replaces
+ * csr_matrix::spmv (csr-matrix-spmv.cpp:148-167), coo_matrix::spmv
+ * (coo-matrix.cpp:313-335), ell_matrix::spmv (ell-matrix.cpp:311-335). */
+int spmv_hip_run(spmv_hip_ctx *ctx);
+/* Block until the stream is idle: must precede the harness's closing barrier
+ * (src/profile-kernel.cpp:161). */
+int spmv_hip_sync(spmv_hip_ctx *ctx);
+/* Device time of the last spmv_hip_run (hipEvent pair), valid after a sync. */
+int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
+
+/* Descriptive numbers for JSON output / tests.  out[] receives up to n of:
+ * [0] format (0 none, 1 csr, 2 coo, 3 ell)  [1] rows  [2] cols  [3] stored entries
+ * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
+ * [7] row blocks (adaptive)  [8] long-row blocks (adaptive)  [9] device bytes held */
+int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
+
+/* =================================================================================
+ * Level 2 -- device-pointer API: the caller owns device memory and the stream
+ * (bench.py and the tests pass torch tensors' data_ptr() and torch's stream).
+ * `stream` is a hipStream_t (NULL = default stream).
+ * ============================================================================== */
+
+/* Build the launch plan of a CSR matrix from its HOST row_ptr (the only part of
+ * the matrix the schedule depends on).  Allocates a few KB of device metadata on
+ * the current device. */
+int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
+                      const int32_t *host_row_ptr, int algorithm, int lanes_per_row,
+                      unsigned flags);
+void spmv_hip_plan_destroy(spmv_hip_plan *plan);
+/* out[]: [0] algorithm  [1] lanes per row  [2] workgroups  [3] row blocks
+ *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device */
+int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
+
+/* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop
+ * (src/matrix/csr-matrix-spmv.cpp:21-33, 63-76). */
+int spmv_hip_csr_spmv(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
+                      const int32_t *d_column_index, const double *d_value,
+                      const double *d_x, double *d_y, void *stream);
+
+/* y += A*x, COO in any order: wave-level segmented sums + fp64 atomics, i.e. the
+ * semantics of coo_spmv_atomic (src/matrix/coo-matrix.cpp:287-309); equals
+ * coo_spmv (:248-285) up to summation order. */
+int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t *d_row_index,
+                      const int32_t *d_column_index, const double *d_value,
+                      const double *d_x, double *d_y, void *stream);
+
+/* Row-major (reference layout) -> column-major (k = l*rows + i) on the device. */
+int spmv_hip_ell_to_column_major(int32_t rows, int32_t row_length,
+                                 const int32_t *d_col_row_major, const double *d_val_row_major,
+                                 int32_t *d_col_col_major, double *d_val_col_major,
+                                 void *stream);
+
+/* y += A*x, ELLPACK, column-major device layout; padded entries are multiplied
+ * like real ones (0.0 * x[j]), as ell_spmv_inner_loop does
+ * (src/matrix/ell-matrix.cpp:243-258).  Sums in the reference's order: bit-exact. */
+int spmv_hip_ell_spmv(int32_t rows, int32_t row_length, const int32_t *d_col_col_major,
+                      const double *d_val_col_major, const double *d_x, double *d_y,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPMV_HIP_H */

@@ -1,0 +1,662 @@
+// spmv_hip.hip -- implementation of the C ABI declared in include/spmv_hip.h.
+//
+// Host side of the device library: argument checks, launch plans (row blocks for
+// the adaptive CSR kernel), kernel launches, and the Level-1 context that owns
+// device copies of A, x, y.  No CPU compute path exists here: if HIP cannot run,
+// the entry points return an error.
+#include "spmv_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "spmv_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char * what)
+{
+    g_last_error = what ? what : "";
+    return code;
+}
+
+int fail_hip(hipError_t e, const char * call)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s: %s (%s)", call, hipGetErrorString(e), hipGetErrorName(e));
+    g_last_error = buf;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+        return SPMV_HIP_ERR_NO_DEVICE;
+    if (e == hipErrorOutOfMemory)
+        return SPMV_HIP_ERR_ALLOC;
+    return SPMV_HIP_ERR_HIP;
+}
+
+#define HIP_TRY(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess)                           \
+            return fail_hip(e_, #call);                 \
+    } while (0)
+
+bool aligned16(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kBlock = 256;
+constexpr int kTile = 2048;
+constexpr int kCUs = 256;
+
+int grid_for(long long work_items, int per_block, int max_blocks = kCUs * 8)
+{
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int) g;
+}
+
+} // namespace
+
+struct spmv_hip_plan {
+    int32_t rows = 0, cols = 0, nnz = 0;
+    int algorithm = SPMV_HIP_CSR_ADAPTIVE;
+    int lanes_per_row = 0;
+    unsigned flags = 0;
+    int workgroups = 0;
+    int nblk = 0;
+    int long_blocks = 0;
+    int32_t * d_blk_row = nullptr;
+    size_t meta_bytes = 0;
+};
+
+struct spmv_hip_ctx {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int format = 0; // 0 none, 1 csr, 2 coo, 3 ell
+    int32_t rows = 0, cols = 0, nnz = 0, row_length = 0;
+    int csr_algorithm = SPMV_HIP_CSR_AUTO;
+    int csr_lanes = 0;
+    spmv_hip_plan * plan = nullptr;
+    int32_t *d_ptr = nullptr, *d_idx = nullptr, *d_col = nullptr;
+    double *d_val = nullptr, *d_x = nullptr, *d_y = nullptr;
+    size_t bytes = 0;
+};
+
+namespace {
+
+int pick_lanes(double mean_len)
+{
+    int l = 2;
+    while (l < 64 && l < mean_len)
+        l *= 2;
+    return l;
+}
+
+template <int LPR>
+void launch_vector(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
+                   const double * x, double * y, hipStream_t s)
+{
+    hipLaunchKernelGGL((spmv::csr_vector_kernel<LPR, kBlock>), dim3(pl->workgroups), dim3(kBlock), 0, s,
+                       pl->rows, p, j, a, x, y);
+}
+
+void free_ctx_matrix(spmv_hip_ctx * c)
+{
+    if (c->plan) {
+        spmv_hip_plan_destroy(c->plan);
+        c->plan = nullptr;
+    }
+    void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y};
+    for (void * p : ptrs)
+        if (p)
+            (void) hipFree(p);
+    c->d_ptr = c->d_idx = c->d_col = nullptr;
+    c->d_val = c->d_x = c->d_y = nullptr;
+    c->format = 0;
+    c->rows = c->cols = c->nnz = c->row_length = 0;
+    c->bytes = 0;
+}
+
+// device allocation padded so that 16-byte vector loads at the tail stay inside it
+template <typename T>
+int dev_alloc(spmv_hip_ctx * c, T ** out, size_t n)
+{
+    size_t bytes = n * sizeof(T) + 64;
+    void * p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail_hip(e, "hipMalloc");
+    *out = static_cast<T *>(p);
+    c->bytes += bytes;
+    return SPMV_HIP_OK;
+}
+
+int ctx_common_vectors(spmv_hip_ctx * c)
+{
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_x, (size_t) c->cols)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_y, (size_t) c->rows)) != 0) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_x, 0, (size_t) c->cols * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_y, 0, (size_t) c->rows * sizeof(double), c->stream));
+    return SPMV_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_version(void) { return SPMV_HIP_VERSION; }
+
+const char * spmv_hip_strerror(int code)
+{
+    switch (code) {
+    case SPMV_HIP_OK: return "success";
+    case SPMV_HIP_ERR_INVALID: return "invalid argument";
+    case SPMV_HIP_ERR_NO_DEVICE: return "no HIP device available";
+    case SPMV_HIP_ERR_HIP: return "HIP runtime error";
+    case SPMV_HIP_ERR_ALLOC: return "out of memory";
+    case SPMV_HIP_ERR_STATE: return "invalid call sequence";
+    case SPMV_HIP_ERR_OVERFLOW: return "Integer overflow when computing number of non-zeros";
+    case SPMV_HIP_ERR_ALIGN: return "device pointer is not 16-byte aligned";
+    default: return "unknown error";
+    }
+}
+
+const char * spmv_hip_last_error(void) { return g_last_error.c_str(); }
+
+int spmv_hip_device_count(int * count)
+{
+    if (!count)
+        return fail(SPMV_HIP_ERR_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return SPMV_HIP_OK;
+}
+
+/* ================================ Level 2 ======================================= */
+
+int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
+                      int algorithm, int lanes_per_row, unsigned flags)
+{
+    if (!out)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    *out = nullptr;
+    if (rows < 0 || cols < 0 || !p)
+        return fail(SPMV_HIP_ERR_INVALID, "rows/cols negative or row_ptr null");
+    if (p[0] < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] is negative");
+    for (int32_t r = 0; r < rows; ++r)
+        if (p[r + 1] < p[r])
+            return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
+    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_ADAPTIVE)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
+    if (lanes_per_row != 0 &&
+        (lanes_per_row < 2 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1))))
+        return fail(SPMV_HIP_ERR_INVALID, "lanes_per_row must be 0 or a power of two in 2..64");
+
+    spmv_hip_plan * pl = new (std::nothrow) spmv_hip_plan;
+    if (!pl)
+        return fail(SPMV_HIP_ERR_ALLOC, "plan allocation failed");
+    pl->rows = rows;
+    pl->cols = cols;
+    pl->nnz = p[rows];
+    pl->flags = flags;
+    const double mean = rows > 0 ? double(p[rows] - p[0]) / rows : 0.0;
+
+    if (algorithm == SPMV_HIP_CSR_AUTO)
+        algorithm = SPMV_HIP_CSR_ADAPTIVE;
+    if (flags & SPMV_HIP_FLAG_EXACT_ORDER) {
+        if (algorithm == SPMV_HIP_CSR_VECTOR)
+            algorithm = SPMV_HIP_CSR_ADAPTIVE;
+    }
+    pl->algorithm = algorithm;
+
+    if (algorithm == SPMV_HIP_CSR_SCALAR) {
+        pl->workgroups = grid_for(rows, kBlock);
+    } else if (algorithm == SPMV_HIP_CSR_VECTOR) {
+        pl->lanes_per_row = lanes_per_row ? lanes_per_row : pick_lanes(mean);
+        pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, kCUs * 32);
+    } else {
+        // adaptive: cut rows into blocks of <= kTile entries (from the 4-aligned
+        // start of the block's first row) and <= kBlock rows
+        std::vector<int32_t> blk;
+        blk.reserve((size_t) rows / 64 + 16);
+        blk.push_back(0);
+        int32_t r = 0;
+        while (r < rows) {
+            const int32_t kb = p[r] & ~3;
+            int32_t r1 = r;
+            while (r1 < rows && (r1 - r) < kBlock && (long long) p[r1 + 1] - kb <= kTile)
+                ++r1;
+            if (r1 == r) { // one row longer than a tile
+                r1 = r + 1;
+                pl->long_blocks++;
+            }
+            blk.push_back(r1);
+            r = r1;
+        }
+        pl->nblk = (int) blk.size() - 1;
+        pl->workgroups = pl->nblk;
+        if (pl->nblk > 0) {
+            pl->meta_bytes = blk.size() * sizeof(int32_t);
+            hipError_t e = hipMalloc((void **) &pl->d_blk_row, pl->meta_bytes);
+            if (e == hipSuccess)
+                e = hipMemcpy(pl->d_blk_row, blk.data(), pl->meta_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                int rc = fail_hip(e, "plan metadata upload");
+                if (pl->d_blk_row)
+                    (void) hipFree(pl->d_blk_row);
+                delete pl;
+                return rc;
+            }
+        }
+    }
+    *out = pl;
+    return SPMV_HIP_OK;
+}
+
+void spmv_hip_plan_destroy(spmv_hip_plan * pl)
+{
+    if (!pl)
+        return;
+    if (pl->d_blk_row)
+        (void) hipFree(pl->d_blk_row);
+    delete pl;
+}
+
+int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
+{
+    if (!pl || !out || n < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
+    const int64_t v[8] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+                          pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes};
+    for (int i = 0; i < n && i < 8; ++i)
+        out[i] = v[i];
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j,
+                      const double * a, const double * x, double * y, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->rows == 0)
+        return SPMV_HIP_OK;
+    if (!p || !y || (pl->nnz > 0 && (!j || !a || !x)))
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (!aligned16(j) || !aligned16(a))
+        return fail(SPMV_HIP_ERR_ALIGN, "column_index/value must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (pl->algorithm) {
+    case SPMV_HIP_CSR_SCALAR:
+        hipLaunchKernelGGL((spmv::csr_scalar_kernel<kBlock>), dim3(pl->workgroups), dim3(kBlock), 0, s,
+                           pl->rows, p, j, a, x, y);
+        break;
+    case SPMV_HIP_CSR_VECTOR:
+        switch (pl->lanes_per_row) {
+        case 2: launch_vector<2>(pl, p, j, a, x, y, s); break;
+        case 4: launch_vector<4>(pl, p, j, a, x, y, s); break;
+        case 8: launch_vector<8>(pl, p, j, a, x, y, s); break;
+        case 16: launch_vector<16>(pl, p, j, a, x, y, s); break;
+        case 32: launch_vector<32>(pl, p, j, a, x, y, s); break;
+        default: launch_vector<64>(pl, p, j, a, x, y, s); break;
+        }
+        break;
+    default:
+        if (pl->nblk > 0)
+            hipLaunchKernelGGL((spmv::csr_adaptive_kernel<kBlock, kTile>), dim3(pl->nblk), dim3(kBlock), 0, s,
+                               pl->nblk, pl->d_blk_row, p, j, a, x, y, pl->nnz,
+                               (pl->flags & SPMV_HIP_FLAG_NO_XCD_REMAP) ? 0 : 1,
+                               (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0);
+        break;
+    }
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32_t * ci,
+                      const double * v, const double * x, double * y, void * stream)
+{
+    if (rows < 0 || nnz < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "negative size");
+    if (nnz == 0 || rows == 0)
+        return SPMV_HIP_OK;
+    if (!ri || !ci || !v || !x || !y)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(nnz, kBlock, kCUs * 16);
+    hipLaunchKernelGGL((spmv::coo_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, nnz, ri, ci, v, x, y);
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_ell_to_column_major(int32_t rows, int32_t row_length, const int32_t * j_rm,
+                                 const double * a_rm, int32_t * j_cm, double * a_cm, void * stream)
+{
+    if (rows < 0 || row_length < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "negative size");
+    int32_t n;
+    if (__builtin_mul_overflow(rows, row_length, &n))
+        return fail(SPMV_HIP_ERR_OVERFLOW, "rows*row_length overflows int32");
+    if (n == 0)
+        return SPMV_HIP_OK;
+    if (!j_rm || !a_rm || !j_cm || !a_cm)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n, kBlock, kCUs * 16);
+    hipLaunchKernelGGL((spmv::ell_transpose_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, rows,
+                       row_length, j_rm, a_rm, j_cm, a_cm);
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_ell_spmv(int32_t rows, int32_t row_length, const int32_t * j, const double * a,
+                      const double * x, double * y, void * stream)
+{
+    if (rows < 0 || row_length < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "negative size");
+    int32_t n;
+    if (__builtin_mul_overflow(rows, row_length, &n))
+        return fail(SPMV_HIP_ERR_OVERFLOW, "rows*row_length overflows int32");
+    if (rows == 0)
+        return SPMV_HIP_OK;
+    if (!y || (n > 0 && (!j || !a || !x)))
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(rows, kBlock, kCUs * 16);
+    hipLaunchKernelGGL((spmv::ell_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, rows, row_length, j, a, x, y);
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+/* ================================ Level 1 ======================================= */
+
+int spmv_hip_create(spmv_hip_ctx ** out, int device, unsigned flags)
+{
+    if (!out)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void) hipGetLastError();
+        return fail(SPMV_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (device < 0 || device >= n)
+        return fail(SPMV_HIP_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    spmv_hip_ctx * c = new (std::nothrow) spmv_hip_ctx;
+    if (!c)
+        return fail(SPMV_HIP_ERR_ALLOC, "ctx allocation failed");
+    c->device = device;
+    c->flags = flags;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        int rc = fail_hip(e, "stream/event creation");
+        spmv_hip_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SPMV_HIP_OK;
+}
+
+void spmv_hip_destroy(spmv_hip_ctx * c)
+{
+    if (!c)
+        return;
+    (void) hipSetDevice(c->device);
+    if (c->stream)
+        (void) hipStreamSynchronize(c->stream);
+    free_ctx_matrix(c);
+    if (c->ev0) (void) hipEventDestroy(c->ev0);
+    if (c->ev1) (void) hipEventDestroy(c->ev1);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int spmv_hip_set_csr_algorithm(spmv_hip_ctx * c, int algorithm, int lanes_per_row)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_ADAPTIVE)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
+    c->csr_algorithm = algorithm;
+    c->csr_lanes = lanes_per_row;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz,
+                        const int32_t * row_ptr, const int32_t * column_index, const double * value)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
+        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
+    for (int32_t k = 0; k < nnz; ++k)
+        if (column_index[k] < 0 || column_index[k] >= cols)
+            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_ctx_matrix(c);
+    int rc = spmv_hip_plan_csr(&c->plan, rows, cols, row_ptr, c->csr_algorithm, c->csr_lanes, c->flags);
+    if (rc != 0)
+        return rc;
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = nnz;
+    if ((rc = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_col, (size_t) nnz)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_val, (size_t) nnz)) != 0) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr, ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ctx_common_vectors(c)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->format = 1;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz,
+                        const int32_t * row_index, const int32_t * column_index, const double * value)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
+    for (int32_t k = 0; k < nnz; ++k)
+        if (row_index[k] < 0 || row_index[k] >= rows || column_index[k] < 0 || column_index[k] >= cols)
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_ctx_matrix(c);
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = nnz;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_idx, (size_t) nnz)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_col, (size_t) nnz)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_val, (size_t) nnz)) != 0) return rc;
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_idx, row_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ctx_common_vectors(c)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->format = 2;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length,
+                        const int32_t * column_index, const double * value)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (rows < 0 || cols < 0 || row_length < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "bad ELL arguments");
+    int32_t n;
+    if (__builtin_mul_overflow(rows, row_length, &n))
+        return fail(SPMV_HIP_ERR_OVERFLOW, "Integer overflow when computing number of non-zeros");
+    if (n > 0 && (!column_index || !value))
+        return fail(SPMV_HIP_ERR_INVALID, "null ELL arrays");
+    for (int32_t k = 0; k < n; ++k)
+        if (column_index[k] < 0 || column_index[k] >= cols)
+            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_ctx_matrix(c);
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = n;
+    c->row_length = row_length;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_col, (size_t) n)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_val, (size_t) n)) != 0) return rc;
+    if (n > 0) {
+        int32_t * t_col = nullptr;
+        double * t_val = nullptr;
+        HIP_TRY(hipMalloc((void **) &t_col, (size_t) n * sizeof(int32_t)));
+        hipError_t e = hipMalloc((void **) &t_val, (size_t) n * sizeof(double));
+        if (e != hipSuccess) {
+            (void) hipFree(t_col);
+            return fail_hip(e, "hipMalloc");
+        }
+        e = hipMemcpyAsync(t_col, column_index, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(t_val, value, (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            rc = spmv_hip_ell_to_column_major(rows, row_length, t_col, t_val, c->d_col, c->d_val, c->stream);
+            e = hipStreamSynchronize(c->stream);
+        }
+        (void) hipFree(t_col);
+        (void) hipFree(t_val);
+        if (e != hipSuccess)
+            return fail_hip(e, "ELL upload");
+        if (rc != 0)
+            return rc;
+    }
+    if ((rc = ctx_common_vectors(c)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->format = 3;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_set_x(spmv_hip_ctx * c, const double * x)
+{
+    if (!c || !x)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx/x null");
+    if (c->format == 0)
+        return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->cols > 0)
+        HIP_TRY(hipMemcpyAsync(c->d_x, x, (size_t) c->cols * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_set_y(spmv_hip_ctx * c, const double * y)
+{
+    if (!c || !y)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx/y null");
+    if (c->format == 0)
+        return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->rows > 0)
+        HIP_TRY(hipMemcpyAsync(c->d_y, y, (size_t) c->rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_get_y(spmv_hip_ctx * c, double * y)
+{
+    if (!c || !y)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx/y null");
+    if (c->format == 0)
+        return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->rows > 0)
+        HIP_TRY(hipMemcpyAsync(y, c->d_y, (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_run(spmv_hip_ctx * c)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->format == 0)
+        return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int rc = SPMV_HIP_OK;
+    switch (c->format) {
+    case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 2: rc = spmv_hip_coo_spmv(c->rows, c->nnz, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 3: rc = spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    }
+    if (rc != 0)
+        return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_sync(spmv_hip_ctx * c)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_last_run_ns(spmv_hip_ctx * c, uint64_t * kernel_ns)
+{
+    if (!c || !kernel_ns)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
+    if (!c->timed)
+        return fail(SPMV_HIP_ERR_STATE, "no run recorded");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *kernel_ns = (uint64_t) (ms * 1.0e6 + 0.5);
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
+{
+    if (!c || !out || n < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
+    int64_t v[10] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes};
+    if (c->plan) {
+        v[4] = c->plan->algorithm;
+        v[5] = c->plan->lanes_per_row;
+        v[6] = c->plan->workgroups;
+        v[7] = c->plan->nblk;
+        v[8] = c->plan->long_blocks;
+        v[9] += (int64_t) c->plan->meta_bytes;
+    }
+    for (int i = 0; i < n && i < 10; ++i)
+        out[i] = v[i];
+    return SPMV_HIP_OK;
+}
+
+} // extern "C"

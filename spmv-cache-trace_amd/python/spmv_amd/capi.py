@@ -1,0 +1,235 @@
+"""ctypes binding of include/spmv_hip.h (the C ABI of libspmv_hip.so).
+
+This is plumbing: it loads the in-tree shared library and turns negative return
+codes into ``SpmvHipError``.  There is deliberately no fallback of any kind: if
+the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(PKG_ROOT, "libspmv_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
+CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE = 0, 1, 2, 3
+FLAG_NO_XCD_REMAP, FLAG_EXACT_ORDER = 0x1, 0x2
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/spmv_hip.h declares
+SIGNATURES = {
+    "spmv_hip_version": (C.c_int, []),
+    "spmv_hip_strerror": (C.c_char_p, [C.c_int]),
+    "spmv_hip_last_error": (C.c_char_p, []),
+    "spmv_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "spmv_hip_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_uint]),
+    "spmv_hip_destroy": (None, [_vp]),
+    "spmv_hip_set_csr_algorithm": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "spmv_hip_upload_csr": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
+    "spmv_hip_upload_coo": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
+    "spmv_hip_upload_ell": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _f64p]),
+    "spmv_hip_set_x": (C.c_int, [_vp, _f64p]),
+    "spmv_hip_set_y": (C.c_int, [_vp, _f64p]),
+    "spmv_hip_get_y": (C.c_int, [_vp, _f64p]),
+    "spmv_hip_run": (C.c_int, [_vp]),
+    "spmv_hip_sync": (C.c_int, [_vp]),
+    "spmv_hip_last_run_ns": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
+    "spmv_hip_plan_csr": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _i32p, C.c_int, C.c_int, C.c_uint]),
+    "spmv_hip_plan_destroy": (None, [_vp]),
+    "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
+    "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_coo_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_ell_to_column_major": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_ell_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class SpmvHipError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__("%s (%d): %s" % (what, code, detail))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libspmv_hip.so (in-tree).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not found: build it with `make -C %s lib` (there is no CPU fallback)"
+                % (LIB_PATH, PKG_ROOT))
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        lib = load()
+        raise SpmvHipError(rc, lib.spmv_hip_strerror(rc).decode(), lib.spmv_hip_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().spmv_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+_EMPTY_I32 = np.zeros(1, dtype=np.int32)
+_EMPTY_F64 = np.zeros(1, dtype=np.float64)
+
+
+class Context:
+    """Level-1 API: host arrays in, host arrays out (what the C++ adapters use)."""
+
+    def __init__(self, device=0, flags=0):
+        self.lib = load()
+        h = _vp()
+        check(self.lib.spmv_hip_create(C.byref(h), device, flags))
+        self.h = h
+        self.rows = self.cols = 0
+
+    def close(self):
+        if self.h:
+            self.lib.spmv_hip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_csr_algorithm(self, algorithm, lanes_per_row=0):
+        check(self.lib.spmv_hip_set_csr_algorithm(self.h, algorithm, lanes_per_row))
+
+    def upload_csr(self, rows, cols, row_ptr, col, val):
+        row_ptr, col, val = _i32(row_ptr), _i32(col), _f64(val)
+        nnz = int(row_ptr[rows]) if len(row_ptr) > rows else -1
+        if len(col) == 0:
+            col, val = _EMPTY_I32, _EMPTY_F64
+        check(self.lib.spmv_hip_upload_csr(self.h, rows, cols, nnz, row_ptr, col, val))
+        self.rows, self.cols = rows, cols
+
+    def upload_coo(self, rows, cols, row_idx, col, val):
+        row_idx, col, val = _i32(row_idx), _i32(col), _f64(val)
+        nnz = len(val)
+        if nnz == 0:
+            row_idx, col, val = _EMPTY_I32, _EMPTY_I32, _EMPTY_F64
+        check(self.lib.spmv_hip_upload_coo(self.h, rows, cols, nnz, row_idx, col, val))
+        self.rows, self.cols = rows, cols
+
+    def upload_ell(self, rows, cols, row_length, col, val):
+        col, val = _i32(col), _f64(val)
+        if len(col) == 0:
+            col, val = _EMPTY_I32, _EMPTY_F64
+        check(self.lib.spmv_hip_upload_ell(self.h, rows, cols, row_length, col, val))
+        self.rows, self.cols = rows, cols
+
+    def set_x(self, x):
+        x = _f64(x)
+        assert len(x) == self.cols
+        check(self.lib.spmv_hip_set_x(self.h, x if len(x) else _EMPTY_F64))
+
+    def set_y(self, y):
+        y = _f64(y)
+        assert len(y) == self.rows
+        check(self.lib.spmv_hip_set_y(self.h, y if len(y) else _EMPTY_F64))
+
+    def get_y(self):
+        y = np.zeros(max(1, self.rows))
+        check(self.lib.spmv_hip_get_y(self.h, y))
+        return y[:self.rows]
+
+    def run(self, runs=1, sync=True):
+        for _ in range(runs):
+            check(self.lib.spmv_hip_run(self.h))
+        if sync:
+            check(self.lib.spmv_hip_sync(self.h))
+
+    def last_run_ns(self):
+        ns = C.c_uint64(0)
+        check(self.lib.spmv_hip_last_run_ns(self.h, C.byref(ns)))
+        return ns.value
+
+    def info(self):
+        out = np.zeros(10, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 10))
+        keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
+                "row_blocks", "long_blocks", "device_bytes"]
+        return dict(zip(keys, out.tolist()))
+
+
+class CsrPlan:
+    """Level-2 launch plan for caller-owned device arrays (torch tensors)."""
+
+    def __init__(self, rows, cols, host_row_ptr, algorithm=CSR_AUTO, lanes_per_row=0, flags=0):
+        self.lib = load()
+        h = _vp()
+        check(self.lib.spmv_hip_plan_csr(C.byref(h), rows, cols, _i32(host_row_ptr), algorithm,
+                                         lanes_per_row, flags))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.spmv_hip_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        out = np.zeros(8, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 8))
+        keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
+                "nnz", "meta_bytes"]
+        return dict(zip(keys, out.tolist()))
+
+    def spmv(self, d_row_ptr, d_col, d_val, d_x, d_y, stream=0):
+        """All arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""
+        check(self.lib.spmv_hip_csr_spmv(self.h, d_row_ptr, d_col, d_val, d_x, d_y, stream))
+
+
+def coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream=0):
+    check(load().spmv_hip_coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream))
+
+
+def ell_to_column_major(rows, row_length, d_col_rm, d_val_rm, d_col_cm, d_val_cm, stream=0):
+    check(load().spmv_hip_ell_to_column_major(rows, row_length, d_col_rm, d_val_rm, d_col_cm,
+                                              d_val_cm, stream))
+
+
+def ell_spmv(rows, row_length, d_col_cm, d_val_cm, d_x, d_y, stream=0):
+    check(load().spmv_hip_ell_spmv(rows, row_length, d_col_cm, d_val_cm, d_x, d_y, stream))

@@ -1,0 +1,160 @@
+"""Synthetic sparse matrices of SURVEY.md 8(d), generated straight into CSR.
+
+All generators return ``(rows, cols, row_ptr[int32], col_idx[int32], val[f64])``
+with column indices ascending inside each row (what the reference's CSR
+converter produces after its row-major sort, src/matrix/csr-matrix.cpp:200-237).
+They are deterministic: same arguments, same arrays.
+"""
+import numpy as np
+
+
+def poisson2d(n):
+    """5-point stencil on an n x n grid: N = n*n rows, Z = 5N - 4n entries.
+
+    Row r = i*n + j has columns {r-n, r-1, r, r+1, r+n} where the neighbour
+    exists on the grid, values {-1, -1, 4, -1, -1}.  n = 4096 is BASELINE.json's
+    configs[1] (Z = 83 869 696).
+    """
+    N = n * n
+    r = np.arange(N, dtype=np.int32)
+    j = r % n
+    i = r // n
+    off = np.array([-n, -1, 0, 1, n], dtype=np.int32)
+    cols = r[:, None] + off[None, :]
+    mask = np.empty((N, 5), dtype=bool)
+    mask[:, 0] = i > 0
+    mask[:, 1] = j > 0
+    mask[:, 2] = True
+    mask[:, 3] = j < n - 1
+    mask[:, 4] = i < n - 1
+    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(mask.sum(axis=1), out=row_ptr[1:])
+    col_idx = cols[mask]
+    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), (N, 5))[mask]
+    return N, N, row_ptr.astype(np.int32), np.ascontiguousarray(col_idx, dtype=np.int32), \
+        np.ascontiguousarray(vals, dtype=np.float64)
+
+
+def banded(N, offsets, seed=1):
+    """N x N matrix with one diagonal per entry of `offsets`, values U(-1,1)."""
+    rng = np.random.default_rng(seed)
+    off = np.array(sorted(set(int(o) for o in offsets)), dtype=np.int64)
+    r = np.arange(N, dtype=np.int64)
+    cols = r[:, None] + off[None, :]
+    mask = (cols >= 0) & (cols < N)
+    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(mask.sum(axis=1), out=row_ptr[1:])
+    col_idx = cols[mask].astype(np.int32)
+    vals = rng.uniform(-1.0, 1.0, size=col_idx.shape[0])
+    return N, N, row_ptr.astype(np.int32), col_idx, vals
+
+
+def stencil27_like(nx, ny, nz, seed=2):
+    """27-point stencil on an nx*ny*nz grid (nlpkkt-like: ~27 entries per row,
+    three bands of bands).  Used as the stand-in for configs[3] (nlpkkt200),
+    whose file cannot be fetched here."""
+    N = nx * ny * nz
+    offs = [dz * nx * ny + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    return banded(N, offs, seed=seed)
+
+
+def random_uniform(N, M, k, seed=3):
+    """k distinct uniformly random columns per row (sorted), values U(-1,1)."""
+    rng = np.random.default_rng(seed)
+    k = min(k, M)
+    # sample with a random start + distinct strides to stay vectorised, then
+    # fall back to per-row choice only for tiny M where collisions are likely
+    if M >= 4 * k:
+        cols = rng.integers(0, M, size=(N, k), dtype=np.int64)
+        cols.sort(axis=1)
+        # resolve duplicates by nudging (keeps sortedness, stays in range)
+        for _ in range(8):
+            dup = np.zeros_like(cols, dtype=bool)
+            dup[:, 1:] = cols[:, 1:] <= cols[:, :-1]
+            if not dup.any():
+                break
+            cols[dup] = cols[dup] + 1
+            cols = np.minimum(cols, M - 1)
+            cols.sort(axis=1)
+        keep = np.ones_like(cols, dtype=bool)
+        keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    else:
+        cols = np.stack([np.sort(rng.choice(M, size=k, replace=False)) for _ in range(N)])
+        keep = np.ones_like(cols, dtype=bool)
+    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(keep.sum(axis=1), out=row_ptr[1:])
+    col_idx = cols[keep].astype(np.int32)
+    vals = rng.uniform(-1.0, 1.0, size=col_idx.shape[0])
+    return N, M, row_ptr.astype(np.int32), col_idx, vals
+
+
+def powerlaw(N, M, alpha=1.8, max_len=4700, seed=4, mean_target=3.1):
+    """webbase-like: row lengths ~ Zipf(alpha) capped at max_len, random columns.
+    Includes empty rows and a few very long rows."""
+    rng = np.random.default_rng(seed)
+    lens = rng.zipf(alpha, size=N).astype(np.int64)
+    lens = np.minimum(lens, min(max_len, M))
+    # thin to roughly the requested mean, keep some empty rows
+    scale = mean_target / max(lens.mean(), 1e-9)
+    if scale < 1.0:
+        lens = np.floor(lens * scale + rng.uniform(0, 1, size=N)).astype(np.int64)
+    lens[rng.integers(0, N, size=max(1, N // 50))] = 0
+    if N > 10:
+        lens[rng.integers(0, N, size=3)] = min(max_len, M)
+    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=row_ptr[1:])
+    Z = int(row_ptr[-1])
+    # random columns, sorted inside each row; duplicate (row, col) pairs may
+    # occur and are kept (the reference keeps duplicates too)
+    rows_of = np.repeat(np.arange(N, dtype=np.int64), lens)
+    rc = rng.integers(0, M, size=Z, dtype=np.int64)
+    order = np.lexsort((rc, rows_of))
+    col_idx = rc[order].astype(np.int32)
+    vals = rng.uniform(-1.0, 1.0, size=Z)
+    return N, M, row_ptr.astype(np.int32), col_idx, vals
+
+
+def x_vector(M, kind="uniform", seed=12345):
+    """`ones` is what the reference CLI multiplies by (src/kernels/csr-spmv.cpp:35);
+    `uniform` is the meaningful parity input."""
+    if kind == "ones":
+        return np.ones(M)
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, size=M)
+
+
+def csr_to_coordinate(rows, row_ptr, col_idx, val):
+    """1-based coordinate triplets in row-major order."""
+    lens = np.diff(row_ptr.astype(np.int64))
+    i = np.repeat(np.arange(1, rows + 1, dtype=np.int32), lens)
+    return i, (col_idx + 1).astype(np.int32), val
+
+
+def write_mtx(path, rows, cols, i, j, a, field="real", symmetry="general", comments=()):
+    """Write coordinate entries as a Matrix Market file (17 significant digits)."""
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n" % (field, symmetry))
+        for c in comments:
+            f.write("%" + c + "\n")
+        f.write("%d %d %d\n" % (rows, cols, len(i)))
+        if field == "pattern":
+            for r, c in zip(i, j):
+                f.write("%d %d\n" % (r, c))
+        elif field == "integer":
+            for r, c, v in zip(i, j, a):
+                f.write("%d %d %d\n" % (r, c, int(v)))
+        else:
+            for r, c, v in zip(i, j, a):
+                f.write("%d %d %.17g\n" % (r, c, v))
+
+
+def csr_bytes(rows, cols, nnz):
+    """Algorithmic bytes of one CSR y += A*x (SURVEY 8d / BASELINE.md 3)."""
+    return 12 * nnz + 4 * (rows + 1) + 16 * rows + 8 * cols
+
+
+def coo_bytes(rows, cols, nnz):
+    return 16 * nnz + 16 * rows + 8 * cols
+
+
+def ell_bytes(rows, cols, row_length):
+    return 12 * rows * row_length + 16 * rows + 8 * cols

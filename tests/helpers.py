@@ -1,0 +1,104 @@
+"""Shared helpers for the tests: golden-fixture loading, tolerances, small parsers."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# BASELINE.json: "y within 1e-10 relative of CPU reference".  Paths that add a row's
+# products in the reference's order must be bit-exact instead (tolerance 0).
+RTOL = 1e-10
+
+
+def unhex(a):
+    return np.array([float.fromhex(s) for s in a], dtype=np.float64)
+
+
+def load_golden():
+    g = {}
+    g["kat"] = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    ref = json.load(open(os.path.join(GOLDEN, "ref_vectors.json")))
+    g["cases"] = ref["cases"]
+    g["print_sample"] = ref["print_sample"]
+    g["poisson2D_mtx"] = open(os.path.join(GOLDEN, "poisson2D.mtx")).read()
+    g["poisson2D_b"] = np.array([float(t) for t in open(os.path.join(GOLDEN, "poisson2D_b.txt")).read().split()])
+    g["poisson2D_result"] = np.array(
+        [float(t) for t in open(os.path.join(GOLDEN, "poisson2D_result.txt")).read().split()])
+    return g
+
+
+def case_mtx(g, case):
+    return g["poisson2D_mtx"] if case["mtx"] == "@poisson2D.mtx" else case["mtx"]
+
+
+def parse_mtx_text(text):
+    """Tiny Matrix Market reader for test inputs (coordinate only): the pure-Python
+    oracle of the loader's accept set.  Returns rows, cols, i, j, a (1-based; values per
+    reference src/matrix/matrix-market.cpp:243-277: complex -> real part, pattern -> 1.0)."""
+    lines = text.split("\n")
+    hdr = lines[0].split()
+    assert hdr[0] == "%%MatrixMarket" and hdr[1].lower() == "matrix" and hdr[2].lower() == "coordinate"
+    field = hdr[3].lower()
+    k = 1
+    while lines[k].startswith("%"):
+        k += 1
+    rows, cols, n = (int(t) for t in lines[k].split()[:3])
+    toks = " ".join(lines[k + 1:]).split()
+    per = {"real": 3, "integer": 3, "complex": 4, "pattern": 2}[field]
+    i = np.array([int(toks[per * e]) for e in range(n)], dtype=np.int32)
+    j = np.array([int(toks[per * e + 1]) for e in range(n)], dtype=np.int32)
+    if field == "pattern":
+        a = np.ones(n)
+    else:
+        a = np.array([float(toks[per * e + 2]) for e in range(n)], dtype=np.float64)
+    return rows, cols, i, j, a, field, hdr[4].lower()
+
+
+def abs_products(rows, row_ptr, col, val, x):
+    """(|A||x|)_i: the scale a reordered sum's rounding error is proportional to."""
+    lens = np.diff(np.asarray(row_ptr, dtype=np.int64))
+    r = np.repeat(np.arange(rows), lens)
+    out = np.zeros(rows)
+    np.add.at(out, r, np.abs(val) * np.abs(x[col]))
+    return out
+
+
+def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what=""):
+    """Tolerance of BASELINE.json (1e-10 relative): norm-wise, and per row against
+    the magnitude of the products that were summed."""
+    y_gpu = np.asarray(y_gpu)
+    y_cpu = np.asarray(y_cpu)
+    assert y_gpu.shape == y_cpu.shape, what
+    if y_cpu.size == 0:
+        return
+    err = np.abs(y_gpu - y_cpu)
+    ninf = np.max(np.abs(y_cpu))
+    assert np.max(err) <= rtol * max(ninf, np.finfo(float).tiny), \
+        "%s: inf-norm rel err %.3e" % (what, np.max(err) / max(ninf, 1e-300))
+    n2 = np.linalg.norm(y_cpu)
+    assert np.linalg.norm(y_gpu - y_cpu) <= rtol * max(n2, np.finfo(float).tiny), what
+    if scale is not None:
+        bound = rtol * np.maximum(scale, np.abs(y_cpu)) + 1e-300
+        bad = np.nonzero(err > bound)[0]
+        assert bad.size == 0, "%s: %d rows off, first %d: gpu=%r cpu=%r" % (
+            what, bad.size, bad[0], y_gpu[bad[0]], y_cpu[bad[0]])
+
+
+def assert_bitexact(y_gpu, y_cpu, what=""):
+    y_gpu = np.ascontiguousarray(y_gpu, dtype=np.float64)
+    y_cpu = np.ascontiguousarray(y_cpu, dtype=np.float64)
+    assert y_gpu.shape == y_cpu.shape, what
+    same = y_gpu.view(np.uint64) == y_cpu.view(np.uint64)
+    if not same.all():
+        k = int(np.nonzero(~same)[0][0])
+        raise AssertionError("%s: %d of %d values differ bitwise, first at %d: %r vs %r" % (
+            what, int((~same).sum()), same.size, k, y_gpu[k].hex(), y_cpu[k].hex()))
+
+
+def have_gpu():
+    try:
+        from spmv_amd import capi
+        return capi.device_count() > 0
+    except Exception:
+        return False
