@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X SpMV path.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path, y += A*x, over the workload with all inputs
+already resident in HBM.  Workload (BASELINE.json configs[1]): Poisson 5-point stencil
+CSR on a 4096 x 4096 grid, N = 16 777 216 rows, Z = 83 869 696 stored entries, fp64
+values / int32 indices.  With N > 1 GPUs the SAME matrix is row-partitioned
+(ceil(rows/N) rows per rank, the reference's static chunk rule), x is replicated, and
+every step ends with ONE all-gather of the y segments (RCCL): total work is fixed, so
+scaling is "strong".
+
+Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).
+`roofline` prices the local SpMV kernel: algorithmic bytes of one launch
+(CSR: 12*Z + 4*(rows+1) + 16*rows + 8*cols, BASELINE.md section 3, for the rank's row
+slice) divided by its mean duration measured with HIP events on the launch stream.
+`cpu_baseline` (rank 0, N = 1 only) times the reference's own OpenMP CSR kernel
+(oracle/_ref, kind "reference") or the C oracle (kind "port") on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "stencil27", "random"])
+    ap.add_argument("--grid", type=int, default=4096, help="poisson2d grid edge (4096 = BASELINE configs[1])")
+    ap.add_argument("--algorithm", default="auto", choices=["auto", "scalar", "vector", "adaptive"])
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-xcd-remap", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores visible to this process")
+    ap.add_argument("--no-parity-check", action="store_true")
+    return ap.parse_args()
+
+
+def make_rows(args, begin, end):
+    """This rank's rows [begin, end) of the workload, plus global sizes."""
+    from spmv_amd import synth, partition
+    if args.workload == "poisson2d":
+        n = args.grid
+        rows = n * n
+        nr, cols, p, c, v = synth.poisson2d(n, begin, rows if end is None else end)
+        return rows, cols, 5 * rows - 4 * n, p, c, v, "poisson2d-5pt-%dx%d-csr" % (n, n)
+    if args.workload == "stencil27":
+        # nlpkkt200-like stand-in (configs[3]): 27-point stencil, ~16.2M rows, ~436M entries
+        rows, cols, p, c, v = synth.stencil27_like(253, 253, 253)
+        name = "stencil27-253^3-csr"
+    else:
+        rows, cols, p, c, v = synth.random_uniform(4000000, 4000000, 24, seed=3)
+        name = "random-4M-24perrow-csr"
+    nnz = int(p[-1])
+    if end is not None:
+        p, c, v = partition.csr_slice(p, c, v, begin, end)
+    return rows, cols, nnz, p, c, v, name
+
+
+def cpu_baseline(args, rows, cols, p, c, v, x):
+    """Reference OpenMP CSR kernel (or the C oracle) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    nnz = int(p[-1])
+    budget = args.cpu_seconds
+    if oracle_py.RefLib.available():
+        R = oracle_py.RefLib()
+        A = R.csr_from_arrays(rows, cols, p, c, v)
+        t = time.perf_counter()
+        ns, _ = R.csr_spmv_timed(A, x, threads, 2)  # 1 warm-up + 2 timed, to size the sample
+        per = max(float(np.median(ns)) * 1e-9, 1e-4)
+        runs = int(max(3, min(200, (budget - (time.perf_counter() - t)) / per)))
+        ns, _ = R.csr_spmv_timed(A, x, threads, runs)
+        R.csr_free(A)
+        kind = "reference"
+    else:
+        O = oracle_py.Oracle()
+        y = np.zeros(rows)
+        O.csr_spmv_inplace(rows, p, c, v, x, y, threads)  # warm-up
+        ns = []
+        t_end = time.perf_counter() + budget
+        while len(ns) < 3 or (time.perf_counter() < t_end and len(ns) < 200):
+            t0 = time.perf_counter_ns()
+            O.csr_spmv_inplace(rows, p, c, v, x, y, threads)
+            ns.append(time.perf_counter_ns() - t0)
+        ns = np.array(ns)
+        kind = "port"
+    med = float(np.median(ns)) * 1e-9
+    return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
+            "sample": "full workload, %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
+                      % (len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
+            "gbs": round((12.0 * nnz + 4 * (rows + 1) + 16.0 * rows + 8.0 * cols) / med / 1e9, 2)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from spmv_amd import capi, partition, synth
+    from spmv_amd.distributed import DistributedCsrSpmv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; this benchmark has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- workload: this rank's rows, global x ------------------------------------------
+    t_setup = time.perf_counter()
+    if args.workload == "poisson2d":
+        rows = args.grid * args.grid
+    else:
+        rows = None
+    if rows is not None and world > 1:
+        begin, end = partition.row_range(rows, rank, world)
+        rows, cols, nnz, p, c, v, wname = make_rows(args, begin, end)
+    elif world > 1:
+        rows_g, cols, nnz, p, c, v, wname = make_rows(args, 0, None)
+        begin, end = partition.row_range(rows_g, rank, world)
+        p, c, v = partition.csr_slice(p, c, v, begin, end)
+        rows = rows_g
+    else:
+        rows, cols, nnz, p, c, v, wname = make_rows(args, 0, None)
+        begin, end = 0, rows
+    x = synth.x_vector(cols, "uniform", seed=12345)
+    algo = {"auto": capi.CSR_AUTO, "scalar": capi.CSR_SCALAR, "vector": capi.CSR_VECTOR,
+            "adaptive": capi.CSR_ADAPTIVE}[args.algorithm]
+    flags = capi.FLAG_NO_XCD_REMAP if args.no_xcd_remap else 0
+    op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags)
+    local_rows, local_nnz = end - begin, int(p[-1])
+    local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    # ---- parity gate (rank-local rows against the oracle, as a checker) ------------------
+    parity = None
+    if not args.no_parity_check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py
+        O = oracle_py.Oracle()
+        op.multiply_local()
+        torch.cuda.synchronize()
+        lo = local_rows // 3
+        hi = min(local_rows, lo + 200000)
+        ps, cs, vs = partition.csr_slice(p, c, v, lo, hi)
+        want = O.csr_spmv(hi - lo, ps, cs, vs, x, num_threads=4)
+        got = op.y_local[lo:hi].cpu().numpy()
+        err = float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300))
+        if not err <= 1e-10:
+            sys.exit("bench.py: parity check failed on rank %d: rel err %.3e" % (rank, err))
+        parity = {"rows_checked": hi - lo, "max_rel_err": err, "bitexact": bool(np.array_equal(got, want))}
+        op.y_local.zero_()
+
+    # ---- warm-up, then K timed steps -------------------------------------------------------
+    for _ in range(args.warmup):
+        op.step()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev0[k].record()
+        op.multiply_local()
+        ev1[k].record()
+        if world > 1:
+            op.gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+
+    stats = torch.tensor([elapsed, float(kernel_ms.mean())], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    elapsed_max, kern_ms_max = stats.tolist()
+
+    if rank == 0:
+        ms_per_step = elapsed_max / args.steps * 1e3
+        gflops = 2.0 * nnz * args.steps / elapsed_max / 1e9
+        kern_s = kern_ms_max * 1e-3  # slowest rank's mean launch duration
+        achieved = local_bytes / kern_s / 1e9
+        info = op.plan.info()
+        out = {
+            "metric": "spmv_csr_gflops", "value": round(gflops, 2), "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wname, "rows": rows, "cols": cols, "nnz": nnz, "format": "csr",
+                       "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
+                       "algorithm": {1: "scalar", 2: "vector", 3: "adaptive"}[info["algorithm"]],
+                       "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
+                       "partition": "rows/%d static chunks, x replicated, 1 all-gather(y)/step" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "csr_%s" % {1: "scalar", 2: "vector", 3: "adaptive"}[info["algorithm"]],
+                         "kernel_us": round(kern_s * 1e6, 2), "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2),
+                         "algorithmic_bytes_per_launch": int(local_bytes),
+                         "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)},
+            "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
+            "setup_s": round(setup_s, 1),
+        }
+        if parity:
+            out["parity"] = parity
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, rows, cols, p, c, v, x)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,31 @@ class SpmvHipError(RuntimeError):
 
 
 _lib = None
+hip_runtime_path = None  # which libamdhip64 the process ended up with (diagnostic)
+
+
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and
+    ask for it by file name, so a process that first loads /opt/rocm's copy through
+    libspmv_hip.so and then imports torch ends up with TWO HIP runtimes, and the second
+    one sees no GPU.  Loading torch's copy first makes the dynamic loader satisfy our
+    DT_NEEDED libamdhip64.so.7 with it (SONAME match), and torch later finds the same
+    file already mapped.  Set SPMV_HIP_RUNTIME=system to skip this (no torch in the
+    process)."""
+    global hip_runtime_path
+    if os.environ.get("SPMV_HIP_RUNTIME", "torch") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        hip_runtime_path = cand
 
 
 def load():
@@ -69,6 +94,7 @@ def load():
             raise FileNotFoundError(
                 "%s not found: build it with `make -C %s lib` (there is no CPU fallback)"
                 % (LIB_PATH, PKG_ROOT))
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -1,0 +1,75 @@
+"""Row-partitioned SpMV across ranks: one process per GPU, one all-gather of the
+y segments per multiply (RCCL over xGMI when the process group is "nccl").
+
+    rank g:   y_g += A[rows_g, :] @ x            (HIP kernel, local rows only)
+    all:      y = all_gather(y_0, ..., y_{G-1})  (the only collective on the path)
+
+The partition rule is the reference's static row chunking (partition.row_range).
+Segments are padded to the common chunk length so the collective is a plain
+equal-count all-gather; because chunks are contiguous and only the last one is
+short, the first `rows` entries of the gathered buffer are y itself.
+
+The local multiply is injected (``local_spmv``) so the partition / gather logic can
+be exercised with gloo on CPU tensors; the product constructor
+``DistributedCsrSpmv.on_gpu`` wires in the HIP path and has no other option.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi, partition
+
+
+class DistributedCsrSpmv:
+    def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None):
+        self.rows, self.cols = rows, cols
+        self.rank, self.world = rank, world
+        self.chunk = partition.row_chunk(rows, world)
+        self.begin, self.end = partition.row_range(rows, rank, world)
+        assert local_rows == self.end - self.begin
+        self.device = device
+        self.group = group
+        self.local_spmv = local_spmv
+        # padded local segment and the gathered vector (world * chunk >= rows)
+        self.y_local = torch.zeros(self.chunk, dtype=torch.float64, device=device)
+        self.y_full = torch.zeros(self.chunk * world, dtype=torch.float64, device=device)
+
+    @classmethod
+    def on_gpu(cls, rows, cols, rank, world, device, p_local, c_local, v_local, x_host,
+               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None):
+        """Product path: local slice uploaded to `device`, multiplied by the HIP kernel
+        on torch's current stream.  Raises if the HIP library or the GPU is missing."""
+        local_rows = len(p_local) - 1
+        plan = capi.CsrPlan(local_rows, cols, p_local, algorithm, lanes_per_row, flags)
+        tp = torch.from_numpy(np.ascontiguousarray(p_local, dtype=np.int32)).to(device)
+        tc = torch.from_numpy(np.ascontiguousarray(c_local, dtype=np.int32)).to(device)
+        tv = torch.from_numpy(np.ascontiguousarray(v_local, dtype=np.float64)).to(device)
+        tx = torch.from_numpy(np.ascontiguousarray(x_host, dtype=np.float64)).to(device)
+
+        def local_spmv(y_local):
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_local.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+
+        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group)
+        self.plan = plan
+        self._keep = (tp, tc, tv, tx)
+        return self
+
+    def multiply_local(self):
+        """y_local += A_local @ x (enqueue only)."""
+        self.local_spmv(self.y_local)
+
+    def gather(self):
+        """The one collective of the path: equal-count all-gather of the y segments."""
+        if self.world == 1:
+            self.y_full.copy_(self.y_local)
+        else:
+            dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
+
+    def step(self):
+        self.multiply_local()
+        self.gather()
+
+    def y(self):
+        """The assembled y (first `rows` entries of the gathered buffer)."""
+        return self.y_full[:self.rows]

@@ -8,30 +8,35 @@ They are deterministic: same arguments, same arrays.
 import numpy as np
 
 
-def poisson2d(n):
+def poisson2d(n, row_begin=0, row_end=None):
     """5-point stencil on an n x n grid: N = n*n rows, Z = 5N - 4n entries.
 
     Row r = i*n + j has columns {r-n, r-1, r, r+1, r+n} where the neighbour
     exists on the grid, values {-1, -1, 4, -1, -1}.  n = 4096 is BASELINE.json's
-    configs[1] (Z = 83 869 696).
+    configs[1] (Z = 83 869 696).  With row_begin/row_end only that row range is
+    generated (row_ptr rebased to 0, column indices still global): one rank's
+    partition of the matrix.
     """
     N = n * n
-    r = np.arange(N, dtype=np.int32)
+    if row_end is None:
+        row_end = N
+    r = np.arange(row_begin, row_end, dtype=np.int32)
+    nr = len(r)
     j = r % n
     i = r // n
     off = np.array([-n, -1, 0, 1, n], dtype=np.int32)
     cols = r[:, None] + off[None, :]
-    mask = np.empty((N, 5), dtype=bool)
+    mask = np.empty((nr, 5), dtype=bool)
     mask[:, 0] = i > 0
     mask[:, 1] = j > 0
     mask[:, 2] = True
     mask[:, 3] = j < n - 1
     mask[:, 4] = i < n - 1
-    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    row_ptr = np.zeros(nr + 1, dtype=np.int64)
     np.cumsum(mask.sum(axis=1), out=row_ptr[1:])
     col_idx = cols[mask]
-    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), (N, 5))[mask]
-    return N, N, row_ptr.astype(np.int32), np.ascontiguousarray(col_idx, dtype=np.int32), \
+    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0]), (nr, 5))[mask]
+    return nr, N, row_ptr.astype(np.int32), np.ascontiguousarray(col_idx, dtype=np.int32), \
         np.ascontiguousarray(vals, dtype=np.float64)
 
 

@@ -1,0 +1,366 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X.
+
+Bars (BASELINE.json / north_star): y within 1e-10 relative of the CPU reference;
+paths that keep the reference's summation order (CSR scalar, CSR adaptive with one
+lane per row, ELL) must be BIT-EXACT.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import unhex, assert_bitexact, assert_close, abs_products
+from spmv_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = [("scalar", capi.CSR_SCALAR, 0), ("vector2", capi.CSR_VECTOR, 2), ("vector8", capi.CSR_VECTOR, 8),
+         ("vector64", capi.CSR_VECTOR, 64), ("vector_auto", capi.CSR_VECTOR, 0),
+         ("adaptive", capi.CSR_ADAPTIVE, 0), ("auto", capi.CSR_AUTO, 0)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_csr(ctx, rows, cols, p, c, v, x, y0=None, algo=capi.CSR_AUTO, lanes=0, runs=1):
+    ctx.set_csr_algorithm(algo, lanes)
+    ctx.upload_csr(rows, cols, p, c, v)
+    ctx.set_x(x)
+    if y0 is not None:
+        ctx.set_y(y0)
+    ctx.run(runs)
+    return ctx.get_y()
+
+
+def is_exact_class(ctx, name):
+    """Which launches keep the reference order: scalar always; adaptive when every row
+    block got one lane per row, which the kernel chooses when avg entries/row < 8."""
+    return name == "scalar"
+
+
+# ---- golden vectors (reference library outputs) -------------------------------------
+
+@pytest.mark.parametrize("aname,algo,lanes", ALGOS)
+def test_golden_csr(ctx, oracle, golden, aname, algo, lanes):
+    for case in golden["cases"]:
+        rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+        p, c, v = oracle.csr_from_coordinate(rows, i, j, a, row_alignment=case["csr"]["row_alignment"])
+        x = unhex(case["x"])
+        want = unhex(case["csr"]["y"])
+        got = gpu_csr(ctx, rows, cols, p, c, v, x, algo=algo, lanes=lanes, runs=case["runs"])
+        what = "%s/%s" % (case["name"], aname)
+        if aname == "scalar":
+            assert_bitexact(got, want, what)
+        else:
+            assert_close(got, want, abs_products(rows, p, c, v, x) * case["runs"], what=what)
+
+
+def test_golden_csr_exact_order_flag(oracle, golden):
+    """SPMV_HIP_FLAG_EXACT_ORDER: every algorithm choice collapses to reference order."""
+    c2 = capi.Context(0, flags=capi.FLAG_EXACT_ORDER)
+    try:
+        for case in golden["cases"]:
+            rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+            p, c, v = oracle.csr_from_coordinate(rows, i, j, a)
+            if case["csr"]["row_alignment"] != 1:
+                continue
+            got = gpu_csr(c2, rows, cols, p, c, v, unhex(case["x"]), algo=capi.CSR_ADAPTIVE, runs=case["runs"])
+            assert_bitexact(got, unhex(case["csr"]["y"]), case["name"] + "/exact")
+    finally:
+        c2.close()
+
+
+def test_golden_coo(ctx, oracle, golden):
+    for case in golden["cases"]:
+        if case["threads"] != 1:
+            continue  # the multi-thread vectors carry the CPU workspace recurrence
+        rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+        r, c, v = oracle.coo_from_coordinate(i, j, a)
+        x = unhex(case["x"])
+        ctx.upload_coo(rows, cols, r, c, v)
+        ctx.set_x(x)
+        ctx.run(case["runs"])
+        got = ctx.get_y()
+        scale = np.zeros(rows)
+        np.add.at(scale, r, np.abs(v * x[c]) * case["runs"])
+        assert_close(got, unhex(case["coo"]["y"]), scale, what=case["name"] + "/coo")
+
+
+def test_golden_ell_bitexact(ctx, oracle, golden):
+    for case in golden["cases"]:
+        rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+        rc, L, c, v = oracle.ell_from_coordinate(rows, i, j, a)
+        assert rc == 0
+        ctx.upload_ell(rows, cols, L, c, v)
+        ctx.set_x(unhex(case["x"]))
+        ctx.run(case["runs"])
+        assert_bitexact(ctx.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell")
+
+
+def test_reference_kats(ctx, oracle, golden):
+    k = golden["kat"]["csr_spmv"]
+    rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(k["mtx"])
+    p, c, v = oracle.csr_from_coordinate(rows, i, j, a)
+    for aname, algo, lanes in ALGOS:
+        assert gpu_csr(ctx, rows, cols, p, c, v, np.array(k["x"]), algo=algo, lanes=lanes).tolist() == k["y"]
+    for name in ("coo_spmv", "coo_spmv_column_major"):
+        k = golden["kat"][name]
+        rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(k["mtx"])
+        r, c, v = oracle.coo_from_coordinate(i, j, a)
+        ctx.upload_coo(rows, cols, r, c, v)
+        ctx.set_x(np.array(k["x"]))
+        ctx.run()
+        assert ctx.get_y().tolist() == k["y"]
+    k = golden["kat"]["ell_spmv"]
+    rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(k["mtx"])
+    rc, L, c, v = oracle.ell_from_coordinate(rows, i, j, a)
+    ctx.upload_ell(rows, cols, L, c, v)
+    ctx.set_x(np.array(k["x"]))
+    ctx.run()
+    assert ctx.get_y().tolist() == k["y"]
+
+
+def test_poisson2d_reference_tolerance(ctx, oracle, golden):
+    """The reference's own check: l2norm(y - z) <= DBL_EPSILON on FEMLAB/poisson2D."""
+    rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(golden["poisson2D_mtx"])
+    p, c, v = oracle.csr_from_coordinate(rows, i, j, a)
+    z = golden["poisson2D_result"]
+    for aname, algo, lanes in ALGOS:
+        y = gpu_csr(ctx, rows, cols, p, c, v, golden["poisson2D_b"], algo=algo, lanes=lanes)
+        assert np.sqrt(np.dot(y - z, y - z)) <= np.finfo(float).eps, aname
+
+
+# ---- seeded synthetic inputs vs the oracle --------------------------------------------
+
+SYNTH = [
+    ("poisson64", lambda: synth.poisson2d(64)),
+    ("poisson512", lambda: synth.poisson2d(512)),
+    ("banded", lambda: synth.banded(100003, [-4097, -300, -2, -1, 0, 1, 2, 300, 4097], seed=1)),
+    ("random16", lambda: synth.random_uniform(50000, 70001, 16, seed=2)),
+    ("random80", lambda: synth.random_uniform(20011, 20011, 80, seed=3)),
+    ("powerlaw", lambda: synth.powerlaw(200000, 200000, seed=4)),
+    ("stencil27", lambda: synth.stencil27_like(40, 37, 33, seed=5)),
+    ("longrows", lambda: synth.random_uniform(37, 100000, 5000, seed=6)),
+]
+
+
+@pytest.mark.parametrize("name,gen", SYNTH)
+def test_synthetic_csr_all_algorithms(ctx, oracle, name, gen):
+    rows, cols, p, c, v = gen()
+    x = synth.x_vector(cols)
+    y0 = synth.x_vector(rows, seed=99)  # non-zero start: the kernels accumulate
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
+    scale = 2 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    for aname, algo, lanes in ALGOS:
+        got = gpu_csr(ctx, rows, cols, p, c, v, x, y0=y0, algo=algo, lanes=lanes, runs=2)
+        if aname == "scalar":
+            assert_bitexact(got, want, name + "/" + aname)
+        else:
+            assert_close(got, want, scale, what=name + "/" + aname)
+
+
+@pytest.mark.parametrize("name,gen", SYNTH[:2] + SYNTH[5:6])
+def test_adaptive_short_rows_bitexact(ctx, oracle, name, gen):
+    """Row blocks whose rows average < 8 entries get one lane per row, i.e. the reference's
+    left-to-right order: poisson (5/row) must be bit-exact; powerlaw is only where all its
+    blocks are short, so it is checked with the exact-order flag."""
+    rows, cols, p, c, v = gen()
+    x = synth.x_vector(cols)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=2)
+    if name.startswith("poisson"):
+        assert_bitexact(gpu_csr(ctx, rows, cols, p, c, v, x, algo=capi.CSR_ADAPTIVE), want, name)
+    c2 = capi.Context(0, flags=capi.FLAG_EXACT_ORDER)
+    try:
+        assert_bitexact(gpu_csr(c2, rows, cols, p, c, v, x, algo=capi.CSR_ADAPTIVE), want, name + "/exact")
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("name,gen", SYNTH[:1] + SYNTH[3:4] + SYNTH[5:6])
+def test_synthetic_coo_sorted_and_shuffled(ctx, oracle, name, gen):
+    rows, cols, p, c, v = gen()
+    x = synth.x_vector(cols)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    r = (i - 1).astype(np.int32)
+    scale = abs_products(rows, p, c, v, x)
+    for order in ("sorted", "shuffled"):
+        perm = np.arange(len(a)) if order == "sorted" else np.random.default_rng(1).permutation(len(a))
+        rr, cc, vv = r[perm], c[perm], v[perm]
+        want = oracle.coo_spmv(rows, rr, cc, vv, x)
+        ctx.upload_coo(rows, cols, rr, cc, vv)
+        ctx.set_x(x)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what="%s/coo/%s" % (name, order))
+
+
+@pytest.mark.parametrize("name,gen", SYNTH[:2] + SYNTH[2:4] + SYNTH[6:7])
+def test_synthetic_ell_bitexact(ctx, oracle, name, gen):
+    rows, cols, p, c, v = gen()
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+    assert rc == 0
+    x = synth.x_vector(cols)
+    y0 = synth.x_vector(rows, seed=5)
+    want = oracle.ell_spmv(rows, L, ec, ev, x, y=y0, num_threads=3, runs=2)
+    ctx.upload_ell(rows, cols, L, ec, ev)
+    ctx.set_x(x)
+    ctx.set_y(y0)
+    ctx.run(2)
+    assert_bitexact(ctx.get_y(), want, name + "/ell")
+
+
+# ---- edge cases ------------------------------------------------------------------------
+
+def test_edge_cases_csr(ctx, oracle):
+    T = 2048  # adaptive tile
+    cases = {}
+    cases["empty_matrix"] = (5, 7, np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    cases["single_entry"] = (1, 1, np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32), np.array([2.5]))
+    # many empty rows around a few full ones
+    p = np.zeros(1001, dtype=np.int32)
+    p[501:] = 3
+    p[901:] = 10
+    cases["mostly_empty"] = (1000, 11, p, np.arange(10, dtype=np.int32), np.linspace(-1, 1, 10))
+    rng = np.random.default_rng(11)
+    for L in (T - 4, T - 1, T, T + 1, 3 * T + 5):  # rows right at the tile boundary
+        lens = np.array([3, L, 2, L, 1], dtype=np.int64)
+        p = np.zeros(6, dtype=np.int32)
+        p[1:] = np.cumsum(lens)
+        cols = 4 * T
+        c = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) for n in lens]).astype(np.int32)
+        cases["tile_edge_%d" % L] = (5, cols, p, c, rng.uniform(-1, 1, len(c)))
+    for name, (rows, cols, p, c, v) in cases.items():
+        x = synth.x_vector(cols, seed=3)
+        y0 = synth.x_vector(rows, seed=4)
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0)
+        scale = abs_products(rows, p, c, v, x) + np.abs(y0) if len(v) else np.abs(y0)
+        for aname, algo, lanes in ALGOS:
+            got = gpu_csr(ctx, rows, cols, p, c, v, x, y0=y0, algo=algo, lanes=lanes)
+            if aname == "scalar":
+                assert_bitexact(got, want, name + "/" + aname)
+            else:
+                assert_close(got, want, scale, what=name + "/" + aname)
+
+
+def test_zero_rows(ctx):
+    ctx.upload_csr(0, 3, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    ctx.set_x(np.ones(3))
+    ctx.run()
+    assert ctx.get_y().shape == (0,)
+    ctx.upload_coo(4, 4, [], [], [])
+    ctx.set_x(np.ones(4))
+    ctx.run()
+    assert ctx.get_y().tolist() == [0.0] * 4
+    ctx.upload_ell(3, 3, 0, [], [])
+    ctx.set_x(np.ones(3))
+    ctx.set_y(np.array([1.0, 2.0, 3.0]))
+    ctx.run()
+    assert ctx.get_y().tolist() == [1.0, 2.0, 3.0]
+
+
+def test_errors_cross_the_abi_as_codes(ctx):
+    with pytest.raises(capi.SpmvHipError) as e:
+        ctx.upload_csr(2, 2, np.array([0, 1, 2], dtype=np.int32), np.array([0, 5], dtype=np.int32), np.ones(2))
+    assert e.value.code == capi.ERR_INVALID and "column index" in str(e.value)
+    with pytest.raises(capi.SpmvHipError) as e:
+        ctx.upload_ell(70000, 5, 40000, np.zeros(4, dtype=np.int32), np.zeros(4))
+    assert e.value.code == capi.ERR_OVERFLOW
+    c2 = capi.Context(0)
+    with pytest.raises(capi.SpmvHipError) as e:
+        c2.run()
+    assert e.value.code == capi.ERR_STATE
+    c2.close()
+
+
+def test_accumulate_semantics(ctx, oracle):
+    """y is never reset between runs: after N runs y = y0 + N*A*x."""
+    rows, cols, p, c, v = synth.poisson2d(48)
+    x = np.ones(cols)  # what the reference CLI multiplies by
+    one = oracle.csr_spmv(rows, p, c, v, x)
+    got = gpu_csr(ctx, rows, cols, p, c, v, x, runs=11)
+    assert_bitexact(got, oracle.csr_spmv(rows, p, c, v, x, runs=11), "11 runs")
+    assert np.array_equal(got, 11 * one)  # integer-valued here, so exact
+
+
+# ---- Level 2: caller-owned device memory (torch tensors), caller's stream --------------
+
+def test_level2_device_pointers_with_torch(oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    rows, cols, p, c, v = synth.stencil27_like(30, 30, 30, seed=8)
+    x = synth.x_vector(cols)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
+    tx = torch.from_numpy(x).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for algo in (capi.CSR_SCALAR, capi.CSR_VECTOR, capi.CSR_ADAPTIVE):
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan = capi.CsrPlan(rows, cols, p, algo)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_close(ty.cpu().numpy(), want, abs_products(rows, p, c, v, x), what="level2 algo %d" % algo)
+        plan.close()
+    # COO + ELL through device pointers
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    tr = torch.from_numpy((i - 1).astype(np.int32)).to(dev)
+    ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+    capi.coo_spmv(rows, len(a), tr.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_close(ty.cpu().numpy(), want, abs_products(rows, p, c, v, x), what="level2 coo")
+    rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+    tec, tev = torch.from_numpy(ec).to(dev), torch.from_numpy(ev).to(dev)
+    tcc, tcv = torch.empty_like(tec), torch.empty_like(tev)
+    capi.ell_to_column_major(rows, L, tec.data_ptr(), tev.data_ptr(), tcc.data_ptr(), tcv.data_ptr(), stream)
+    ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+    capi.ell_spmv(rows, L, tcc.data_ptr(), tcv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(tcc.cpu().numpy().reshape(L, rows).T.ravel(), ec)
+    assert_bitexact(ty.cpu().numpy(), oracle.ell_spmv(rows, L, ec, ev, x), "level2 ell")
+    # misaligned device pointer is refused, not mis-read
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_ADAPTIVE)
+    with pytest.raises(capi.SpmvHipError) as e:
+        plan.spmv(tp.data_ptr(), tc.data_ptr() + 4, tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    assert e.value.code == capi.ERR_ALIGN
+    plan.close()
+
+
+# ---- BASELINE full size: size-independent properties -------------------------------------
+
+def test_full_size_poisson4096_properties(oracle):
+    """configs[1]: Poisson 5-point 4096 x 4096 (N = 16 777 216, Z = 83 869 696).
+    x = ones gives the row sums, known in closed form: 4 - (number of neighbours).
+    Also linearity A(ax + bz) = aAx + bAz and a spot check of rows against the oracle."""
+    import torch
+    n = 4096
+    rows, cols, p, c, v = synth.poisson2d(n)
+    assert len(v) == 83869696
+    dev = torch.device("cuda:0")
+    tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO)
+
+    def mul(xh):
+        tx = torch.from_numpy(xh).to(dev)
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return ty.cpu().numpy()
+
+    y1 = mul(np.ones(cols))
+    r = np.arange(rows)
+    i, j = r // n, r % n
+    neigh = (i > 0).astype(int) + (i < n - 1) + (j > 0) + (j < n - 1)
+    assert np.array_equal(y1, (4 - neigh).astype(np.float64))
+    x = synth.x_vector(cols, seed=1)
+    z = synth.x_vector(cols, seed=2)
+    yx, yz, yl = mul(x), mul(z), mul(0.5 * x - 2.0 * z)
+    assert_close(yl, 0.5 * yx - 2.0 * yz, scale=np.full(rows, 16.0), what="linearity")
+    # rows [5e6, 5e6+100k) against the oracle, bit for bit (5 entries/row: reference order)
+    lo, hi = 5000000, 5100000
+    ps = (p[lo:hi + 1] - p[lo]).astype(np.int32)
+    want = oracle.csr_spmv(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x, num_threads=4)
+    assert_bitexact(yx[lo:hi], want, "full-size slice")
+    plan.close()

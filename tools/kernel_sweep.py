@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of the CSR kernel variants on one matrix, one process
+(perf deltas only count when measured this way: cdna_hip_programming.md rule 24).
+
+    python tools/kernel_sweep.py [--workload poisson2d --grid 4096 --rounds 5 --reps 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="poisson2d")
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--variants", default="")
+    args = ap.parse_args()
+    import torch
+    from spmv_amd import capi, synth
+
+    if args.workload == "poisson2d":
+        rows, cols, p, c, v = synth.poisson2d(args.grid)
+    elif args.workload == "stencil27":
+        rows, cols, p, c, v = synth.stencil27_like(160, 160, 160)
+    elif args.workload == "random":
+        rows, cols, p, c, v = synth.random_uniform(2000000, 2000000, 24, seed=3)
+    elif args.workload == "queen":  # ~80 entries/row, banded-ish
+        rows, cols, p, c, v = synth.banded(2000000, list(range(-40, 41)), seed=5)
+    else:
+        rows, cols, p, c, v = synth.powerlaw(1000005, 1000005, seed=4)
+    nnz = int(p[-1])
+    nbytes = synth.csr_bytes(rows, cols, nnz)
+    dev = torch.device("cuda:0")
+    tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
+    tx = torch.from_numpy(synth.x_vector(cols)).to(dev)
+    ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    variants = {
+        "scalar": (capi.CSR_SCALAR, 0, 0),
+        "vector2": (capi.CSR_VECTOR, 2, 0), "vector4": (capi.CSR_VECTOR, 4, 0),
+        "vector8": (capi.CSR_VECTOR, 8, 0), "vector16": (capi.CSR_VECTOR, 16, 0),
+        "vector32": (capi.CSR_VECTOR, 32, 0), "vector64": (capi.CSR_VECTOR, 64, 0),
+        "adaptive": (capi.CSR_ADAPTIVE, 0, 0),
+        "adaptive_noxcd": (capi.CSR_ADAPTIVE, 0, capi.FLAG_NO_XCD_REMAP),
+        "adaptive_exact": (capi.CSR_ADAPTIVE, 0, capi.FLAG_EXACT_ORDER),
+    }
+    if args.variants:
+        variants = {k: variants[k] for k in args.variants.split(",")}
+    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f) for k, (a, l, f) in variants.items()}
+    times = {k: [] for k in plans}
+    for rnd in range(args.rounds + 1):
+        for k, plan in plans.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd > 0:  # round 0 is warm-up
+                times[k].append(e0.elapsed_time(e1) / args.reps * 1e3)
+    print("workload %s rows %d nnz %d (%.1f/row) algorithmic bytes %.3f GB" % (
+        args.workload, rows, nnz, nnz / rows, nbytes / 1e9))
+    res = {}
+    for k, t in times.items():
+        med, mn = float(np.median(t)), float(np.min(t))
+        res[k] = {"us_median": round(med, 2), "us_min": round(mn, 2), "gbs": round(nbytes / med / 1e3, 1),
+                  "frac_of_8TBs": round(nbytes / med / 1e3 / 8000, 4), "gflops": round(2 * nnz / med / 1e3, 1),
+                  "plan": plans[k].info()}
+        print("%-16s median %9.2f us  min %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s" % (
+            k, med, mn, nbytes / med / 1e3, 100 * nbytes / med / 1e3 / 8000, 2 * nnz / med / 1e3))
+    print(json.dumps({"workload": args.workload, "rows": rows, "nnz": nnz, "results": res}))
+
+
+if __name__ == "__main__":
+    main()
