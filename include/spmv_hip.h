@@ -51,10 +51,17 @@ extern "C" {
 #define SPMV_HIP_CSR_ADAPTIVE 3 /* row blocks: coalesced stream of col/val -> products in LDS ->
                                    per-row sums (reference order when a row gets one lane);
                                    rows longer than a tile get a whole workgroup */
+#define SPMV_HIP_CSR_WAVETILE 4 /* per-wavefront row ownership: tiles of <= 64 rows owned by one
+                                   wave, descriptor-driven so all of a tile's loads issue at once,
+                                   products in the wave's LDS slice, no workgroup barrier; very
+                                   long rows are split over several waves (fp64 atomics) */
 
 /* plan / ctx flags */
-#define SPMV_HIP_FLAG_NO_XCD_REMAP 0x1u /* keep blockIdx order (A/B switch for the XCD-aware mapping) */
+#define SPMV_HIP_FLAG_XCD_REMAP 0x1u   /* give each XCD one contiguous run of tiles instead of the round-robin
+                                           deal (measured SLOWER on MI355X for streaming SpMV: off by default) */
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
+#define SPMV_HIP_FLAG_NT_LOADS 0x4u     /* wavetile: non-temporal loads for the once-read column/value streams */
+#define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
 typedef struct spmv_hip_plan spmv_hip_plan;
@@ -163,6 +170,13 @@ int spmv_hip_ell_to_column_major(int32_t rows, int32_t row_length,
 int spmv_hip_ell_spmv(int32_t rows, int32_t row_length, const int32_t *d_col_col_major,
                       const double *d_val_col_major, const double *d_x, double *d_y,
                       void *stream);
+
+/* STREAM triad a[i] = b[i] + q*c[i] on device arrays of n doubles (24 B and 2 flop
+ * per element).  Replaces triad_kernel::run (src/kernels/triad.cpp:48-54, q = 3.1);
+ * used as the EMPIRICAL HBM roofline next to the 8 TB/s spec peak.
+ * mul then add, not fused: bit-exact with the reference loop. */
+int spmv_hip_triad(int64_t n, double *d_a, const double *d_b, const double *d_c, double q,
+                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,10 @@ bool aligned16(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15u) =
 constexpr int kBlock = 256;
 constexpr int kTile = 2048;
 constexpr int kCUs = 256;
+// wavetile: rows longer than kSplitThreshold entries are cut into kSplitChunk-entry
+// chunks handled by different waves (each adds its partial sum with one atomic)
+constexpr int kSplitThreshold = 8192;
+constexpr int kSplitChunk = 4096;
 
 int grid_for(long long work_items, int per_block, int max_blocks = kCUs * 8)
 {
@@ -71,6 +75,9 @@ struct spmv_hip_plan {
     int nblk = 0;
     int long_blocks = 0;
     int32_t * d_blk_row = nullptr;
+    int4 * d_tiles = nullptr; // wavetile descriptors {first row | partial flag, first entry, longest row, log2 lanes/row}
+    int ntiles = 0;
+    int tile = 0;
     size_t meta_bytes = 0;
 };
 
@@ -201,7 +208,7 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
     for (int32_t r = 0; r < rows; ++r)
         if (p[r + 1] < p[r])
             return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
-    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_ADAPTIVE)
+    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_WAVETILE)
         return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
     if (lanes_per_row != 0 &&
         (lanes_per_row < 2 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1))))
@@ -217,10 +224,10 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
     const double mean = rows > 0 ? double(p[rows] - p[0]) / rows : 0.0;
 
     if (algorithm == SPMV_HIP_CSR_AUTO)
-        algorithm = SPMV_HIP_CSR_ADAPTIVE;
+        algorithm = SPMV_HIP_CSR_WAVETILE;
     if (flags & SPMV_HIP_FLAG_EXACT_ORDER) {
         if (algorithm == SPMV_HIP_CSR_VECTOR)
-            algorithm = SPMV_HIP_CSR_ADAPTIVE;
+            algorithm = SPMV_HIP_CSR_WAVETILE;
     }
     pl->algorithm = algorithm;
 
@@ -229,6 +236,63 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
     } else if (algorithm == SPMV_HIP_CSR_VECTOR) {
         pl->lanes_per_row = lanes_per_row ? lanes_per_row : pick_lanes(mean);
         pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, kCUs * 32);
+    } else if (algorithm == SPMV_HIP_CSR_WAVETILE) {
+        // wave tiles: <= 64 rows and <= tile entries (from the 4-aligned start) per wave
+        const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
+        const bool exact = (flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
+        pl->tile = tile;
+        std::vector<int4> desc;
+        desc.reserve((size_t) rows / 48 + 16);
+        int32_t r = 0;
+        while (r < rows) {
+            const int32_t kb = p[r] & ~3;
+            int32_t r1 = r;
+            int32_t maxlen = 0;
+            while (r1 < rows && (r1 - r) < 64 && (long long) p[r1 + 1] - kb <= tile) {
+                maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
+                ++r1;
+            }
+            if (r1 == r) { // one row longer than a tile
+                const long long len = (long long) p[r + 1] - p[r];
+                pl->long_blocks++;
+                if (!exact && len > kSplitThreshold) {
+                    for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                        desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+                } else {
+                    desc.push_back(make_int4(r, p[r], (int) std::min<long long>(len, INT32_MAX), 0));
+                }
+                r1 = r + 1;
+            } else {
+                // lanes per row: as many as fit in the wave, never more than the rows are
+                // long; one lane per row keeps the reference's summation order
+                const int nrows = r1 - r;
+                const int avg = (p[r1] - p[r]) / nrows;
+                const int cap = 64 / nrows;
+                int lanes_log2 = 0;
+                if (!exact)
+                    while ((2 << lanes_log2) <= cap && (8 << lanes_log2) <= avg)
+                        ++lanes_log2;
+                desc.push_back(make_int4(r, p[r], maxlen, lanes_log2));
+            }
+            r = r1;
+        }
+        pl->ntiles = (int) desc.size();
+        desc.push_back(make_int4(rows, p[rows], 0, 0));
+        pl->nblk = pl->ntiles;
+        pl->workgroups = (pl->ntiles + 3) / 4;
+        if (pl->ntiles > 0) {
+            pl->meta_bytes = desc.size() * sizeof(int4);
+            hipError_t e = hipMalloc((void **) &pl->d_tiles, pl->meta_bytes);
+            if (e == hipSuccess)
+                e = hipMemcpy(pl->d_tiles, desc.data(), pl->meta_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                int rc = fail_hip(e, "plan metadata upload");
+                if (pl->d_tiles)
+                    (void) hipFree(pl->d_tiles);
+                delete pl;
+                return rc;
+            }
+        }
     } else {
         // adaptive: cut rows into blocks of <= kTile entries (from the 4-aligned
         // start of the block's first row) and <= kBlock rows
@@ -274,6 +338,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         return;
     if (pl->d_blk_row)
         (void) hipFree(pl->d_blk_row);
+    if (pl->d_tiles)
+        (void) hipFree(pl->d_tiles);
     delete pl;
 }
 
@@ -315,11 +381,31 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         default: launch_vector<64>(pl, p, j, a, x, y, s); break;
         }
         break;
+    case SPMV_HIP_CSR_WAVETILE:
+        if (pl->ntiles > 0) {
+            const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
+            const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
+            const bool nt = (pl->flags & SPMV_HIP_FLAG_NT_LOADS) != 0;
+#define SPMV_WT_LAUNCH(T, N, X)                                                                      \
+    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, N, X>), dim3(pl->workgroups), dim3(256), 0, s,  \
+                       pl->ntiles, pl->d_tiles, p, j, a, x, y, pl->nnz, xcd, exact)
+            // x below 4 GiB: 32-bit gather offsets from a scalar base
+            const bool x32 = pl->cols < (1 << 29);
+            if (pl->tile == 1024) {
+                if (nt) { if (x32) SPMV_WT_LAUNCH(1024, true, true); else SPMV_WT_LAUNCH(1024, true, false); }
+                else    { if (x32) SPMV_WT_LAUNCH(1024, false, true); else SPMV_WT_LAUNCH(1024, false, false); }
+            } else {
+                if (nt) { if (x32) SPMV_WT_LAUNCH(512, true, true); else SPMV_WT_LAUNCH(512, true, false); }
+                else    { if (x32) SPMV_WT_LAUNCH(512, false, true); else SPMV_WT_LAUNCH(512, false, false); }
+            }
+#undef SPMV_WT_LAUNCH
+        }
+        break;
     default:
         if (pl->nblk > 0)
             hipLaunchKernelGGL((spmv::csr_adaptive_kernel<kBlock, kTile>), dim3(pl->nblk), dim3(kBlock), 0, s,
                                pl->nblk, pl->d_blk_row, p, j, a, x, y, pl->nnz,
-                               (pl->flags & SPMV_HIP_FLAG_NO_XCD_REMAP) ? 0 : 1,
+                               (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0,
                                (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0);
         break;
     }
@@ -382,6 +468,23 @@ int spmv_hip_ell_spmv(int32_t rows, int32_t row_length, const int32_t * j, const
     return SPMV_HIP_OK;
 }
 
+int spmv_hip_triad(int64_t n, double * a, const double * b, const double * c, double q, void * stream)
+{
+    if (n < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "negative size");
+    if (n == 0)
+        return SPMV_HIP_OK;
+    if (!a || !b || !c)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (!aligned16(a) || !aligned16(b) || !aligned16(c))
+        return fail(SPMV_HIP_ERR_ALIGN, "triad arrays must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((n + 1) / 2, kBlock, kCUs * 16);
+    hipLaunchKernelGGL((spmv::triad_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
 /* ================================ Level 1 ======================================= */
 
 int spmv_hip_create(spmv_hip_ctx ** out, int device, unsigned flags)
@@ -433,7 +536,7 @@ int spmv_hip_set_csr_algorithm(spmv_hip_ctx * c, int algorithm, int lanes_per_ro
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
-    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_ADAPTIVE)
+    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_WAVETILE)
         return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
     c->csr_algorithm = algorithm;
     c->csr_lanes = lanes_per_row;

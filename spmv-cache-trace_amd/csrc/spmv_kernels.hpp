@@ -226,6 +226,222 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// CSR, wave tiles ("wavetile"): per-wavefront row ownership, no workgroup barrier.
+//
+// The host cuts the rows into tiles owned by ONE wave: up to 64 consecutive rows
+// holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
+// described by an int4 {first row | flags, first entry, longest row, lanes per row};
+// tile w ends where tile w+1 starts.  A wave reads its descriptor pair with scalar
+// loads and then has everything it needs to issue ALL its independent loads back to
+// back -- the row_ptr pair and old y of the lane's row, then the column/value quads
+// (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs three
+// dependent memory round trips (descriptor -> streams -> x gather) instead of the six
+// of a row_ptr-driven kernel.  The rounded products are parked in the wave's private
+// LDS slice (same-wave LDS operations execute in order: no barrier, no wait beyond the
+// data dependence), then each row is added up by L lanes; L = 1 (rows shorter than 16
+// entries on average) walks the row left to right exactly like the reference loop.
+//
+// The kernel is also kept lean in issued instructions, which at 5 entries per row is
+// what bounds it next to HBM: no per-entry predicates (entries of neighbouring tiles
+// that share a 16-byte quad are multiplied too, their products are simply never
+// read), clamped indices instead of divergent branches, the per-tile integer
+// divisions done once on the host (descriptor .z/.w), and a row loop whose trip count
+// is wave-uniform (the tile's longest row).
+//
+// A row longer than TILE is a tile by itself (the wave strides it); rows longer than
+// kSplitThreshold are cut into chunks spread over several waves (bit 31 of the row
+// field), each adding its partial sum with one fp64 atomic.
+// ---------------------------------------------------------------------------------
+constexpr int kTileFlagPartial = (int) 0x80000000u;
+
+// native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <typename T, bool NT>
+__device__ __forceinline__ T stream_load(const T * ptr)
+{
+    if (NT)
+        return __builtin_nontemporal_load(ptr);
+    return *ptr;
+}
+
+// x[c] with a 32-bit byte offset from a scalar base when x is smaller than 4 GiB
+// (global_load saddr + voffset: one shift instead of 64-bit address arithmetic)
+template <bool X32>
+__device__ __forceinline__ double gather_x(const double * __restrict__ x, int c)
+{
+    if (X32)
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned) c << 3));
+    return x[c];
+}
+
+template <int L>
+__device__ __forceinline__ double tile_row_sum(const double * prod, int s, int e_row, int part, int trips)
+{
+    double z = 0.0;
+    int k = s + part;
+    for (int t = 0; t < trips; ++t, k += L) { // wave-uniform trip count
+        // +0.0 for the lanes whose row is already finished: z can never be -0.0 (it
+        // starts at +0.0 and a sum that cancels rounds to +0.0), so this is an identity
+        const double v = (k < e_row) ? prod[k] : 0.0;
+        z += v;
+    }
+    return group_sum<L>(z);
+}
+
+template <int TILE, bool NT, bool X32>
+__global__ __launch_bounds__(256) void csr_wavetile_kernel(
+    int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
+    const int32_t * __restrict__ j, const double * __restrict__ a,
+    const double * __restrict__ x, double * __restrict__ y, int nnz_total, int xcd_aware,
+    int exact_order)
+{
+    constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
+    __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    const int lane = (int) __lane_id();
+    const int nblk = (ntiles + 3) >> 2;
+    const int w = xcd_remap(blockIdx.x, nblk, xcd_aware != 0) * 4 + wave;
+    if (w >= ntiles)
+        return; // whole wave leaves; no workgroup barrier anywhere in this kernel
+    double * prod = prod_all[wave];
+
+    const int4 d0 = desc[w];
+    const int4 d1 = desc[w + 1];
+    const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
+    const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
+    const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
+    const int maxlen = __builtin_amdgcn_readfirstlane(d0.z);
+    const int lanes_log2 = __builtin_amdgcn_readfirstlane(d0.w);
+    const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
+    const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
+    const int nrows = r1 - r0;
+    const int kb = k0 & ~3;
+    // vector loads of the tile's last quad stay inside the arrays unless this is the
+    // ragged end of the whole matrix
+    const bool tail_safe = ((k1 - 1) | 3) < nnz_total;
+
+    if (!partial && k1 - kb <= TILE && tail_safe && k1 > k0) {
+        // ---- stream tile, fast path ----------------------------------------------------
+        // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row
+        const int sub = lane >> lanes_log2;
+        const int part = lane & ((1 << lanes_log2) - 1);
+        const int rowi = sub < nrows ? sub : nrows - 1; // clamp instead of branching
+        const int32_t * pt = p + r0;
+        double * yt = y + r0;
+        const int ps = pt[rowi];
+        const int pe = pt[rowi + 1];
+        const double yv = yt[rowi];
+        // (2) the tile's column/value quads; lanes past the tile's end re-read its last quad
+        const int32_t * jt = j + kb;
+        const double * at = a + kb;
+        const int last = (k1 - 1 - kb) & ~3;
+        v4i c[QUADS];
+        v2d va[QUADS], vb[QUADS];
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            int o = 256 * q + 4 * lane;
+            o = o < last ? o : last;
+            c[q] = stream_load<v4i, NT>(reinterpret_cast<const v4i *>(jt + o));
+            va[q] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(at + o));
+            vb[q] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(at + o + 2));
+        }
+        // (3) gather x and park the rounded products; entries of neighbouring tiles that
+        // share the first/last quad are multiplied as well and never read back
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            const int o = 256 * q + 4 * lane;
+            if (o <= last) {
+                const double q0 = va[q].x * gather_x<X32>(x, c[q].x);
+                const double q1 = va[q].y * gather_x<X32>(x, c[q].y);
+                const double q2 = vb[q].x * gather_x<X32>(x, c[q].z);
+                const double q3 = vb[q].y * gather_x<X32>(x, c[q].w);
+                v2d * dst = reinterpret_cast<v2d *>(prod + o);
+                dst[0] = v2d{q0, q1};
+                dst[1] = v2d{q2, q3};
+            }
+        }
+        // same-wave LDS operations execute in order; the fences only pin the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (4) row sums from LDS
+        const int s = ps - kb;
+        const int e_row = pe - kb;
+        const int trips = (maxlen + (1 << lanes_log2) - 1) >> lanes_log2;
+        double z;
+        switch (lanes_log2) {
+        case 0: z = tile_row_sum<1>(prod, s, e_row, part, trips); break;
+        case 1: z = tile_row_sum<2>(prod, s, e_row, part, trips); break;
+        case 2: z = tile_row_sum<4>(prod, s, e_row, part, trips); break;
+        case 3: z = tile_row_sum<8>(prod, s, e_row, part, trips); break;
+        case 4: z = tile_row_sum<16>(prod, s, e_row, part, trips); break;
+        case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
+        default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
+        }
+        if (sub < nrows && part == 0)
+            yt[sub] = yv + z;
+    } else if (!partial && k1 - kb <= TILE) {
+        // ---- stream tile at the ragged end of the arrays, or a tile of empty rows: scalar
+        // loads, one lane per row
+        for (int k = k0 + lane; k < k1; k += kWave)
+            prod[k - kb] = a[k] * x[j[k]];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nrows) {
+            const int s = p[r0 + lane] - kb, e_row = p[r0 + lane + 1] - kb;
+            double z = 0.0;
+            for (int k = s; k < e_row; ++k)
+                z += prod[k];
+            y[r0 + lane] += z;
+        }
+    } else if (!exact_order) {
+        // ---- one long row, or one chunk of a very long row: the wave strides it ----------
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+        int k = k0 + lane;
+        for (; k + 3 * kWave < k1; k += 4 * kWave) { // 4 independent gathers in flight
+            const int c0 = j[k], c1 = j[k + kWave], c2 = j[k + 2 * kWave], c3 = j[k + 3 * kWave];
+            const double v0 = a[k], v1 = a[k + kWave], v2 = a[k + 2 * kWave], v3 = a[k + 3 * kWave];
+            z0 += v0 * x[c0];
+            z1 += v1 * x[c1];
+            z2 += v2 * x[c2];
+            z3 += v3 * x[c3];
+        }
+        for (; k < k1; k += kWave)
+            z0 += a[k] * x[j[k]];
+        double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
+        if (lane == 0) {
+            if (partial)
+                unsafeAtomicAdd(y + r0, z);
+            else
+                y[r0] += z;
+        }
+    } else {
+        // ---- one long row in the reference's order: lane 0 adds tiles of products ---------
+        double z = 0.0;
+        for (int t0 = k0; t0 < k1; t0 += TILE) {
+            const int t1 = (t0 + TILE < k1) ? t0 + TILE : k1;
+            for (int k = t0 + lane; k < t1; k += kWave)
+                prod[k - t0] = a[k] * x[j[k]];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0)
+                for (int k = 0; k < t1 - t0; ++k)
+                    z += prod[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane == 0)
+            y[r0] += z;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // COO in any order.  Each wave takes 64 consecutive entries per step, forms the
 // products, adds runs of equal row index inside the wave (segmented inclusive scan
 // over head flags, ds_bpermute moves) and issues ONE fp64 atomic per run, so a
@@ -317,6 +533,28 @@ __global__ __launch_bounds__(BLOCK) void ell_transpose_kernel(
         j_cm[l * rows + i] = j_rm[k];
         a_cm[l * rows + i] = a_rm[k];
     }
+}
+
+// ---------------------------------------------------------------------------------
+// STREAM triad a = b + q*c (reference src/kernels/triad.cpp:48-54): two doubles per
+// lane per step (16-byte loads/stores), grid-stride.  The measured rate of this
+// kernel is the empirical HBM roofline the SpMV kernels are compared against.
+// ---------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void triad_kernel(
+    long long n, double * __restrict__ a, const double * __restrict__ b,
+    const double * __restrict__ c, double q)
+{
+    const long long n2 = n >> 1;
+    const long long stride = (long long) gridDim.x * BLOCK;
+    const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
+    for (long long i = gid; i < n2; i += stride) {
+        const double2 vb = reinterpret_cast<const double2 *>(b)[i];
+        const double2 vc = reinterpret_cast<const double2 *>(c)[i];
+        reinterpret_cast<double2 *>(a)[i] = make_double2(vb.x + q * vc.x, vb.y + q * vc.y);
+    }
+    if ((n & 1) && gid == 0)
+        a[n - 1] = b[n - 1] + q * c[n - 1];
 }
 
 } // namespace spmv

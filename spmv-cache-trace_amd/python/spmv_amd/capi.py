@@ -15,8 +15,9 @@ HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
-CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE = 0, 1, 2, 3
-FLAG_NO_XCD_REMAP, FLAG_EXACT_ORDER = 0x1, 0x2
+CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
+FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_NT_LOADS, FLAG_BIG_TILE = 0x1, 0x2, 0x4, 0x8
+CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -49,6 +50,7 @@ SIGNATURES = {
     "spmv_hip_coo_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_to_column_major": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_triad": (C.c_int, [C.c_int64, _vp, _vp, _vp, C.c_double, _vp]),
 }
 
 
@@ -259,3 +261,8 @@ def ell_to_column_major(rows, row_length, d_col_rm, d_val_rm, d_col_cm, d_val_cm
 
 def ell_spmv(rows, row_length, d_col_cm, d_val_cm, d_x, d_y, stream=0):
     check(load().spmv_hip_ell_spmv(rows, row_length, d_col_cm, d_val_cm, d_x, d_y, stream))
+
+
+def triad(n, d_a, d_b, d_c, q=3.1, stream=0):
+    """a = b + q*c on device arrays (STREAM triad, the empirical bandwidth roofline)."""
+    check(load().spmv_hip_triad(n, d_a, d_b, d_c, q, stream))

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 ALGOS = [("scalar", capi.CSR_SCALAR, 0), ("vector2", capi.CSR_VECTOR, 2), ("vector8", capi.CSR_VECTOR, 8),
          ("vector64", capi.CSR_VECTOR, 64), ("vector_auto", capi.CSR_VECTOR, 0),
-         ("adaptive", capi.CSR_ADAPTIVE, 0), ("auto", capi.CSR_AUTO, 0)]
+         ("adaptive", capi.CSR_ADAPTIVE, 0), ("wavetile", capi.CSR_WAVETILE, 0), ("auto", capi.CSR_AUTO, 0)]
 
 
 @pytest.fixture(scope="module")
@@ -172,9 +172,29 @@ def test_adaptive_short_rows_bitexact(ctx, oracle, name, gen):
     want = oracle.csr_spmv(rows, p, c, v, x, num_threads=2)
     if name.startswith("poisson"):
         assert_bitexact(gpu_csr(ctx, rows, cols, p, c, v, x, algo=capi.CSR_ADAPTIVE), want, name)
+        assert_bitexact(gpu_csr(ctx, rows, cols, p, c, v, x, algo=capi.CSR_WAVETILE), want, name)
     c2 = capi.Context(0, flags=capi.FLAG_EXACT_ORDER)
     try:
-        assert_bitexact(gpu_csr(c2, rows, cols, p, c, v, x, algo=capi.CSR_ADAPTIVE), want, name + "/exact")
+        for algo in (capi.CSR_ADAPTIVE, capi.CSR_WAVETILE, capi.CSR_VECTOR):
+            assert_bitexact(gpu_csr(c2, rows, cols, p, c, v, x, algo=algo), want, "%s/exact/%d" % (name, algo))
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("flags", [capi.FLAG_NT_LOADS, capi.FLAG_BIG_TILE,
+                                   capi.FLAG_NT_LOADS | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
+def test_wavetile_variants(oracle, flags):
+    """The tuning switches of the wave-tile kernel change speed only, never y."""
+    c2 = capi.Context(0, flags=flags)
+    try:
+        for name, gen in SYNTH:
+            rows, cols, p, c, v = gen()
+            x = synth.x_vector(cols)
+            want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+            got = gpu_csr(c2, rows, cols, p, c, v, x, algo=capi.CSR_WAVETILE)
+            assert_close(got, want, abs_products(rows, p, c, v, x), what="%s/wavetile/flags%x" % (name, flags))
+            if name.startswith("poisson"):
+                assert_bitexact(got, want, name)
     finally:
         c2.close()
 
@@ -225,11 +245,13 @@ def test_edge_cases_csr(ctx, oracle):
     p[901:] = 10
     cases["mostly_empty"] = (1000, 11, p, np.arange(10, dtype=np.int32), np.linspace(-1, 1, 10))
     rng = np.random.default_rng(11)
-    for L in (T - 4, T - 1, T, T + 1, 3 * T + 5):  # rows right at the tile boundary
+    # rows right at the tile boundaries of the adaptive (2048) and wave-tile (512 / 1024)
+    # kernels, and rows long enough to be split over several waves (> 8192 entries)
+    for L in (508, 511, 512, 513, 1023, 1024, 1025, T - 4, T - 1, T, T + 1, 3 * T + 5, 8193, 20001):
         lens = np.array([3, L, 2, L, 1], dtype=np.int64)
         p = np.zeros(6, dtype=np.int32)
         p[1:] = np.cumsum(lens)
-        cols = 4 * T
+        cols = 12 * T
         c = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) for n in lens]).astype(np.int32)
         cases["tile_edge_%d" % L] = (5, cols, p, c, rng.uniform(-1, 1, len(c)))
     for name, (rows, cols, p, c, v) in cases.items():
@@ -296,7 +318,7 @@ def test_level2_device_pointers_with_torch(oracle):
     tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
     tx = torch.from_numpy(x).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    for algo in (capi.CSR_SCALAR, capi.CSR_VECTOR, capi.CSR_ADAPTIVE):
+    for algo in (capi.CSR_SCALAR, capi.CSR_VECTOR, capi.CSR_ADAPTIVE, capi.CSR_WAVETILE):
         ty = torch.zeros(rows, dtype=torch.float64, device=dev)
         plan = capi.CsrPlan(rows, cols, p, algo)
         plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
@@ -364,3 +386,19 @@ def test_full_size_poisson4096_properties(oracle):
     want = oracle.csr_spmv(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x, num_threads=4)
     assert_bitexact(yx[lo:hi], want, "full-size slice")
     plan.close()
+
+
+def test_triad_bitexact():
+    """STREAM triad (reference src/kernels/triad.cpp:48-54): a = b + 3.1*c, mul then add."""
+    import torch
+    dev = torch.device("cuda:0")
+    for n in (0, 1, 2, 1001, 1 << 20):
+        rng = np.random.default_rng(n)
+        b, c = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        tb, tc = torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev)
+        ta = torch.full((max(n, 1),), 7.0, dtype=torch.float64, device=dev)
+        capi.triad(n, ta.data_ptr(), tb.data_ptr() if n else 0, tc.data_ptr() if n else 0, 3.1,
+                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if n:
+            assert_bitexact(ta.cpu().numpy()[:n], b + 3.1 * c, "triad n=%d" % n)

@@ -50,8 +50,14 @@ def main():
         "vector8": (capi.CSR_VECTOR, 8, 0), "vector16": (capi.CSR_VECTOR, 16, 0),
         "vector32": (capi.CSR_VECTOR, 32, 0), "vector64": (capi.CSR_VECTOR, 64, 0),
         "adaptive": (capi.CSR_ADAPTIVE, 0, 0),
-        "adaptive_noxcd": (capi.CSR_ADAPTIVE, 0, capi.FLAG_NO_XCD_REMAP),
+        "adaptive_xcd": (capi.CSR_ADAPTIVE, 0, capi.FLAG_XCD_REMAP),
         "adaptive_exact": (capi.CSR_ADAPTIVE, 0, capi.FLAG_EXACT_ORDER),
+        "wavetile": (capi.CSR_WAVETILE, 0, 0),
+        "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
+        "wavetile_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_LOADS),
+        "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
+        "wavetile_big_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | capi.FLAG_NT_LOADS),
+        "wavetile_nt_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_LOADS | capi.FLAG_XCD_REMAP),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
@@ -67,6 +73,25 @@ def main():
             torch.cuda.synchronize()
             if rnd > 0:  # round 0 is warm-up
                 times[k].append(e0.elapsed_time(e1) / args.reps * 1e3)
+    # empirical roofline: STREAM triad on 3 x 512 MiB (past the 256 MiB Infinity Cache)
+    nt = 64 * 1024 * 1024
+    ta = torch.zeros(nt, dtype=torch.float64, device=dev)
+    tb = torch.ones(nt, dtype=torch.float64, device=dev)
+    tcv = torch.ones(nt, dtype=torch.float64, device=dev)
+    tt = []
+    for rnd in range(args.rounds + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            capi.triad(nt, ta.data_ptr(), tb.data_ptr(), tcv.data_ptr(), 3.1, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        if rnd > 0:
+            tt.append(e0.elapsed_time(e1) / args.reps * 1e3)
+    triad_gbs = 24.0 * nt / float(np.median(tt)) / 1e3
+    print("triad (3 x 512 MiB): median %.2f us = %.1f GB/s (%.1f%% of 8 TB/s)" % (
+        float(np.median(tt)), triad_gbs, triad_gbs / 80))
+    del ta, tb, tcv
     print("workload %s rows %d nnz %d (%.1f/row) algorithmic bytes %.3f GB" % (
         args.workload, rows, nnz, nnz / rows, nbytes / 1e9))
     res = {}
@@ -75,9 +100,10 @@ def main():
         res[k] = {"us_median": round(med, 2), "us_min": round(mn, 2), "gbs": round(nbytes / med / 1e3, 1),
                   "frac_of_8TBs": round(nbytes / med / 1e3 / 8000, 4), "gflops": round(2 * nnz / med / 1e3, 1),
                   "plan": plans[k].info()}
-        print("%-16s median %9.2f us  min %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s" % (
-            k, med, mn, nbytes / med / 1e3, 100 * nbytes / med / 1e3 / 8000, 2 * nnz / med / 1e3))
-    print(json.dumps({"workload": args.workload, "rows": rows, "nnz": nnz, "results": res}))
+        print("%-16s median %9.2f us  min %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s, %.1f%% of triad)  %7.1f GFLOP/s" % (
+            k, med, mn, nbytes / med / 1e3, 100 * nbytes / med / 1e3 / 8000,
+            100 * nbytes / med / 1e3 / triad_gbs, 2 * nnz / med / 1e3))
+    print(json.dumps({"workload": args.workload, "rows": rows, "nnz": nnz, "triad_gbs": round(triad_gbs, 1), "results": res}))
 
 
 if __name__ == "__main__":
