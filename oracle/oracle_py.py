@@ -200,6 +200,8 @@ class RefLib:
         L.ref_ell_spmv.restype = C.c_int
         L.ref_print_sample.argtypes = [_i64p, C.c_int64, C.c_char_p, C.c_int64]
         L.ref_print_sample.restype = C.c_int64
+        L.ref_trace_config_echo.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, _i32p]
+        L.ref_trace_config_echo.restype = C.c_int64
 
     def error(self):
         return self.lib.ref_last_error().decode()
@@ -351,3 +353,15 @@ class RefLib:
         n = self.lib.ref_print_sample(v, len(v), buf, 4096)
         assert n >= 0
         return buf.value.decode()
+
+    def trace_config_echo(self, path):
+        """(json text, info dict) of the reference's parse + print of a trace-config file;
+        raises RuntimeError with the reference's message on a trace_config_error."""
+        buf = C.create_string_buffer(1 << 16)
+        info = np.zeros(4, dtype=np.int32)
+        n = self.lib.ref_trace_config_echo(path.encode(), buf, 1 << 16, info)
+        if n == -1:
+            raise RuntimeError(self.error())
+        assert n >= 0
+        return buf.value.decode(), dict(zip(["threads", "numa_domains", "caches", "max_cache_size"],
+                                            info.tolist()))

@@ -16,6 +16,7 @@
  *   {csr,coo,ell}_matrix::from_matrix_market     csr-matrix.cpp:187-243, coo-matrix.cpp:220-243, ell-matrix.cpp:190-238
  *   {csr,coo,ell}_matrix::spmv                   csr-matrix-spmv.cpp:148-167, coo-matrix.cpp:313-335, ell-matrix.cpp:311-335
  *   print_sample                                 src/util/sample.hpp:137-165
+ *   read_trace_config / operator<<(TraceConfig)  src/trace-config.cpp:386-404, 579-597
  */
 #include "matrix/coo-matrix.hpp"
 #include "matrix/csr-matrix.hpp"
@@ -24,6 +25,7 @@
 #include "matrix/matrix-market.hpp"
 #include "util/json-ostreambuf.hpp"
 #include "util/sample.hpp"
+#include "trace-config.hpp"
 
 #include <omp.h>
 
@@ -332,6 +334,33 @@ int64_t ref_print_sample(const int64_t * v, int64_t n, char * out, int64_t cap)
     std::string str = s.str();
     if ((int64_t) str.size() + 1 > cap)
         return -(int64_t) str.size() - 1;
+    std::memcpy(out, str.c_str(), str.size() + 1);
+    return (int64_t) str.size();
+}
+
+/* ---- trace-config: parse a file and echo it through the JSON stream buffer ------
+ * Returns the length written, or a negative number: -1 = trace_config_error (message in
+ * ref_last_error), -(n+2) = buffer too small for n bytes. */
+int64_t ref_trace_config_echo(const char * path, char * out, int64_t cap, int32_t * info)
+{
+    std::string str;
+    int rc = guarded([&] {
+        TraceConfig tc = read_trace_config(path);
+        std::ostringstream s;
+        {
+            json_ostreambuf buf(s);
+            s << tc;
+        }
+        str = s.str();
+        info[0] = (int32_t) tc.thread_affinities().size();
+        info[1] = tc.num_numa_domains();
+        info[2] = (int32_t) tc.caches().size();
+        info[3] = (int32_t) tc.max_cache_size();
+    });
+    if (rc != 0)
+        return -1;
+    if ((int64_t) str.size() + 1 > cap)
+        return -(int64_t) str.size() - 2;
     std::memcpy(out, str.c_str(), str.size() + 1);
     return (int64_t) str.size();
 }

@@ -1,0 +1,295 @@
+// main.cpp -- command line of the MI355X SpMV engine.
+//
+// Keeps the reference's surface (src/main.cpp:139-188): --trace-config/-c, --matrix/-m,
+// --spmv-format {coo,coo-atomic,csr,ell}, --profile/-p N, --warmup, --flush-caches,
+// --verbose/-v, --triad N, one JSON document on stdout, one-line errors on stderr with
+// EXIT_FAILURE.  Accepted as well: the README's --csr/--coo/--ell PATH spellings.
+// New: --device hip (or --spmv-format hip-csr|hip-coo|hip-ell) runs the format on the GPU.
+// The default mode of the reference (simulated cache tracing, no --profile) and its libpfm4
+// counters are outside this engine and are refused with a message.
+#include "kernels/spmv-kernels.hpp"
+#include "kernels/triad-kernel.hpp"
+#include "profile-kernel.hpp"
+#include "trace-config.hpp"
+#include "util/json-ostreambuf.hpp"
+
+#include "spmv_hip.h"
+
+#include <argp.h>
+#include <locale.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <system_error>
+
+char const * argp_program_version = "spmv-cache-trace-hip 1.0 (drop-in for spmv-cache-trace 2.0 --profile)";
+char const * argp_program_bug_address = nullptr;
+
+namespace {
+
+enum class KernelType { none, triad, spmv };
+
+struct Arguments
+{
+    KernelType kernel_type = KernelType::none;
+    SpmvFormat format = SpmvFormat::csr;
+    bool hip = false;
+    std::size_t triad_entries = 0;
+    std::string matrix_path;
+    std::string trace_config;
+    int threads = 0;
+    int profile = 0;
+    bool warmup = false;
+    bool flush_caches = false;
+    bool list_perf_events = false;
+    bool verbose = false;
+    bool check = false;
+    SpmvOptions spmv;
+};
+
+enum Key
+{
+    key_matrix = 'm',
+    key_trace_config = 'c',
+    key_profile = 'p',
+    key_verbose = 'v',
+    key_first_long = 128,
+    key_list_perf_events,
+    key_warmup,
+    key_flush_caches,
+    key_triad,
+    key_spmv_format,
+    key_csr,
+    key_coo,
+    key_ell,
+    key_device,
+    key_gpu,
+    key_csr_algorithm,
+    key_lanes,
+    key_expand_symmetric,
+    key_exact_order,
+    key_threads,
+    key_check,
+};
+
+bool parse_count(char const * arg, long long & out)
+{
+    char * end = nullptr;
+    errno = 0;
+    out = std::strtoll(arg, &end, 10);
+    return errno == 0 && end != arg && *end == '\0' && out >= 0;
+}
+
+error_t parse_option(int key, char * arg, argp_state * state)
+{
+    Arguments & a = *static_cast<Arguments *>(state->input);
+    long long n = 0;
+    switch (key) {
+    case key_matrix: a.matrix_path = arg; break;
+    case key_trace_config: a.trace_config = arg; break;
+    case key_profile:
+        if (!parse_count(arg, n) || n > 1000000000)
+            argp_error(state, "Expected 'profile' to be an integer");
+        a.profile = (int) n;
+        break;
+    case key_warmup: a.warmup = true; break;
+    case key_flush_caches: a.flush_caches = true; break;
+    case key_list_perf_events: a.list_perf_events = true; break;
+    case key_verbose: a.verbose = true; break;
+    case key_triad:
+        if (!parse_count(arg, n))
+            argp_error(state, "triad: expected integer");
+        a.kernel_type = KernelType::triad;
+        a.triad_entries = (std::size_t) n;
+        break;
+    case key_spmv_format:
+        a.kernel_type = KernelType::spmv;
+        if (!std::strncmp(arg, "hip-", 4)) {
+            a.hip = true;
+            arg += 4;
+        }
+        if (!std::strcmp(arg, "coo")) a.format = SpmvFormat::coo;
+        else if (!std::strcmp(arg, "coo-atomic")) a.format = SpmvFormat::coo_atomic;
+        else if (!std::strcmp(arg, "csr")) a.format = SpmvFormat::csr;
+        else if (!std::strcmp(arg, "ell")) a.format = SpmvFormat::ell;
+        else if (!std::strcmp(arg, "mkl-csr") || !std::strcmp(arg, "hybrid"))
+            argp_error(state, "spmv-format '%s' is not part of this build (choose coo, coo-atomic, csr or ell)", arg);
+        else argp_error(state, "invalid argument");
+        break;
+    case key_csr: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::csr; a.matrix_path = arg; break;
+    case key_coo: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::coo; a.matrix_path = arg; break;
+    case key_ell: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::ell; a.matrix_path = arg; break;
+    case key_device:
+        if (!std::strcmp(arg, "hip") || !std::strcmp(arg, "gpu")) a.hip = true;
+        else if (!std::strcmp(arg, "cpu")) a.hip = false;
+        else argp_error(state, "device: expected 'cpu' or 'hip'");
+        break;
+    case key_gpu:
+        if (!parse_count(arg, n))
+            argp_error(state, "gpu: expected a device index");
+        a.spmv.device = (int) n;
+        break;
+    case key_csr_algorithm:
+        if (!std::strcmp(arg, "auto")) a.spmv.csr_algorithm = SPMV_HIP_CSR_AUTO;
+        else if (!std::strcmp(arg, "scalar")) a.spmv.csr_algorithm = SPMV_HIP_CSR_SCALAR;
+        else if (!std::strcmp(arg, "vector")) a.spmv.csr_algorithm = SPMV_HIP_CSR_VECTOR;
+        else if (!std::strcmp(arg, "adaptive")) a.spmv.csr_algorithm = SPMV_HIP_CSR_ADAPTIVE;
+        else if (!std::strcmp(arg, "wavetile")) a.spmv.csr_algorithm = SPMV_HIP_CSR_WAVETILE;
+        else argp_error(state, "csr-algorithm: expected auto, scalar, vector, adaptive or wavetile");
+        break;
+    case key_lanes:
+        if (!parse_count(arg, n))
+            argp_error(state, "lanes-per-row: expected integer");
+        a.spmv.csr_lanes_per_row = (int) n;
+        break;
+    case key_expand_symmetric: a.spmv.expand_symmetric = true; break;
+    case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
+    case key_threads:
+        if (!parse_count(arg, n) || n < 1 || n > 4096)
+            argp_error(state, "threads: expected a positive integer");
+        a.threads = (int) n;
+        break;
+    case key_check: a.check = true; break;
+    case ARGP_KEY_END:
+        if (a.list_perf_events)
+            break;
+        if (a.trace_config.empty() && a.threads == 0)
+            argp_error(state, "Please specify --trace-config");
+        break;
+    default: return ARGP_ERR_UNKNOWN;
+    }
+    return 0;
+}
+
+// max_i |y_i - z_i| / max_i |z_i|
+double relative_error(std::vector<double> const & y, std::vector<double> const & z)
+{
+    double err = 0.0, scale = 0.0;
+    for (std::size_t i = 0; i < y.size() && i < z.size(); ++i) {
+        err = std::max(err, std::fabs(y[i] - z[i]));
+        scale = std::max(scale, std::fabs(z[i]));
+    }
+    return scale > 0.0 ? err / scale : err;
+}
+
+} // namespace
+
+int main(int argc, char ** argv)
+{
+    setlocale(LC_ALL, "");
+
+    argp_option options[] = {
+        {"matrix", key_matrix, "PATH", 0, "Read matrix from file in Matrix Market format.", 0},
+        {"trace-config", key_trace_config, "PATH", 0,
+         "Read cache parameters and thread affinities from a configuration file in JSON format.", 0},
+        {"threads", key_threads, "T", 0, "Use a generated configuration with T threads instead of --trace-config", 0},
+        {"profile", key_profile, "N", 0, "Time N runs of the kernel", 0},
+        {"warmup", key_warmup, nullptr, 0, "Accepted for compatibility (profiling always warms up once)", 0},
+        {"flush-caches", key_flush_caches, nullptr, 0, "Flush CPU caches between each profiling run", 0},
+        {"list-perf-events", key_list_perf_events, nullptr, 0, "Not available (libpfm4 is not part of this build)", 0},
+        {"verbose", key_verbose, nullptr, 0, "be more verbose", 0},
+        {"check", key_check, nullptr, 0,
+         "After profiling, compare y with the CPU CSR kernel run the same number of times; adds \"parity\"", 0},
+
+        {nullptr, 0, nullptr, 0, "STREAM-like kernels:", 1},
+        {"triad", key_triad, "N", 0, "Triad: a(i)=b(i)+q*c(i), 24 bytes and 2 flops per iteration", 1},
+
+        {nullptr, 0, nullptr, 0, "Sparse matrix-vector multplication kernels:", 2},
+        {"spmv-format", key_spmv_format, "FMT", 0,
+         "choose one of: coo, coo-atomic, csr, ell (CPU, OpenMP) or hip-csr, hip-coo, hip-ell (MI355X)", 2},
+        {"csr", key_csr, "PATH", 0, "same as --spmv-format csr --matrix PATH", 2},
+        {"coo", key_coo, "PATH", 0, "same as --spmv-format coo --matrix PATH", 2},
+        {"ell", key_ell, "PATH", 0, "same as --spmv-format ell --matrix PATH", 2},
+        {"expand-symmetric", key_expand_symmetric, nullptr, 0,
+         "EXTENSION: mirror the entries of symmetric files (the reference multiplies the stored triangle only)", 2},
+
+        {nullptr, 0, nullptr, 0, "GPU:", 3},
+        {"device", key_device, "cpu|hip", 0, "Where the kernel runs (default cpu; hip = MI355X, no fallback)", 3},
+        {"gpu", key_gpu, "INDEX", 0, "HIP device index (default 0)", 3},
+        {"csr-algorithm", key_csr_algorithm, "NAME", 0, "auto, scalar, vector, adaptive or wavetile", 3},
+        {"lanes-per-row", key_lanes, "L", 0, "lanes per row of the vector algorithm (2..64, power of two)", 3},
+        {"exact-order", key_exact_order, nullptr, 0, "sum every row left to right like the CPU loop (bit-exact)", 3},
+        {nullptr, 0, nullptr, 0, nullptr, 0}};
+
+    argp parser{options, parse_option, nullptr,
+                "Time sparse matrix-vector multiplication (y += A*x) on CPU threads or on an MI355X",
+                nullptr, nullptr, nullptr};
+
+    Arguments args;
+    if (error_t err = argp_parse(&parser, argc, argv, 0, nullptr, &args)) {
+        std::cerr << strerror(err) << '\n';
+        return err;
+    }
+
+    if (args.list_perf_events) {
+        std::cerr << "Please re-build with libpfm enabled\n"; // the reference's NO_LIBPFM message
+        return EXIT_FAILURE;
+    }
+    if (args.kernel_type == KernelType::none) {
+        std::cerr << "Please choose a kernel: --spmv-format FMT --matrix PATH, --csr/--coo/--ell PATH or --triad N\n";
+        return EXIT_FAILURE;
+    }
+
+    std::unique_ptr<Kernel> kernel;
+    if (args.kernel_type == KernelType::triad)
+        kernel = make_triad_kernel(args.triad_entries, args.hip, args.spmv.device);
+    else
+        kernel = make_spmv_kernel(args.format, args.hip, args.matrix_path, args.spmv);
+
+    try {
+        TraceConfig trace_config =
+            args.trace_config.empty() ? default_trace_config(args.threads) : read_trace_config(args.trace_config);
+
+        if (args.profile == 0) {
+            std::cerr << "Cache tracing (the mode without --profile) is not part of this engine: "
+                         "use --profile=N to time the kernel\n";
+            return EXIT_FAILURE;
+        }
+
+        kernel->init(trace_config, std::cerr, args.verbose);
+        Profiling profiling =
+            profile_kernel(trace_config, *kernel, true, args.flush_caches, args.profile, std::cerr, args.verbose);
+
+        std::string parity;
+        if (args.check && args.kernel_type == KernelType::spmv) {
+            // the same matrix through the CPU CSR kernel, one thread, warm-up + N accumulating runs
+            TraceConfig one = default_trace_config(1);
+            std::unique_ptr<Kernel> ref = make_spmv_kernel(SpmvFormat::csr, false, args.matrix_path, args.spmv);
+            ref->init(one, std::cerr, false);
+            for (int r = 0; r < args.profile + 1; ++r)
+                ref->run(one);
+            double const err = relative_error(kernel->result(), ref->result());
+            parity = ",\n\"parity\": {\"against\": \"csr-spmv (CPU, 1 thread), " + std::to_string(args.profile + 1) +
+                " accumulating runs\", \"max_relative_error\": ";
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%.3e", err);
+            parity += buf;
+            parity += std::string(", \"tolerance\": 1e-10, \"pass\": ") + (err <= 1e-10 ? "true" : "false") + "}";
+        }
+
+        profiling.set_extra(parity);
+        {
+            json_ostreambuf pretty(std::cout);
+            std::cout << profiling << '\n';
+        }
+        if (!parity.empty() && parity.find("\"pass\": false") != std::string::npos) {
+            std::cerr << kernel->name() << ": parity check failed\n";
+            return EXIT_FAILURE;
+        }
+    } catch (trace_config_error const & e) {
+        std::cerr << args.trace_config << ": " << e.what() << '\n';
+        return EXIT_FAILURE;
+    } catch (kernel_error const & e) {
+        std::cerr << kernel->name() << ": " << e.what() << '\n';
+        return EXIT_FAILURE;
+    } catch (std::system_error const & e) {
+        std::cerr << e.what() << '\n';
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

@@ -255,7 +255,18 @@ def reference_vectors():
     print("ref_vectors.json:", len(cases), "cases")
 
 
+def trace_config_echoes():
+    """Reference parse + print of the committed trace-config fixtures."""
+    R = oracle_py.RefLib()
+    out = {}
+    for name in ("trace_config_2threads.json", "trace_config_1thread.json"):
+        text, info = R.trace_config_echo(os.path.join(HERE, name))
+        out[name] = {"echo": text, "info": info}
+    json.dump(out, open(os.path.join(HERE, "trace_config_echo.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    trace_config_echoes()
     extract_poisson2d()
     extract_byte_arrays()
     known_answer_tests()

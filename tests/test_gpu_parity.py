@@ -402,3 +402,46 @@ def test_triad_bitexact():
         torch.cuda.synchronize()
         if n:
             assert_bitexact(ta.cpu().numpy()[:n], b + 3.1 * c, "triad n=%d" % n)
+
+
+# ---- the C++ host program on the GPU: Kernel adapters over the C ABI, timed loop, JSON ---------
+
+def test_cli_hip_kernels(tmp_path, golden):
+    import json
+    import os
+    import hostlib
+    bus = os.path.join(helpers.GOLDEN, "bus1138_like.mtx")
+    poisson = os.path.join(helpers.GOLDEN, "poisson2D.mtx")
+    tc = os.path.join(helpers.GOLDEN, "trace_config_2threads.json")
+    for fmt in ("hip-csr", "hip-coo", "hip-ell"):
+        for path in (bus, poisson):
+            rc, out, err = hostlib.run_cli("-c", tc, "--spmv-format", fmt, "-m", path, "--profile=5", "--check")
+            assert rc == 0, (fmt, err)
+            doc = json.loads(out)
+            assert doc["kernel"]["name"] == fmt + "-spmv" and doc["kernel"]["matrix_format"] == fmt[4:]
+            assert doc["kernel"]["device"]["backend"] == "hip"
+            assert doc["parity"]["pass"] is True and doc["parity"]["max_relative_error"] <= 1e-10
+            assert doc["execution_time"]["samples"] == 5 and doc["device_time"]["samples"] == 5
+            assert doc["device_time"]["min"] > 0
+            assert doc["execution_time"]["min"] >= doc["device_time"]["min"] * 0.5
+    # the README spelling plus --device, every CSR algorithm, exact order
+    for algo in ("scalar", "vector", "adaptive", "wavetile"):
+        rc, out, err = hostlib.run_cli("-c", tc, "--csr", poisson, "--device", "hip", "--csr-algorithm", algo,
+                                       "-p", 2, "--check")
+        assert rc == 0, err
+        doc = json.loads(out)
+        assert doc["kernel"]["device"]["csr_algorithm"] == algo and doc["parity"]["pass"] is True
+    rc, out, err = hostlib.run_cli("--threads", 1, "--csr", poisson, "--device", "hip", "--exact-order", "-p", 2, "--check")
+    assert rc == 0 and json.loads(out)["parity"]["max_relative_error"] == 0.0
+    # a generated stencil through the loader (gz) and the GPU, against the CPU kernel
+    rows, cols, p, c, v = synth.poisson2d(200)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    path = str(tmp_path / "stencil.mtx")
+    synth.write_mtx(path, rows, cols, i, j, a)
+    rc, out, err = hostlib.run_cli("--threads", 4, "--csr", path, "--device", "hip", "-p", 3, "--check")
+    assert rc == 0, err
+    assert json.loads(out)["parity"]["max_relative_error"] == 0.0  # x = 1: integer row sums
+    # hip triad
+    rc, out, err = hostlib.run_cli("--threads", 1, "--triad", 1 << 22, "--device", "hip", "-p", 3)
+    assert rc == 0, err
+    assert json.loads(out)["kernel"]["name"] == "hip-triad"

@@ -1,0 +1,428 @@
+"""Host side (C++): Matrix Market loader, format converters, CPU kernels, statistics and JSON,
+trace-config, and the CLI -- against the reference's known answers, the reference-generated
+golden vectors, the oracle, and (when built) the reference library itself.  CPU only."""
+import gzip
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+
+import helpers
+import hostlib
+from helpers import GOLDEN, unhex, assert_bitexact
+from spmv_amd import synth
+
+
+@pytest.fixture(scope="module")
+def host():
+    return hostlib.Host()
+
+
+# ---- loader: the reference's test_matrix-market.cpp cases --------------------------------
+
+@pytest.mark.parametrize("key", ["mm_real", "mm_complex", "mm_integer", "mm_pattern"])
+def test_loader_fields(host, golden, key):
+    k = golden["kat"][key]
+    h = host.mm_from_text(k["mtx"])
+    info = host.mm_info(h)
+    assert (info["rows"], info["columns"], info["num_entries"]) == (1, 1, 1)
+    assert info["format"] == 0 and info["symmetry"] == 0
+    assert info["field"] == ["real", "complex", "integer", "pattern"].index(k["field"])
+    assert host.mm_comment(h, 0) == "% Test matrix"
+    i, j, a = host.mm_entries(h)
+    assert i.tolist() == k["i"] and j.tolist() == k["j"] and a.tolist() == k["a"]
+    host.mm_free(h)
+
+
+def test_loader_compressed_fixtures(host, golden, tmp_path):
+    k = golden["kat"]["mm_compressed"]
+    # gzip'ed .mtx straight from the reference's byte array
+    h = host.mm_load(os.path.join(GOLDEN, "test_mtx.gz"))
+    i, j, a = host.mm_entries(h)
+    assert (i.tolist(), j.tolist(), a.tolist()) == (k["i"], k["j"], k["a"])
+    assert host.mm_comment(h, 0) == k["comment"]
+    host.mm_free(h)
+    # the reference's tar.gz fixture holds member "test.mtx"
+    h = host.mm_load_tar_gz_member(os.path.join(GOLDEN, "test_mtx.tar.gz"), k["member"])
+    i, j, a = host.mm_entries(h)
+    assert (i.tolist(), j.tolist(), a.tolist()) == (k["i"], k["j"], k["a"])
+    host.mm_free(h)
+    # its plain tar fixture, gzip'ed here
+    p = str(tmp_path / "fixture.tar.gz")
+    with gzip.open(p, "wb") as f:
+        f.write(open(os.path.join(GOLDEN, "test_mtx.tar"), "rb").read())
+    h = host.mm_load_tar_gz_member(p, k["member"])
+    assert host.mm_entries(h)[2].tolist() == k["a"]
+    host.mm_free(h)
+
+
+def test_loader_suitesparse_tarball_layout(host, golden, tmp_path):
+    """<name>.tar.gz containing <name>/<name>.mtx next to other members (what SuiteSparse ships)."""
+    text = golden["poisson2D_mtx"].encode()
+    for suffix in (".tar.gz", ".tgz"):
+        p = str(tmp_path / ("poisson2D" + suffix))
+        with tarfile.open(p, "w:gz") as t:
+            for name, data in (("poisson2D/README.txt", b"x" * 3000), ("poisson2D/poisson2D_b.mtx", b"%%junk\n" * 200),
+                               ("poisson2D/poisson2D.mtx", text), ("poisson2D/zzz", b"tail")):
+                ti = tarfile.TarInfo(name)
+                ti.size = len(data)
+                t.addfile(ti, io.BytesIO(data))
+        h = host.mm_load(p)
+        assert host.mm_info(h)["num_entries"] == 2417
+        host.mm_free(h)
+    with pytest.raises(hostlib.HostError):
+        host.mm_load_tar_gz_member(p, "nope/nope.mtx")
+
+
+def test_loader_accept_set(host):
+    # entries are whitespace-separated records, not lines; '+' signs; header words case-insensitive
+    h = host.mm_from_text("%%MatrixMarket MATRIX Coordinate Real GENERAL\n%c1\n%c2\n3 3 3\n1 1 +1.5 2\n2 -2.5e0\n\n3   3\t.25\n")
+    i, j, a = host.mm_entries(h)
+    assert (i.tolist(), j.tolist(), a.tolist()) == ([1, 2, 3], [1, 2, 3], [1.5, -2.5, 0.25])
+    assert host.mm_info(h)["comments"] == 2
+    host.mm_free(h)
+    # extra tokens after the declared entries are ignored (the reference stops reading too)
+    h = host.mm_from_text("%%MatrixMarket matrix coordinate real general\n1 1 1\n1 1 2.0\n9 9 9\n")
+    assert host.mm_entries(h)[2].tolist() == [2.0]
+    host.mm_free(h)
+    # array format: size only; converters reject it
+    h = host.mm_from_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    assert host.mm_info(h)["format"] == 1
+    with pytest.raises(hostlib.HostError, match="Expected matrix in coordinate format"):
+        host.csr(h)
+    host.mm_free(h)
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("%%matrixmarket matrix coordinate real general\n1 1 0\n", 'Expected "%%MatrixMarket", got "%%matrixmarket"'),
+    ("%%MatrixMarket vector coordinate real general\n1 1 0\n", 'Expected "matrix", got "vector"'),
+    ("%%MatrixMarket matrix sparse real general\n1 1 0\n", 'Expected "coordinate" or "array", got "sparse"'),
+    ("%%MatrixMarket matrix coordinate quaternion general\n1 1 0\n", 'got "quaternion"'),
+    ("%%MatrixMarket matrix coordinate real diagonal\n1 1 0\n", 'got "diagonal"'),
+    ("%%MatrixMarket matrix coordinate real general\n", "Failed to parse size"),
+    ("%%MatrixMarket matrix coordinate real general\n3000000000 1 1\n", "number of rows"),
+    ("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n2 2 2.0\n", "Expected 3 entries, got 2 entries"),
+    ("%%MatrixMarket matrix coordinate real general\n2 2 1\n1 x 1.0\n", "bad token in entry 1"),
+])
+def test_loader_rejects(host, text, msg):
+    with pytest.raises(hostlib.HostError, match=msg.replace('"', '\\"').replace("%", "%")):
+        host.mm_from_text(text)
+
+
+def test_loader_missing_file_and_reorder_suffix(host):
+    with pytest.raises(hostlib.HostError, match="No such file or directory"):
+        host.mm_load("/nonexistent/a.mtx")
+    with pytest.raises(hostlib.HostError, match="reordering"):
+        host.mm_load("/tmp/a.mtx__RCM")
+
+
+def test_index_bounds_are_checked(host):
+    h = host.mm_from_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(hostlib.HostError, match="Row index out of bounds"):
+        host.csr(h)
+    host.mm_free(h)
+    h = host.mm_from_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n1 0 1.0\n")
+    for conv in (host.csr, host.coo, host.ell):
+        with pytest.raises(hostlib.HostError, match="Column index out of bounds"):
+            conv(h)
+    host.mm_free(h)
+
+
+def test_sorting_and_row_length_kats(host, golden):
+    k = golden["kat"]["mm_max_row_length"]
+    h = host.mm_from_text(k["mtx"])
+    assert host.mm_max_row_length(h) == k["max_row_length"]
+    k = golden["kat"]["mm_sort_row_major"]
+    i, j, a = host.mm_sorted(h)
+    assert (i.tolist(), j.tolist(), a.tolist()) == (k["i"], k["j"], k["a"])
+    i, j, a = host.mm_sorted(h, column_major=True)  # test_matrix-market.cpp:181-199
+    assert (i.tolist(), j.tolist()) == ([1, 2, 1, 2, 3, 1, 4, 4], [1, 1, 2, 2, 3, 4, 4, 5])
+    host.mm_free(h)
+
+
+# ---- converters + CPU kernels: reference KATs and reference-generated vectors ----------------
+
+def test_converter_kats(host, golden):
+    K = golden["kat"]
+    h = host.mm_from_text(K["csr_from_matrix_market"]["mtx"])
+    A, info, p, j, a = host.csr(h)
+    k = K["csr_from_matrix_market"]
+    assert (p.tolist(), j.tolist(), a.tolist()) == (k["row_ptr"], k["column_index"], k["value"])
+    assert host.csr_spmv(A, 4, K["csr_spmv"]["x"]).tolist() == K["csr_spmv"]["y"]
+    A2, info2, p, j, a = host.csr(h, row_alignment=2)
+    k = K["csr_from_matrix_market_row_aligned"]
+    assert (p.tolist(), j.tolist(), a.tolist()) == (k["row_ptr"], k["column_index"], k["value"])
+    assert info2["num_entries"] == 7
+    host.mm_free(h)
+    h = host.mm_from_text(K["coo_from_matrix_market"]["mtx"])
+    A, info, r, c, v = host.coo(h)
+    k = K["coo_from_matrix_market"]
+    assert (r.tolist(), c.tolist(), v.tolist()) == (k["row_index"], k["column_index"], k["value"])
+    assert host.coo_spmv(A, 4, K["coo_spmv"]["x"]).tolist() == K["coo_spmv"]["y"]
+    host.mm_free(h)
+    h = host.mm_from_text(K["ell_from_matrix_market"]["mtx"])
+    A, info, c, v = host.ell(h)
+    k = K["ell_from_matrix_market"]
+    assert info["row_length"] == k["row_length"] and info["num_entries"] == k["num_entries"]
+    assert (c.tolist(), v.tolist()) == (k["column_index"], k["value"])
+    assert host.ell_spmv(A, 4, K["ell_spmv"]["x"]).tolist() == K["ell_spmv"]["y"]
+    Ac, _, r, c, v = host.coo(h)
+    assert host.coo_spmv(Ac, 4, K["coo_spmv_column_major"]["x"]).tolist() == K["coo_spmv_column_major"]["y"]
+    host.mm_free(h)
+
+
+def test_reference_vectors_bitexact(host, golden):
+    for case in golden["cases"]:
+        name = case["name"]
+        h = host.mm_from_text(helpers.case_mtx(golden, case))
+        info = host.mm_info(h)
+        assert (info["rows"], info["columns"], info["num_entries"], info["field"], info["symmetry"]) == (
+            case["rows"], case["columns"], case["num_entries"], case["field"], case["symmetry"]), name
+        if "entries" in case:
+            i, j, a = host.mm_entries(h)
+            assert i.tolist() == case["entries"]["i"] and j.tolist() == case["entries"]["j"]
+            assert_bitexact(a, unhex(case["entries"]["a"]), name + " values")
+        assert host.mm_max_row_length(h) == case["max_row_length"]
+        x = unhex(case["x"])
+        runs, threads = case["runs"], case["threads"]
+        g = case["csr"]
+        A, ci, p, j, a = host.csr(h, g["row_alignment"])
+        if "row_ptr" in g:
+            assert p.tolist() == g["row_ptr"] and j.tolist() == g["column_index"], name
+            assert_bitexact(a, unhex(g["value"]), name + " csr values")
+        assert ci["size"] == g["size"]
+        assert_bitexact(host.csr_spmv(A, case["rows"], x, threads=threads, runs=runs), unhex(g["y"]), name + " csr y")
+        g = case["coo"]
+        A, ci, r, c, v = host.coo(h)
+        if "row_index" in g:
+            assert r.tolist() == g["row_index"] and c.tolist() == g["column_index"]
+        assert ci["size"] == g["size"]
+        assert_bitexact(host.coo_spmv(A, case["rows"], x, threads=threads, runs=runs), unhex(g["y"]), name + " coo y")
+        g = case["ell"]
+        A, ci, c, v = host.ell(h)
+        assert ci["row_length"] == g["row_length"] and ci["size"] == g["size"]
+        if "column_index" in g:
+            assert c.tolist() == g["column_index"], name
+            assert_bitexact(v, unhex(g["value"]), name + " ell values")
+        assert_bitexact(host.ell_spmv(A, case["rows"], x, threads=threads, runs=runs), unhex(g["y"]), name + " ell y")
+        host.mm_free(h)
+
+
+def test_poisson2d_reference_tolerance(host, golden):
+    h = host.mm_from_text(golden["poisson2D_mtx"])
+    z = golden["poisson2D_result"]
+    A, _, p, j, a = host.csr(h)
+    for threads in (1, 2):
+        y = host.csr_spmv(A, 367, golden["poisson2D_b"], threads=threads)
+        assert np.sqrt(np.dot(y - z, y - z)) <= np.finfo(float).eps
+    host.mm_free(h)
+
+
+def test_host_matches_oracle_on_synthetic(host, oracle, tmp_path):
+    rows, cols, p, c, v = synth.powerlaw(4000, 4000, seed=21)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    perm = np.random.default_rng(3).permutation(len(a))
+    path = str(tmp_path / "pl.mtx")
+    synth.write_mtx(path, rows, cols, i[perm], j[perm], a[perm])
+    with open(path, "rb") as f, gzip.open(path + ".gz", "wb") as g:
+        g.write(f.read())
+    x = synth.x_vector(cols)
+    for pth in (path, path + ".gz"):
+        h = host.mm_load(pth)
+        A, info, hp, hj, ha = host.csr(h)
+        op, oc, ov = oracle.csr_from_coordinate(rows, i[perm], j[perm], a[perm])
+        # same (row, column) order; equal keys may differ only in the order of duplicates
+        assert hp.tolist() == op.tolist() and hj.tolist() == oc.tolist()
+        assert_bitexact(host.csr_spmv(A, rows, x, threads=3, runs=2),
+                        oracle.csr_spmv(rows, hp, hj, ha, x, num_threads=3, runs=2), "csr")
+        Ac, _, r, cc, vv = host.coo(h)
+        assert_bitexact(host.coo_spmv(Ac, rows, x, threads=2, runs=2),
+                        oracle.coo_spmv(rows, r, cc, vv, x, num_threads=2, runs=2), "coo")
+        assert np.allclose(host.coo_spmv(Ac, rows, x, threads=4, atomic=True), oracle.coo_spmv(rows, r, cc, vv, x),
+                           rtol=1e-12, atol=1e-14)
+        host.mm_free(h)
+
+
+def test_ell_overflow_message(host):
+    # 70000 rows, one row with 40000 entries: rows*row_length overflows int32 -> the reference's error
+    n = 40000
+    lines = ["%%MatrixMarket matrix coordinate pattern general", "70000 40000 %d" % n]
+    lines += ["1 %d" % (k + 1) for k in range(n)]
+    h = host.mm_from_text("\n".join(lines) + "\n")
+    with pytest.raises(hostlib.HostError, match="Failed to convert to ELLPACK: Integer overflow when computing number of non-zeros"):
+        host.ell(h)
+    host.mm_free(h)
+
+
+def test_ell_skip_padding_and_empty_first_row(host, oracle):
+    text = "%%MatrixMarket matrix coordinate real general\n4 4 4\n2 2 1.0\n2 3 2.0\n4 1 3.0\n3 4 4.0\n"
+    h = host.mm_from_text(text)
+    A, info, c, v = host.ell(h)
+    assert info["row_length"] == 2
+    # row 0 is empty: the reference reads before its array there; this build pads with column 0
+    assert c.tolist() == [0, 0, 1, 2, 3, 3, 0, 0] and v.tolist() == [0, 0, 1, 2, 4, 0, 3, 0]
+    x = np.array([1.0, 2.0, 3.0, 4.0])
+    assert host.ell_spmv(A, 4, x).tolist() == [0.0, 8.0, 16.0, 3.0]
+    A, info, c, v = host.ell(h, skip_padding=True)
+    assert c.tolist()[:2] == [2**31 - 1] * 2
+    assert host.ell_spmv(A, 4, x).tolist() == [0.0, 8.0, 16.0, 3.0]
+    host.mm_free(h)
+
+
+def test_expand_symmetry_extension(host, golden):
+    case = next(c for c in golden["cases"] if c["name"] == "symmetric_not_expanded")
+    h = host.mm_from_text(case["mtx"])
+    assert host.mm_info(h)["symmetry"] == 1 and host.mm_info(h)["num_entries"] == 8  # stored entries only
+    e = host.mm_expand_symmetry(h)
+    info = host.mm_info(e)
+    assert info["symmetry"] == 0 and info["num_entries"] == 8 + 3  # three off-diagonal entries mirrored
+    i, j, a = host.mm_entries(e)
+    dense = np.zeros((5, 5))
+    for r, c, v in zip(i, j, a):
+        dense[r - 1, c - 1] += v
+    assert np.array_equal(dense, dense.T)
+    host.mm_free(h)
+    host.mm_free(e)
+    h = host.mm_from_text("%%MatrixMarket matrix coordinate real skew-symmetric\n2 2 1\n2 1 3.0\n")
+    e = host.mm_expand_symmetry(h)
+    assert sorted(zip(*[t.tolist() for t in host.mm_entries(e)])) == [(1, 2, -3.0), (2, 1, 3.0)]
+
+
+# ---- statistics and JSON ------------------------------------------------------------------------
+
+def test_print_sample_matches_reference_text(host, golden):
+    for name, s in golden["print_sample"].items():
+        assert host.print_sample(s["v"]) == s["json"], name
+
+
+def test_print_sample_against_reference_library(host, reflib):
+    rng = np.random.default_rng(8)
+    for n in (1, 2, 3, 10, 101):
+        v = rng.integers(1000, 10**9, n)
+        assert host.print_sample(v) == reflib.print_sample(v)
+
+
+def test_trace_config_echo(host):
+    want = json.load(open(os.path.join(GOLDEN, "trace_config_echo.json")))
+    for name, g in want.items():
+        text, info = host.trace_config_echo(os.path.join(GOLDEN, name))
+        assert text == g["echo"], name
+        assert info == g["info"]
+
+
+@pytest.mark.parametrize("text,msg", [
+    ('{"caches": {}, "thread_affinities": [{"cpu": 0, "cache": "L1", "numa_domain": 0}]}', "Expected a first-level cache"),
+    ('{"thread_affinities": []}', 'Expected "caches" object'),
+    ('{"caches": {"L1": {"size": 100, "line_size": 64, "bandwidth": null, "bandwidth_per_numa_domain": null, '
+     '"cache_miss_event": null, "parent": null}}, "thread_affinities": []}', "to be a multiple of line_size"),
+    ('{"caches": {"L1": {"size": 128, "line_size": 64}}, "thread_affinities": []}', 'Expected "bandwidth"'),
+    ('{"caches": {"L1": {"size": 128, "line_size": 64, "bandwidth": null, "bandwidth_per_numa_domain": null, '
+     '"cache_miss_event": null, "parent": "L9"}}, "thread_affinities": []}', "Expected a cache or numa domain"),
+    ('{"caches": {}, "num_numa_domains": 1, "thread_affinities": [{"cpu": 0, "cache": "L1"}]}', 'Expected "numa_domain"'),
+    ('{"caches": {} "thread_affinities": []}', "line 1, column"),
+])
+def test_trace_config_rejects(host, reflib, tmp_path, text, msg):
+    p = str(tmp_path / "tc.json")
+    open(p, "w").write(text)
+    with pytest.raises(hostlib.HostError, match=msg):
+        host.trace_config_echo(p)
+    with pytest.raises(RuntimeError):  # the reference rejects the same files
+        reflib.trace_config_echo(p)
+
+
+# ---- the CLI: BASELINE configs[0] = 1138_bus-shaped matrix, CSR, CPU path, 1 thread ----------
+
+BUS = os.path.join(GOLDEN, "bus1138_like.mtx")
+TC1 = os.path.join(GOLDEN, "trace_config_1thread.json")
+TC2 = os.path.join(GOLDEN, "trace_config_2threads.json")
+
+
+def test_cli_config0_plumbing():
+    rc, out, err = hostlib.run_cli("--trace-config", TC1, "--spmv-format", "csr", "-m", BUS, "--profile=7")
+    assert rc == 0, err
+    doc = json.loads(out)
+    assert list(doc.keys()) == ["trace_config", "kernel", "execution_time", "profiling_events"]
+    k = doc["kernel"]
+    # field for field the reference's csr kernel object (src/kernels/csr-spmv.cpp:97-112);
+    # the symmetric file is NOT expanded: 2596 stored entries, matrix_size as in README.md:106
+    assert k == {"name": "csr-spmv", "matrix_path": BUS, "matrix_format": "csr", "rows": 1138, "columns": 1138,
+                 "nonzeros": 2596, "matrix_size": 35708, "x_size": 9104, "y_size": 9104}
+    t = doc["execution_time"]
+    assert list(t.keys()) == ["samples", "min", "max", "mean", "median", "variance", "standard_deviation",
+                              "skewness", "kurtosis", "unit"]
+    assert t["samples"] == 7 and t["unit"] == "ns" and 0 < t["min"] <= t["median"] <= t["max"]
+    assert doc["profiling_events"] == []
+    assert doc["trace_config"]["name"] == "one-thread"
+    # the echoed configuration is the reference's echo, re-indented inside the report
+    want = json.load(open(os.path.join(GOLDEN, "trace_config_echo.json")))["trace_config_1thread.json"]["echo"]
+    assert doc["trace_config"] == json.loads(want)
+    assert '"trace_config": ' + want.replace("\n", "\n  ") + "," in out  # same text, two spaces deeper
+
+
+@pytest.mark.parametrize("fmt,name", [("csr", "csr-spmv"), ("coo", "coo-spmv"), ("coo-atomic", "coo-spmv-atomic"), ("ell", "ell-spmv")])
+def test_cli_cpu_formats_and_readme_spellings(fmt, name):
+    # 2-thread COO carries the reference's stale-workspace recurrence: after warm-up + 3
+    # runs y is not 4*A*x, so the parity check is made with one thread for that kernel
+    tc = TC1 if fmt == "coo" else TC2
+    rc, out, err = hostlib.run_cli("-c", tc, "--spmv-format", fmt, "--matrix", BUS, "-p", 3, "--check")
+    assert rc == 0, err
+    doc = json.loads(out)
+    assert doc["kernel"]["name"] == name and doc["kernel"]["nonzeros"] == 2596
+    assert doc["execution_time"]["samples"] == 3
+    assert doc["parity"]["pass"] is True
+    if fmt == "coo":
+        rc, out, err = hostlib.run_cli("-c", TC2, "--spmv-format", fmt, "--matrix", BUS, "-p", 3, "--check")
+        assert rc == 1 and "parity check failed" in err  # the recurrence, faithfully reproduced
+        doc["kernel"] = json.loads(out)["kernel"]
+    if fmt in ("csr", "coo", "ell"):
+        rc, out2, err = hostlib.run_cli("-c", TC2, "--" + fmt, BUS, "--profile=3")  # README.md:81,124
+        assert rc == 0 and json.loads(out2)["kernel"] == doc["kernel"]
+
+
+def test_cli_single_sample_prints_nan_strings():
+    rc, out, err = hostlib.run_cli("--threads", 1, "--csr", BUS, "--profile=1")
+    assert rc == 0, err
+    t = json.loads(out)["execution_time"]
+    assert t["variance"] == "nan" and t["kurtosis"] == "nan" and t["samples"] == 1
+
+
+def test_cli_expand_symmetric_extension():
+    rc, out, err = hostlib.run_cli("--threads", 1, "--csr", BUS, "-p", 2, "--expand-symmetric")
+    assert rc == 0, err
+    assert json.loads(out)["kernel"]["nonzeros"] == 2 * 2596 - 1138
+
+
+def test_cli_errors():
+    rc, out, err = hostlib.run_cli("--csr", BUS, "--profile=1")
+    assert rc != 0 and "Please specify --trace-config" in err
+    rc, out, err = hostlib.run_cli("-c", TC1, "--csr", "/nonexistent.mtx", "--profile=1")
+    assert rc == 1 and err.strip() == "csr-spmv: /nonexistent.mtx: No such file or directory" and out == ""
+    rc, out, err = hostlib.run_cli("-c", "/nonexistent.json", "--csr", BUS, "--profile=1")
+    assert rc == 1 and err.strip() == "/nonexistent.json: No such file or directory"
+    rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS)
+    assert rc == 1 and "Cache tracing" in err
+    rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", "hybrid", "-m", BUS, "-p", 1)
+    assert rc != 0 and "not part of this build" in err
+    rc, out, err = hostlib.run_cli("--list-perf-events")
+    assert rc == 1 and "libpfm" in err
+
+
+def test_cli_gpu_kernels_fail_without_a_gpu():
+    from spmv_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    for fmt in ("hip-csr", "hip-coo", "hip-ell"):
+        rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", fmt, "-m", BUS, "-p", 1)
+        assert rc == 1 and out == "" and "no HIP device" in err, (fmt, err)
+    rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS, "--device", "hip", "-p", 1)
+    assert rc == 1 and "hip-csr-spmv" in err
+
+
+def test_cli_triad_cpu():
+    rc, out, err = hostlib.run_cli("--threads", 2, "--triad", 100000, "-p", 3)
+    assert rc == 0, err
+    doc = json.loads(out)
+    assert doc["kernel"]["name"] == "triad" and doc["kernel"]["num_entries"] == "100000"
