@@ -91,6 +91,27 @@ def host_cores():
     return n
 
 
+def pmc_traffic(kernel_name, algorithmic_bytes):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_summary.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
+    the figure is only reported when the summary was taken on the same kernel and workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            rl = (d.get("bench_line") or {}).get("roofline", {})
+            if rl.get("algorithmic_bytes_per_launch") != algorithmic_bytes:
+                continue
+            for k in d["kernels"]:
+                if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k:
+                    best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+        except (OSError, ValueError, KeyError):
+            continue
+    return best
+
+
 def cpu_baseline(args, rows, cols, p, c, v, x):
     """Reference OpenMP CSR kernel (or the C oracle) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -257,6 +278,10 @@ def main():
             "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
             "setup_s": round(setup_s, 1),
         }
+        tr = pmc_traffic(out["roofline"]["kernel"], int(local_bytes))
+        if tr:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if parity:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:

@@ -53,8 +53,8 @@ constexpr int kTile = 2048;
 constexpr int kCUs = 256;
 // wavetile: rows longer than kSplitThreshold entries are cut into kSplitChunk-entry
 // chunks handled by different waves (each adds its partial sum with one atomic)
-constexpr int kSplitThreshold = 8192;
-constexpr int kSplitChunk = 4096;
+constexpr int kSplitThreshold = 2048;
+constexpr int kSplitChunk = 1024;
 
 int grid_for(long long work_items, int per_block, int max_blocks = kCUs * 8)
 {
@@ -479,8 +479,8 @@ int spmv_hip_triad(int64_t n, double * a, const double * b, const double * c, do
     if (!aligned16(a) || !aligned16(b) || !aligned16(c))
         return fail(SPMV_HIP_ERR_ALIGN, "triad arrays must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for((n + 1) / 2, kBlock, kCUs * 16);
-    hipLaunchKernelGGL((spmv::triad_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+    const int grid = grid_for((n / 2 + 3) / 4, kBlock, kCUs * 8);
+    hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(grid), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
 }

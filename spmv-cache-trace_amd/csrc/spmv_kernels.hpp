@@ -249,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // is wave-uniform (the tile's longest row).
 //
 // A row longer than TILE is a tile by itself (the wave strides it); rows longer than
-// kSplitThreshold are cut into chunks spread over several waves (bit 31 of the row
+// kSplitThreshold (2048 entries) are cut into chunks spread over several waves (bit 31 of the row
 // field), each adding its partial sum with one fp64 atomic.
 // ---------------------------------------------------------------------------------
 constexpr int kTileFlagPartial = (int) 0x80000000u;
@@ -540,18 +540,33 @@ __global__ __launch_bounds__(BLOCK) void ell_transpose_kernel(
 // lane per step (16-byte loads/stores), grid-stride.  The measured rate of this
 // kernel is the empirical HBM roofline the SpMV kernels are compared against.
 // ---------------------------------------------------------------------------------
-template <int BLOCK>
+template <int BLOCK, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void triad_kernel(
     long long n, double * __restrict__ a, const double * __restrict__ b,
     const double * __restrict__ c, double q)
 {
-    const long long n2 = n >> 1;
+    const long long n2 = n >> 1; // double2 elements
+    const double2 * __restrict__ b2 = reinterpret_cast<const double2 *>(b);
+    const double2 * __restrict__ c2 = reinterpret_cast<const double2 *>(c);
+    double2 * __restrict__ a2 = reinterpret_cast<double2 *>(a);
     const long long stride = (long long) gridDim.x * BLOCK;
     const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
-    for (long long i = gid; i < n2; i += stride) {
-        const double2 vb = reinterpret_cast<const double2 *>(b)[i];
-        const double2 vc = reinterpret_cast<const double2 *>(c)[i];
-        reinterpret_cast<double2 *>(a)[i] = make_double2(vb.x + q * vc.x, vb.y + q * vc.y);
+    long long i = gid;
+    // UNROLL independent 16-byte loads per array in flight per lane
+    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
+        double2 vb[UNROLL], vc[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            vb[u] = b2[i + u * stride];
+            vc[u] = c2[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            a2[i + u * stride] = make_double2(vb[u].x + q * vc[u].x, vb[u].y + q * vc[u].y);
+    }
+    for (; i < n2; i += stride) {
+        const double2 vb = b2[i], vc = c2[i];
+        a2[i] = make_double2(vb.x + q * vc.x, vb.y + q * vc.y);
     }
     if ((n & 1) && gid == 0)
         a[n - 1] = b[n - 1] + q * c[n - 1];

@@ -246,8 +246,8 @@ def test_edge_cases_csr(ctx, oracle):
     cases["mostly_empty"] = (1000, 11, p, np.arange(10, dtype=np.int32), np.linspace(-1, 1, 10))
     rng = np.random.default_rng(11)
     # rows right at the tile boundaries of the adaptive (2048) and wave-tile (512 / 1024)
-    # kernels, and rows long enough to be split over several waves (> 8192 entries)
-    for L in (508, 511, 512, 513, 1023, 1024, 1025, T - 4, T - 1, T, T + 1, 3 * T + 5, 8193, 20001):
+    # kernels, and rows long enough to be split over several waves (> 2048 entries)
+    for L in (508, 511, 512, 513, 1023, 1024, 1025, T - 4, T - 1, T, T + 1, 2049, 3 * T + 5, 8193, 20001):
         lens = np.array([3, L, 2, L, 1], dtype=np.int64)
         p = np.zeros(6, dtype=np.int32)
         p[1:] = np.cumsum(lens)

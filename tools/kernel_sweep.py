@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="")
+    ap.add_argument("--formats", default="csr", help="comma list of csr,coo,coo_shuffled,ell")
     args = ap.parse_args()
     import torch
     from spmv_amd import capi, synth
@@ -103,6 +104,60 @@ def main():
         print("%-16s median %9.2f us  min %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s, %.1f%% of triad)  %7.1f GFLOP/s" % (
             k, med, mn, nbytes / med / 1e3, 100 * nbytes / med / 1e3 / 8000,
             100 * nbytes / med / 1e3 / triad_gbs, 2 * nnz / med / 1e3))
+    # ---- the other two formats on the same matrix ------------------------------------------
+    fmts = args.formats.split(",")
+    others = {}
+
+    def time_it(fn):
+        t = []
+        for rnd in range(args.rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd > 0:
+                t.append(e0.elapsed_time(e1) / args.reps * 1e3)
+        return float(np.median(t))
+
+    if "coo" in fmts or "coo_shuffled" in fmts:
+        ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(p.astype(np.int64)))
+        cb = synth.coo_bytes(rows, cols, nnz)
+        for name in ("coo", "coo_shuffled"):
+            if name not in fmts:
+                continue
+            perm = np.arange(nnz) if name == "coo" else np.random.default_rng(1).permutation(nnz)
+            tr = torch.from_numpy(ri[perm]).to(dev)
+            tcc = torch.from_numpy(c[perm]).to(dev)
+            tvv = torch.from_numpy(v[perm]).to(dev)
+            med = time_it(lambda: capi.coo_spmv(rows, nnz, tr.data_ptr(), tcc.data_ptr(), tvv.data_ptr(),
+                                                tx.data_ptr(), ty.data_ptr(), stream))
+            others[name] = {"us_median": round(med, 2), "gbs": round(cb / med / 1e3, 1), "gflops": round(2 * nnz / med / 1e3, 1)}
+            print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [bytes %.3f GB]" % (
+                name, med, cb / med / 1e3, cb / med / 1e3 / 80, 2 * nnz / med / 1e3, cb / 1e9))
+            del tr, tcc, tvv
+    if "ell" in fmts:
+        L = int(np.diff(p).max())
+        if rows * L < 2**31 and rows * L * 12 < 40e9:
+            lens = np.diff(p.astype(np.int64))
+            ec = np.zeros((rows, L), dtype=np.int32)
+            ev = np.zeros((rows, L))
+            mask = np.arange(L)[None, :] < lens[:, None]
+            ec[mask] = c
+            ev[mask] = v
+            tec = torch.from_numpy(np.ascontiguousarray(ec.T)).to(dev)  # column-major
+            tev = torch.from_numpy(np.ascontiguousarray(ev.T)).to(dev)
+            eb = synth.ell_bytes(rows, cols, L)
+            med = time_it(lambda: capi.ell_spmv(rows, L, tec.data_ptr(), tev.data_ptr(), tx.data_ptr(),
+                                                ty.data_ptr(), stream))
+            others["ell"] = {"us_median": round(med, 2), "row_length": L, "gbs": round(eb / med / 1e3, 1),
+                             "gflops": round(2 * nnz / med / 1e3, 1)}
+            print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [L=%d, bytes %.3f GB]" % (
+                "ell", med, eb / med / 1e3, eb / med / 1e3 / 80, 2 * nnz / med / 1e3, L, eb / 1e9))
+        else:
+            print("ell: skipped (rows*row_length = %d x %d too large)" % (rows, L))
+    res["other_formats"] = others
     print(json.dumps({"workload": args.workload, "rows": rows, "nnz": nnz, "triad_gbs": round(triad_gbs, 1), "results": res}))
 
 
