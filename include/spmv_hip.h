@@ -107,6 +107,15 @@ int spmv_hip_upload_coo(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t n
 int spmv_hip_upload_ell(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t row_length,
                         const int32_t *column_index, const double *value);
 
+/* Hybrid ELLPACK + COO (src/matrix/hybrid-matrix.hpp:83-96): the ELL part in the reference's
+ * row-major layout (rows*ell_row_length entries), the remainder as COO triplets.  One run
+ * launches the ELL kernel and then the COO kernel on the same stream
+ * (hybrid_matrix::spmv, src/matrix/hybrid-matrix.cpp:535-567). */
+int spmv_hip_upload_hybrid(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t ell_row_length,
+                           const int32_t *ell_column_index, const double *ell_value,
+                           int32_t num_coo_entries, const int32_t *coo_row_index,
+                           const int32_t *coo_column_index, const double *coo_value);
+
 /* x has `cols` doubles, y has `rows` doubles (src/kernels/csr-spmv.cpp:35-36). */
 int spmv_hip_set_x(spmv_hip_ctx *ctx, const double *x);
 int spmv_hip_set_y(spmv_hip_ctx *ctx, const double *y);
@@ -123,7 +132,7 @@ int spmv_hip_sync(spmv_hip_ctx *ctx);
 int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
 
 /* Descriptive numbers for JSON output / tests.  out[] receives up to n of:
- * [0] format (0 none, 1 csr, 2 coo, 3 ell)  [1] rows  [2] cols  [3] stored entries
+ * [0] format (0 none, 1 csr, 2 coo, 3 ell, 4 hybrid)  [1] rows  [2] cols  [3] stored entries
  * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
  * [7] row blocks (adaptive)  [8] long-row blocks (adaptive)  [9] device bytes held */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);

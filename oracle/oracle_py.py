@@ -72,6 +72,12 @@ class Oracle:
         L.oracle_ell_from_coordinate.restype = C.c_int
         L.oracle_sample_stats.argtypes = [_i64p, C.c_int64, _f64p]
         L.oracle_sample_stats.restype = None
+        L.oracle_hybrid_from_coordinate.argtypes = [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, C.c_int, _i32p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_hybrid_from_coordinate.restype = C.c_int
+        L.oracle_hybrid_spmv.argtypes = [C.c_int, C.c_int32, C.c_int32, _i32p, _f64p, C.c_int, C.c_int32,
+                                         _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]
+        L.oracle_hybrid_spmv.restype = None
 
     # -- SpMV: all of these ACCUMULATE into (a copy of) y, like the reference --
     def csr_spmv(self, rows, row_ptr, col, val, x, y=None, num_threads=1, runs=1):
@@ -143,6 +149,33 @@ class Oracle:
         rc = self.lib.oracle_ell_from_coordinate(rows, len(a), i, j, a, int(skip_padding), L, col, val)
         return rc, L, col[:n], val[:n]
 
+    def hybrid_from_coordinate(self, rows, i, j, a, skip_padding=False):
+        """-> dict(row_length, ell_col, ell_val, coo_row, coo_col, coo_val) or None on int32 overflow."""
+        i, j, a = _i32(i), _i32(j), _f64(a)
+        sizes = np.zeros(3, dtype=np.int32)
+        if self.lib.oracle_hybrid_from_coordinate(rows, len(a), i, j, a, int(skip_padding), sizes,
+                                                  None, None, None, None, None) != 0:
+            return None
+        L, ne, nc = (int(t) for t in sizes)
+        ej, ea = np.zeros(max(1, ne), dtype=np.int32), np.zeros(max(1, ne))
+        cr, cc, cv = np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc))
+        vp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+        self.lib.oracle_hybrid_from_coordinate(rows, len(a), i, j, a, int(skip_padding), sizes,
+                                               vp(ej), vp(ea), vp(cr), vp(cc), vp(cv))
+        return dict(row_length=L, ell_col=ej[:ne], ell_val=ea[:ne], coo_row=cr[:nc], coo_col=cc[:nc],
+                    coo_val=cv[:nc], skip_padding=bool(skip_padding))
+
+    def hybrid_spmv(self, rows, H, x, y=None, num_threads=1, runs=1):
+        y = np.zeros(rows) if y is None else _f64(y).copy()
+        ws = np.zeros(max(1, num_threads * rows))
+        pad = lambda arr, dt: np.ascontiguousarray(arr if len(arr) else np.zeros(1), dtype=dt)
+        for _ in range(runs):
+            self.lib.oracle_hybrid_spmv(num_threads, rows, H["row_length"], pad(H["ell_col"], np.int32),
+                                        pad(H["ell_val"], np.float64), int(H["skip_padding"]), len(H["coo_val"]),
+                                        pad(H["coo_row"], np.int32), pad(H["coo_col"], np.int32),
+                                        pad(H["coo_val"], np.float64), _f64(x), y, ws)
+        return y
+
     def sample_stats(self, v):
         v = np.ascontiguousarray(v, dtype=np.int64)
         out = np.zeros(8)
@@ -200,6 +233,13 @@ class RefLib:
         L.ref_ell_spmv.restype = C.c_int
         L.ref_print_sample.argtypes = [_i64p, C.c_int64, C.c_char_p, C.c_int64]
         L.ref_print_sample.restype = C.c_int64
+        L.ref_hybrid_from_mm.argtypes = [vp, C.c_int]
+        L.ref_hybrid_from_mm.restype = vp
+        L.ref_hybrid_free.argtypes = [vp]
+        L.ref_hybrid_info.argtypes = [vp, _i64p]
+        L.ref_hybrid_arrays.argtypes = [vp, _i32p, _f64p, _i32p, _i32p, _f64p]
+        L.ref_hybrid_spmv.argtypes = [vp, _f64p, _f64p, C.c_int, C.c_int]
+        L.ref_hybrid_spmv.restype = C.c_int
         L.ref_trace_config_echo.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, _i32p]
         L.ref_trace_config_echo.restype = C.c_int64
 
@@ -344,6 +384,37 @@ class RefLib:
         info = self.ell_info(A)
         y = np.zeros(info["rows"]) if y is None else _f64(y).copy()
         if self.lib.ref_ell_spmv(A, _f64(x), y, num_threads, runs) != 0:
+            raise RuntimeError(self.error())
+        return y
+
+    # -- HYBRID --
+    def hybrid_from_mm(self, h, skip_padding=False):
+        A = self.lib.ref_hybrid_from_mm(h, int(skip_padding))
+        if not A:
+            raise RuntimeError(self.error())
+        return A
+
+    def hybrid_free(self, A):
+        self.lib.ref_hybrid_free(A)
+
+    def hybrid_info(self, A):
+        out = np.zeros(7, dtype=np.int64)
+        self.lib.ref_hybrid_info(A, out)
+        return dict(zip(["rows", "columns", "num_entries", "row_length", "ell_stored", "coo_entries", "size"],
+                        out.tolist()))
+
+    def hybrid_arrays(self, A):
+        info = self.hybrid_info(A)
+        ne, nc = info["ell_stored"], info["coo_entries"]
+        ej, ea = np.zeros(max(1, ne), dtype=np.int32), np.zeros(max(1, ne))
+        cr, cc, cv = np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc))
+        self.lib.ref_hybrid_arrays(A, ej, ea, cr, cc, cv)
+        return ej[:ne], ea[:ne], cr[:nc], cc[:nc], cv[:nc]
+
+    def hybrid_spmv(self, A, x, y=None, num_threads=1, runs=1):
+        info = self.hybrid_info(A)
+        y = np.zeros(info["rows"]) if y is None else _f64(y).copy()
+        if self.lib.ref_hybrid_spmv(A, _f64(x), y, num_threads, runs) != 0:
             raise RuntimeError(self.error())
         return y
 

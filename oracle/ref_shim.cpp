@@ -21,6 +21,7 @@
 #include "matrix/coo-matrix.hpp"
 #include "matrix/csr-matrix.hpp"
 #include "matrix/ell-matrix.hpp"
+#include "matrix/hybrid-matrix.hpp"
 #include "matrix/matrix-error.hpp"
 #include "matrix/matrix-market.hpp"
 #include "util/json-ostreambuf.hpp"
@@ -278,6 +279,63 @@ int ref_ell_spmv(void * h, const double * x, double * y, int num_threads, int ru
         {
             for (int r = 0; r < runs; r++) {
                 ell_matrix::spmv(A, xv, yv);
+                #pragma omp barrier
+            }
+        }
+        std::memcpy(y, yv.data(), yv.size() * sizeof(double));
+    });
+}
+
+/* ---- HYBRID ------------------------------------------------------------------- */
+
+void * ref_hybrid_from_mm(void * h, int skip_padding)
+{
+    hybrid_matrix::Matrix * A = nullptr;
+    int rc = guarded([&] {
+        std::ostringstream log;
+        A = new hybrid_matrix::Matrix(hybrid_matrix::from_matrix_market(
+            *static_cast<matrix_market::Matrix *>(h), skip_padding != 0, log, false));
+    });
+    return rc == 0 ? A : nullptr;
+}
+
+void ref_hybrid_free(void * h) { delete static_cast<hybrid_matrix::Matrix *>(h); }
+
+/* out[0..6] = rows, columns, num_entries, ell_row_length, stored ell entries, coo entries, size() */
+void ref_hybrid_info(void * h, int64_t * out)
+{
+    auto & A = *static_cast<hybrid_matrix::Matrix *>(h);
+    out[0] = A.rows;
+    out[1] = A.columns;
+    out[2] = A.num_entries;
+    out[3] = A.ell_row_length;
+    out[4] = (int64_t) A.ell_value.size();
+    out[5] = A.num_coo_entries;
+    out[6] = (int64_t) A.size();
+}
+
+void ref_hybrid_arrays(void * h, int32_t * ej, double * ea, int32_t * cr, int32_t * cc, double * cv)
+{
+    auto & A = *static_cast<hybrid_matrix::Matrix *>(h);
+    std::memcpy(ej, A.ell_column_index.data(), A.ell_column_index.size() * sizeof(int32_t));
+    std::memcpy(ea, A.ell_value.data(), A.ell_value.size() * sizeof(double));
+    std::memcpy(cr, A.coo_row_index.data(), A.coo_row_index.size() * sizeof(int32_t));
+    std::memcpy(cc, A.coo_column_index.data(), A.coo_column_index.size() * sizeof(int32_t));
+    std::memcpy(cv, A.coo_value.data(), A.coo_value.size() * sizeof(double));
+}
+
+int ref_hybrid_spmv(void * h, const double * x, double * y, int num_threads, int runs)
+{
+    auto & A = *static_cast<hybrid_matrix::Matrix *>(h);
+    return guarded([&] {
+        hybrid_matrix::value_array_type xv(x, x + A.columns);
+        hybrid_matrix::value_array_type yv(y, y + A.rows);
+        hybrid_matrix::value_array_type ws((size_t) num_threads * A.rows, 0.0);
+        omp_set_num_threads(num_threads);
+        #pragma omp parallel
+        {
+            for (int r = 0; r < runs; r++) {
+                hybrid_matrix::spmv(num_threads, A, xv, yv, ws);
                 #pragma omp barrier
             }
         }

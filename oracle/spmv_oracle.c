@@ -307,6 +307,137 @@ int oracle_ell_from_coordinate(int32_t rows, int32_t num_entries,
 }
 
 /* ------------------------------------------------------------------------
+ * Hybrid ELLPACK + COO
+ * ---------------------------------------------------------------------- */
+
+int oracle_hybrid_from_coordinate(int32_t rows, int32_t num_entries, const int32_t *i,
+                                  const int32_t *j, const double *a, int skip_padding,
+                                  int32_t *sizes, int32_t *ell_column_index, double *ell_value,
+                                  int32_t *coo_row_index, int32_t *coo_column_index,
+                                  double *coo_value)
+{
+    /* src/matrix/hybrid-matrix.cpp:329-335: histogram of row lengths */
+    int32_t *len = (int32_t *)calloc((size_t)(rows > 0 ? rows : 1), sizeof(int32_t));
+    for (int32_t k = 0; k < num_entries; ++k)
+        ++len[i[k] - 1];
+    int32_t max_len = 0;
+    for (int32_t r = 0; r < rows; ++r)
+        if (len[r] > max_len)
+            max_len = len[r];
+    int32_t *hist = (int32_t *)calloc((size_t)max_len + 1, sizeof(int32_t));
+    for (int32_t r = 0; r < rows; ++r)
+        hist[len[r]]++;
+    /* :337-344: smallest length such that at least 2/3 of the rows are not longer */
+    int32_t median = 0, below = 0;
+    while (below < (2 * rows) / 3) {
+        below += hist[median];
+        median++;
+    }
+    median = (median == 0) ? 0 : median - 1;
+    int32_t L = median, n_ell;
+    if (__builtin_mul_overflow(rows, L, &n_ell)) {
+        free(len);
+        free(hist);
+        return -1;
+    }
+    /* :357-360 */
+    int32_t n_coo = 0;
+    for (int32_t l = L + 1; l <= max_len; l++)
+        n_coo += hist[l] * (l - L);
+    free(hist);
+    sizes[0] = L;
+    sizes[1] = n_ell;
+    sizes[2] = n_coo;
+    if (!ell_column_index) {
+        free(len);
+        return 0;
+    }
+
+    int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(num_entries > 0 ? num_entries : 1));
+    oracle_sort_row_major(num_entries, i, j, perm);
+    /* :376-409 */
+    int32_t k = 0, e = 0, c = 0;
+    for (int32_t r = 0; r < rows; ++r) {
+        if (len[r] < L) {
+            for (int32_t q = 0; q < len[r]; q++) {
+                ell_column_index[e] = j[perm[k]] - 1;
+                ell_value[e] = a[perm[k]];
+                e++;
+                k++;
+            }
+            for (int32_t q = len[r]; q < L; q++) {
+                ell_column_index[e] = skip_padding ? INT32_MAX : (k > 0 ? j[perm[k - 1]] - 1 : 0);
+                ell_value[e] = 0.0;
+                e++;
+            }
+        } else {
+            for (int32_t q = 0; q < L; q++) {
+                ell_column_index[e] = j[perm[k]] - 1;
+                ell_value[e] = a[perm[k]];
+                e++;
+                k++;
+            }
+            for (int32_t q = L; q < len[r]; q++) {
+                coo_row_index[c] = i[perm[k]] - 1;
+                coo_column_index[c] = j[perm[k]] - 1;
+                coo_value[c] = a[perm[k]];
+                c++;
+                k++;
+            }
+        }
+    }
+    free(perm);
+    free(len);
+    return 0;
+}
+
+void oracle_hybrid_spmv(int num_threads, int32_t rows, int32_t L,
+                        const int32_t *ej, const double *ea, int skip_padding,
+                        int32_t n_coo, const int32_t *cr, const int32_t *cc, const double *cv,
+                        const double *x, double *y, double *workspace)
+{
+    if (num_threads < 1)
+        num_threads = 1;
+    /* src/matrix/hybrid-matrix.cpp:543-545: ONE chunk size, from the rows, for all loops */
+    int32_t chunk = (rows + num_threads - 1) / num_threads;
+    if (chunk < 1)
+        chunk = 1;
+#pragma omp parallel num_threads(num_threads)
+    {
+#ifdef _OPENMP
+        size_t thread = (size_t)omp_get_thread_num();
+#else
+        size_t thread = 0;
+#endif
+        /* :547-555 (inner loops :422-437 / :453-470) */
+#pragma omp for nowait schedule(static, chunk)
+        for (int32_t r = 0; r < rows; ++r) {
+            double z = 0.0;
+            for (int32_t l = 0; l < L; ++l) {
+                size_t k = (size_t)r * (size_t)L + (size_t)l;
+                if (skip_padding && ej[k] == INT32_MAX)
+                    break;
+                z += ea[k] * x[ej[k]];
+            }
+            y[r] += z;
+        }
+        /* :557-566 -> :490-527 */
+        if (num_threads == 1) {
+            for (int32_t k = 0; k < n_coo; ++k)
+                y[cr[k]] += cv[k] * x[cc[k]];
+        } else {
+#pragma omp for schedule(static, chunk)
+            for (int32_t k = 0; k < n_coo; ++k)
+                workspace[thread * (size_t)rows + cr[k]] += cv[k] * x[cc[k]];
+#pragma omp for schedule(static, chunk)
+            for (int32_t r = 0; r < rows; r++)
+                for (int32_t t = 0; t < num_threads; t++)
+                    y[r] += workspace[(size_t)t * (size_t)rows + r];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
  * Sample statistics (src/util/sample.hpp)
  * ---------------------------------------------------------------------- */
 

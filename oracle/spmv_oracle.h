@@ -99,6 +99,30 @@ int oracle_ell_from_coordinate(int32_t rows, int32_t num_entries,
                                int32_t row_length, int32_t *column_index,
                                double *value);
 
+/* ---- Hybrid ELLPACK + COO ---------------------------------- */
+
+/* src/matrix/hybrid-matrix.cpp:316-417.  ELL row length = the "2/3 median" of the row
+ * lengths (:337-344); rows shorter than that are padded (value 0.0, column = column of the
+ * entry consumed last, 0 if none yet, or INT32_MAX with skip_padding), the entries of longer
+ * rows beyond it go to a COO remainder in (row, column) order.
+ * Call with ell_column_index == NULL to get the sizes only.
+ * sizes[0] = ell_row_length, sizes[1] = rows*ell_row_length, sizes[2] = num_coo_entries.
+ * Returns 0, or -1 when rows*ell_row_length overflows int32 (:348-353). */
+int oracle_hybrid_from_coordinate(int32_t rows, int32_t num_entries, const int32_t *i,
+                                  const int32_t *j, const double *a, int skip_padding,
+                                  int32_t *sizes, int32_t *ell_column_index, double *ell_value,
+                                  int32_t *coo_row_index, int32_t *coo_column_index,
+                                  double *coo_value);
+
+/* src/matrix/hybrid-matrix.cpp:535-567: the ELL part (static row blocks), then the COO
+ * remainder exactly like coo_spmv but with chunk = ceil(rows / num_threads); workspace as for
+ * oracle_coo_spmv (never re-zeroed). */
+void oracle_hybrid_spmv(int num_threads, int32_t rows, int32_t ell_row_length,
+                        const int32_t *ell_column_index, const double *ell_value,
+                        int skip_padding, int32_t num_coo_entries, const int32_t *coo_row_index,
+                        const int32_t *coo_column_index, const double *coo_value,
+                        const double *x, double *y, double *workspace);
+
 /* ---- Sample statistics (src/util/sample.hpp:11-135) -------------------- */
 /* out[0..7] = min, max, mean, median, variance, standard_deviation,
  * skewness, kurtosis of n int64 samples (NaN where the reference gives NaN). */

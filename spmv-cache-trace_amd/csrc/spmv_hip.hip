@@ -87,13 +87,13 @@ struct spmv_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int format = 0; // 0 none, 1 csr, 2 coo, 3 ell
-    int32_t rows = 0, cols = 0, nnz = 0, row_length = 0;
+    int format = 0; // 0 none, 1 csr, 2 coo, 3 ell, 4 hybrid (ell + coo remainder)
+    int32_t rows = 0, cols = 0, nnz = 0, row_length = 0, nnz2 = 0;
     int csr_algorithm = SPMV_HIP_CSR_AUTO;
     int csr_lanes = 0;
     spmv_hip_plan * plan = nullptr;
-    int32_t *d_ptr = nullptr, *d_idx = nullptr, *d_col = nullptr;
-    double *d_val = nullptr, *d_x = nullptr, *d_y = nullptr;
+    int32_t *d_ptr = nullptr, *d_idx = nullptr, *d_col = nullptr, *d_col2 = nullptr;
+    double *d_val = nullptr, *d_val2 = nullptr, *d_x = nullptr, *d_y = nullptr;
     size_t bytes = 0;
 };
 
@@ -121,14 +121,14 @@ void free_ctx_matrix(spmv_hip_ctx * c)
         spmv_hip_plan_destroy(c->plan);
         c->plan = nullptr;
     }
-    void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y};
+    void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_col2, c->d_val, c->d_val2, c->d_x, c->d_y};
     for (void * p : ptrs)
         if (p)
             (void) hipFree(p);
-    c->d_ptr = c->d_idx = c->d_col = nullptr;
-    c->d_val = c->d_x = c->d_y = nullptr;
+    c->d_ptr = c->d_idx = c->d_col = c->d_col2 = nullptr;
+    c->d_val = c->d_val2 = c->d_x = c->d_y = nullptr;
     c->format = 0;
-    c->rows = c->cols = c->nnz = c->row_length = 0;
+    c->rows = c->cols = c->nnz = c->row_length = c->nnz2 = 0;
     c->bytes = 0;
 }
 
@@ -663,6 +663,39 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     return SPMV_HIP_OK;
 }
 
+int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ell_row_length,
+                           const int32_t * ell_column_index, const double * ell_value,
+                           int32_t num_coo_entries, const int32_t * coo_row_index,
+                           const int32_t * coo_column_index, const double * coo_value)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
+    for (int32_t k = 0; k < num_coo_entries; ++k)
+        if (coo_row_index[k] < 0 || coo_row_index[k] >= rows || coo_column_index[k] < 0 ||
+            coo_column_index[k] >= cols)
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+    // the ELL part is uploaded (validated, transposed) exactly like a plain ELLPACK matrix ...
+    int rc = spmv_hip_upload_ell(c, rows, cols, ell_row_length, ell_column_index, ell_value);
+    if (rc != 0)
+        return rc;
+    // ... and the COO remainder rides along
+    c->format = 0;
+    c->nnz2 = num_coo_entries;
+    if ((rc = dev_alloc(c, &c->d_idx, (size_t) num_coo_entries)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_col2, (size_t) num_coo_entries)) != 0) return rc;
+    if ((rc = dev_alloc(c, &c->d_val2, (size_t) num_coo_entries)) != 0) return rc;
+    if (num_coo_entries > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_idx, coo_row_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_col2, coo_column_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_val2, coo_value, (size_t) num_coo_entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->format = 4;
+    return SPMV_HIP_OK;
+}
+
 int spmv_hip_set_x(spmv_hip_ctx * c, const double * x)
 {
     if (!c || !x)
@@ -715,6 +748,11 @@ int spmv_hip_run(spmv_hip_ctx * c)
     case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
     case 2: rc = spmv_hip_coo_spmv(c->rows, c->nnz, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
     case 3: rc = spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 4:
+        rc = spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+        if (rc == 0)
+            rc = spmv_hip_coo_spmv(c->rows, c->nnz2, c->d_idx, c->d_col2, c->d_val2, c->d_x, c->d_y, c->stream);
+        break;
     }
     if (rc != 0)
         return rc;

@@ -203,6 +203,60 @@ private:
     ell_matrix::value_array_type x, y;
 };
 
+class hybrid_spmv_kernel : public Kernel
+{
+public:
+    hybrid_spmv_kernel(std::string path, SpmvOptions opt) : matrix_path(std::move(path)), options(opt) {}
+
+    void init(TraceConfig const & trace_config, std::ostream & o, bool verbose) override
+    {
+        int const num_threads = (int) trace_config.thread_affinities().size();
+        guarded_init(matrix_path, [&] {
+            if (verbose)
+                o << "Converting matrix to hybrid format" << std::endl;
+            A = hybrid_matrix::from_matrix_market(load(matrix_path, options, o, verbose));
+            x = hybrid_matrix::value_array_type((std::size_t) A.columns, 1.0);
+            y = hybrid_matrix::value_array_type((std::size_t) A.rows, 0.0);
+            std::size_t n;
+            if (__builtin_mul_overflow((std::size_t) num_threads, (std::size_t) A.rows, &n))
+                throw matrix::matrix_error(
+                    "Failed to compute HYBRID SpMV: Integer overflow when computing workspace size");
+            workspace = hybrid_matrix::value_array_type(n, 0.0);
+        });
+    }
+    void prepare(TraceConfig const &) override {}
+    void run(TraceConfig const & trace_config) override
+    {
+        hybrid_matrix::spmv((int) trace_config.thread_affinities().size(), A, x, y, workspace);
+    }
+    MemoryReferenceString memory_reference_string(TraceConfig const &, int, int) const override { no_reference_string(); }
+    std::string name() const override { return "hybrid-spmv"; }
+    std::ostream & print(std::ostream & o) const override { return print_hybrid(o, name(), matrix_path, A) << "\n}"; }
+    std::vector<double> result() const override { return std::vector<double>(y.begin(), y.end()); }
+    void set_x(std::vector<double> const & v) override
+    {
+        if (v.size() != x.size())
+            throw kernel_error("set_x: size mismatch");
+        std::copy(v.begin(), v.end(), x.begin());
+    }
+
+    // the reference's object (src/kernels/hybrid-spmv.cpp:111-131) without its stray second comma
+    // after "matrix_size", which makes the reference's own output invalid JSON
+    static std::ostream & print_hybrid(std::ostream & o, std::string const & name, std::string const & path,
+                                       hybrid_matrix::Matrix const & A)
+    {
+        return print_common(o, name, path, "hybrid", A.rows, A.columns, A.num_entries, A.size())
+            << ",\n\"ell_row_length\": " << A.ell_row_length << ",\n\"num_ell_entries\": " << A.num_ell_entries
+            << ",\n\"num_coo_entries\": " << A.num_coo_entries;
+    }
+
+private:
+    std::string matrix_path;
+    SpmvOptions options;
+    hybrid_matrix::Matrix A;
+    hybrid_matrix::value_array_type x, y, workspace;
+};
+
 // ------------------------------------------------------------------------------------
 // HIP kernels: the host object keeps A, x, y like its CPU sibling; the device copies live in
 // a spmv_hip_ctx.  run() is executed by the master thread only and returns after the device
@@ -385,6 +439,33 @@ private:
     ell_matrix::Matrix A;
 };
 
+class hip_hybrid_spmv_kernel : public hip_kernel_base
+{
+public:
+    using hip_kernel_base::hip_kernel_base;
+    void init(TraceConfig const &, std::ostream & o, bool verbose) override
+    {
+        guarded_init(matrix_path, [&] {
+            A = hybrid_matrix::from_matrix_market(load(matrix_path, options, o, verbose));
+            x.assign((std::size_t) A.columns, 1.0);
+            y.assign((std::size_t) A.rows, 0.0);
+        });
+        create_context();
+        check(spmv_hip_upload_hybrid(ctx, A.rows, A.columns, A.ell_row_length, A.ell_column_index.data(),
+                                     A.ell_value.data(), A.num_coo_entries, A.coo_row_index.data(),
+                                     A.coo_column_index.data(), A.coo_value.data()), "upload_hybrid");
+    }
+    std::string name() const override { return "hip-hybrid-spmv"; }
+    std::ostream & print(std::ostream & o) const override
+    {
+        hybrid_spmv_kernel::print_hybrid(o, name(), matrix_path, A);
+        return print_device(o) << "\n}";
+    }
+
+private:
+    hybrid_matrix::Matrix A;
+};
+
 } // namespace
 
 std::unique_ptr<Kernel> make_spmv_kernel(SpmvFormat format, bool hip, std::string const & path,
@@ -403,6 +484,9 @@ std::unique_ptr<Kernel> make_spmv_kernel(SpmvFormat format, bool hip, std::strin
     case SpmvFormat::ell:
         if (hip) return std::make_unique<hip_ell_spmv_kernel>(path, opt);
         return std::make_unique<ell_spmv_kernel>(path, opt);
+    case SpmvFormat::hybrid:
+        if (hip) return std::make_unique<hip_hybrid_spmv_kernel>(path, opt);
+        return std::make_unique<hybrid_spmv_kernel>(path, opt);
     }
     throw kernel_error("unknown kernel type");
 }

@@ -18,6 +18,7 @@
 #include "../matrix/coo-matrix.hpp"
 #include "../matrix/csr-matrix.hpp"
 #include "../matrix/ell-matrix.hpp"
+#include "../matrix/hybrid-matrix.hpp"
 
 #include <memory>
 #include <string>
@@ -34,7 +35,7 @@ struct SpmvOptions
     unsigned hip_flags = 0;        // SPMV_HIP_FLAG_*
 };
 
-enum class SpmvFormat { csr, coo, coo_atomic, ell };
+enum class SpmvFormat { csr, coo, coo_atomic, ell, hybrid };
 
 // Factory: `hip` selects the GPU implementation of the format.
 std::unique_ptr<Kernel> make_spmv_kernel(SpmvFormat format, bool hip, std::string const & matrix_path,

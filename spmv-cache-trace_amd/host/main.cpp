@@ -1,10 +1,10 @@
 // main.cpp -- command line of the MI355X SpMV engine.
 //
 // Keeps the reference's surface (src/main.cpp:139-188): --trace-config/-c, --matrix/-m,
-// --spmv-format {coo,coo-atomic,csr,ell}, --profile/-p N, --warmup, --flush-caches,
+// --spmv-format {coo,coo-atomic,csr,ell,hybrid}, --profile/-p N, --warmup, --flush-caches,
 // --verbose/-v, --triad N, one JSON document on stdout, one-line errors on stderr with
 // EXIT_FAILURE.  Accepted as well: the README's --csr/--coo/--ell PATH spellings.
-// New: --device hip (or --spmv-format hip-csr|hip-coo|hip-ell) runs the format on the GPU.
+// New: --device hip (or --spmv-format hip-csr|hip-coo|hip-ell|hip-hybrid) runs the format on the GPU.
 // The default mode of the reference (simulated cache tracing, no --profile) and its libpfm4
 // counters are outside this engine and are refused with a message.
 #include "kernels/spmv-kernels.hpp"
@@ -117,8 +117,9 @@ error_t parse_option(int key, char * arg, argp_state * state)
         else if (!std::strcmp(arg, "coo-atomic")) a.format = SpmvFormat::coo_atomic;
         else if (!std::strcmp(arg, "csr")) a.format = SpmvFormat::csr;
         else if (!std::strcmp(arg, "ell")) a.format = SpmvFormat::ell;
-        else if (!std::strcmp(arg, "mkl-csr") || !std::strcmp(arg, "hybrid"))
-            argp_error(state, "spmv-format '%s' is not part of this build (choose coo, coo-atomic, csr or ell)", arg);
+        else if (!std::strcmp(arg, "hybrid")) a.format = SpmvFormat::hybrid;
+        else if (!std::strcmp(arg, "mkl-csr"))
+            argp_error(state, "spmv-format '%s' is not part of this build (choose coo, coo-atomic, csr, ell or hybrid)", arg);
         else argp_error(state, "invalid argument");
         break;
     case key_csr: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::csr; a.matrix_path = arg; break;
@@ -201,7 +202,7 @@ int main(int argc, char ** argv)
 
         {nullptr, 0, nullptr, 0, "Sparse matrix-vector multplication kernels:", 2},
         {"spmv-format", key_spmv_format, "FMT", 0,
-         "choose one of: coo, coo-atomic, csr, ell (CPU, OpenMP) or hip-csr, hip-coo, hip-ell (MI355X)", 2},
+         "choose one of: coo, coo-atomic, csr, ell, hybrid (CPU, OpenMP) or hip-csr, hip-coo, hip-ell, hip-hybrid (MI355X)", 2},
         {"csr", key_csr, "PATH", 0, "same as --spmv-format csr --matrix PATH", 2},
         {"coo", key_coo, "PATH", 0, "same as --spmv-format coo --matrix PATH", 2},
         {"ell", key_ell, "PATH", 0, "same as --spmv-format ell --matrix PATH", 2},

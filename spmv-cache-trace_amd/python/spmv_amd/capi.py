@@ -36,6 +36,7 @@ SIGNATURES = {
     "spmv_hip_upload_csr": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
     "spmv_hip_upload_coo": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
     "spmv_hip_upload_ell": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _f64p]),
+    "spmv_hip_upload_hybrid": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _f64p, C.c_int32, _i32p, _i32p, _f64p]),
     "spmv_hip_set_x": (C.c_int, [_vp, _f64p]),
     "spmv_hip_set_y": (C.c_int, [_vp, _f64p]),
     "spmv_hip_get_y": (C.c_int, [_vp, _f64p]),
@@ -181,6 +182,18 @@ class Context:
         if len(col) == 0:
             col, val = _EMPTY_I32, _EMPTY_F64
         check(self.lib.spmv_hip_upload_ell(self.h, rows, cols, row_length, col, val))
+        self.rows, self.cols = rows, cols
+
+    def upload_hybrid(self, rows, cols, row_length, ell_col, ell_val, coo_row, coo_col, coo_val):
+        ell_col, ell_val = _i32(ell_col), _f64(ell_val)
+        coo_row, coo_col, coo_val = _i32(coo_row), _i32(coo_col), _f64(coo_val)
+        n = len(coo_val)
+        if len(ell_col) == 0:
+            ell_col, ell_val = _EMPTY_I32, _EMPTY_F64
+        if n == 0:
+            coo_row, coo_col, coo_val = _EMPTY_I32, _EMPTY_I32, _EMPTY_F64
+        check(self.lib.spmv_hip_upload_hybrid(self.h, rows, cols, row_length, ell_col, ell_val, n,
+                                              coo_row, coo_col, coo_val))
         self.rows, self.cols = rows, cols
 
     def set_x(self, x):

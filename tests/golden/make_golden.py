@@ -168,6 +168,14 @@ def ref_case(R, name, text, x, runs=1, threads=1, ell=True, row_alignment=1):
                        "size": inf["size"],
                        "y": hexf(R.ell_spmv(A, x, num_threads=threads, runs=runs))}
         R.ell_free(A)
+    A = R.hybrid_from_mm(h)
+    inf = R.hybrid_info(A)
+    ej, ea, cr, cc, cv = R.hybrid_arrays(A)
+    case["hybrid"] = {"row_length": inf["row_length"], "ell_column_index": ints(ej), "ell_value": hexf(ea),
+                      "coo_row_index": ints(cr), "coo_column_index": ints(cc), "coo_value": hexf(cv),
+                      "size": inf["size"],
+                      "y": hexf(R.hybrid_spmv(A, x, num_threads=threads, runs=runs))}
+    R.hybrid_free(A)
     R.mm_free(h)
     return case
 
@@ -191,7 +199,7 @@ def reference_vectors():
     for c in cases[1:]:
         c["mtx"] = "@poisson2D.mtx"
         c.pop("entries")
-        for fmt in ("csr", "coo", "ell"):
+        for fmt in ("csr", "coo", "ell", "hybrid"):
             for k in list(c[fmt].keys()):
                 if k not in ("y", "row_alignment", "row_length", "size") and not (
                         fmt == "csr" and c["name"] == "poisson2D_row_aligned4"):

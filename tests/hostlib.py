@@ -28,7 +28,7 @@ class Host:
         L = self.lib = C.CDLL(HOST_SO)
         L.host_last_error.restype = C.c_char_p
         for name in ("host_mm_from_buffer", "host_mm_load", "host_mm_load_tar_gz_member", "host_mm_expand_symmetry",
-                     "host_csr_from_mm", "host_coo_from_mm", "host_ell_from_mm"):
+                     "host_csr_from_mm", "host_coo_from_mm", "host_ell_from_mm", "host_hybrid_from_mm"):
             getattr(L, name).restype = vp
         L.host_mm_from_buffer.argtypes = [C.c_char_p, C.c_longlong]
         L.host_mm_load.argtypes = [C.c_char_p]
@@ -56,6 +56,11 @@ class Host:
         L.host_ell_info.argtypes = [vp, _i64p]
         L.host_ell_arrays.argtypes = [vp, _i32p, _f64p]
         L.host_ell_spmv.argtypes = [vp, _f64p, _f64p, C.c_int, C.c_int]
+        L.host_hybrid_from_mm.argtypes = [vp, C.c_int]
+        L.host_hybrid_free.argtypes = [vp]
+        L.host_hybrid_info.argtypes = [vp, _i64p]
+        L.host_hybrid_arrays.argtypes = [vp, _i32p, _f64p, _i32p, _i32p, _f64p]
+        L.host_hybrid_spmv.argtypes = [vp, _f64p, _f64p, C.c_int, C.c_int]
         L.host_print_sample.argtypes = [_i64p, C.c_longlong, C.c_char_p, C.c_longlong]
         L.host_print_sample.restype = C.c_longlong
         L.host_trace_config_echo.argtypes = [C.c_char_p, C.c_char_p, C.c_longlong, _i32p]
@@ -157,6 +162,22 @@ class Host:
     def ell_spmv(self, A, rows, x, y=None, threads=1, runs=1):
         y = np.zeros(rows) if y is None else np.array(y, dtype=np.float64)
         self._rc(self.lib.host_ell_spmv(A, np.ascontiguousarray(x, dtype=np.float64), y, threads, runs))
+        return y
+
+    def hybrid(self, h, skip_padding=False):
+        A = self._h(self.lib.host_hybrid_from_mm(h, int(skip_padding)))
+        info = np.zeros(7, dtype=np.int64)
+        self.lib.host_hybrid_info(A, info)
+        rows, cols, nnz, L, ne, nc, size = info.tolist()
+        ej, ea = np.zeros(max(1, ne), dtype=np.int32), np.zeros(max(1, ne))
+        cr, cc, cv = np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc), dtype=np.int32), np.zeros(max(1, nc))
+        self.lib.host_hybrid_arrays(A, ej, ea, cr, cc, cv)
+        return A, dict(rows=rows, columns=cols, num_entries=nnz, row_length=L, size=size), \
+            ej[:ne], ea[:ne], cr[:nc], cc[:nc], cv[:nc]
+
+    def hybrid_spmv(self, A, rows, x, y=None, threads=1, runs=1):
+        y = np.zeros(rows) if y is None else np.array(y, dtype=np.float64)
+        self._rc(self.lib.host_hybrid_spmv(A, np.ascontiguousarray(x, dtype=np.float64), y, threads, runs))
         return y
 
     # ---- statistics / JSON

@@ -100,6 +100,40 @@ def test_golden_ell_bitexact(ctx, oracle, golden):
         assert_bitexact(ctx.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell")
 
 
+def test_golden_hybrid(ctx, oracle, golden):
+    """Hybrid ELL+COO: the ELL part is summed in the reference's order; the COO remainder is added
+    with atomics, so y matches to 1e-10 (bit-exact whenever the remainder is empty)."""
+    for case in golden["cases"]:
+        if case["threads"] != 1:
+            continue  # multi-thread vectors carry the CPU workspace recurrence
+        rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+        H = oracle.hybrid_from_coordinate(rows, i, j, a)
+        x = unhex(case["x"])
+        ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+        ctx.set_x(x)
+        ctx.run(case["runs"])
+        got, want = ctx.get_y(), unhex(case["hybrid"]["y"])
+        p, c, v = oracle.csr_from_coordinate(rows, i, j, a)
+        assert_close(got, want, abs_products(rows, p, c, v, x) * case["runs"], what=case["name"] + "/hybrid")
+        if len(H["coo_val"]) == 0:
+            assert_bitexact(got, want, case["name"] + "/hybrid")
+        assert ctx.info()["format"] == 4
+
+
+def test_synthetic_hybrid_powerlaw(ctx, oracle):
+    """The webbase-like case plain ELLPACK cannot hold (rows * longest row overflows int32)."""
+    rows, cols, p, c, v = synth.powerlaw(300000, 300000, seed=4)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    H = oracle.hybrid_from_coordinate(rows, i, j, a)
+    assert H["row_length"] <= 4 and len(H["coo_val"]) > 0
+    x = synth.x_vector(cols)
+    want = oracle.hybrid_spmv(rows, H, x, runs=2)
+    ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+    ctx.set_x(x)
+    ctx.run(2)
+    assert_close(ctx.get_y(), want, 2 * abs_products(rows, p, c, v, x), what="powerlaw/hybrid")
+
+
 def test_reference_kats(ctx, oracle, golden):
     k = golden["kat"]["csr_spmv"]
     rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(k["mtx"])
@@ -413,7 +447,7 @@ def test_cli_hip_kernels(tmp_path, golden):
     bus = os.path.join(helpers.GOLDEN, "bus1138_like.mtx")
     poisson = os.path.join(helpers.GOLDEN, "poisson2D.mtx")
     tc = os.path.join(helpers.GOLDEN, "trace_config_2threads.json")
-    for fmt in ("hip-csr", "hip-coo", "hip-ell"):
+    for fmt in ("hip-csr", "hip-coo", "hip-ell", "hip-hybrid"):
         for path in (bus, poisson):
             rc, out, err = hostlib.run_cli("-c", tc, "--spmv-format", fmt, "-m", path, "--profile=5", "--check")
             assert rc == 0, (fmt, err)

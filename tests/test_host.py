@@ -211,6 +211,22 @@ def test_reference_vectors_bitexact(host, golden):
         host.mm_free(h)
 
 
+def test_reference_vectors_hybrid(host, golden):
+    for case in golden["cases"]:
+        h = host.mm_from_text(helpers.case_mtx(golden, case))
+        g = case["hybrid"]
+        A, info, ej, ea, cr, cc, cv = host.hybrid(h)
+        assert info["row_length"] == g["row_length"] and info["size"] == g["size"], case["name"]
+        if "ell_column_index" in g:
+            assert ej.tolist() == g["ell_column_index"] and cr.tolist() == g["coo_row_index"]
+            assert cc.tolist() == g["coo_column_index"]
+            assert_bitexact(ea, unhex(g["ell_value"]), case["name"])
+            assert_bitexact(cv, unhex(g["coo_value"]), case["name"])
+        y = host.hybrid_spmv(A, case["rows"], unhex(case["x"]), threads=case["threads"], runs=case["runs"])
+        assert_bitexact(y, unhex(g["y"]), case["name"] + " hybrid y")
+        host.mm_free(h)
+
+
 def test_poisson2d_reference_tolerance(host, golden):
     h = host.mm_from_text(golden["poisson2D_mtx"])
     z = golden["poisson2D_result"]
@@ -362,11 +378,12 @@ def test_cli_config0_plumbing():
     assert '"trace_config": ' + want.replace("\n", "\n  ") + "," in out  # same text, two spaces deeper
 
 
-@pytest.mark.parametrize("fmt,name", [("csr", "csr-spmv"), ("coo", "coo-spmv"), ("coo-atomic", "coo-spmv-atomic"), ("ell", "ell-spmv")])
+@pytest.mark.parametrize("fmt,name", [("csr", "csr-spmv"), ("coo", "coo-spmv"), ("coo-atomic", "coo-spmv-atomic"),
+                                      ("ell", "ell-spmv"), ("hybrid", "hybrid-spmv")])
 def test_cli_cpu_formats_and_readme_spellings(fmt, name):
     # 2-thread COO carries the reference's stale-workspace recurrence: after warm-up + 3
     # runs y is not 4*A*x, so the parity check is made with one thread for that kernel
-    tc = TC1 if fmt == "coo" else TC2
+    tc = TC1 if fmt in ("coo", "hybrid") else TC2
     rc, out, err = hostlib.run_cli("-c", tc, "--spmv-format", fmt, "--matrix", BUS, "-p", 3, "--check")
     assert rc == 0, err
     doc = json.loads(out)
@@ -404,7 +421,7 @@ def test_cli_errors():
     assert rc == 1 and err.strip() == "/nonexistent.json: No such file or directory"
     rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS)
     assert rc == 1 and "Cache tracing" in err
-    rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", "hybrid", "-m", BUS, "-p", 1)
+    rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", "mkl-csr", "-m", BUS, "-p", 1)
     assert rc != 0 and "not part of this build" in err
     rc, out, err = hostlib.run_cli("--list-perf-events")
     assert rc == 1 and "libpfm" in err
@@ -414,7 +431,7 @@ def test_cli_gpu_kernels_fail_without_a_gpu():
     from spmv_amd import capi
     if capi.device_count() > 0:
         pytest.skip("a GPU is present")
-    for fmt in ("hip-csr", "hip-coo", "hip-ell"):
+    for fmt in ("hip-csr", "hip-coo", "hip-ell", "hip-hybrid"):
         rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", fmt, "-m", BUS, "-p", 1)
         assert rc == 1 and out == "" and "no HIP device" in err, (fmt, err)
     rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS, "--device", "hip", "-p", 1)
@@ -426,3 +443,13 @@ def test_cli_triad_cpu():
     assert rc == 0, err
     doc = json.loads(out)
     assert doc["kernel"]["name"] == "triad" and doc["kernel"]["num_entries"] == "100000"
+
+
+def test_cli_hybrid_object():
+    rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", "hybrid", "-m", os.path.join(GOLDEN, "poisson2D.mtx"), "-p", 2)
+    assert rc == 0, err
+    k = json.loads(out)["kernel"]  # valid JSON, unlike the reference's (stray comma, hybrid-spmv.cpp:124)
+    assert list(k.keys()) == ["name", "matrix_path", "matrix_format", "rows", "columns", "nonzeros", "matrix_size",
+                              "x_size", "y_size", "ell_row_length", "num_ell_entries", "num_coo_entries"]
+    assert k["matrix_format"] == "hybrid" and k["ell_row_length"] == 7 and k["num_ell_entries"] == 367 * 7
+    assert k["num_coo_entries"] == 83 and k["matrix_size"] == 31824
