@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores visible to this process")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for each all-gather before the next multiply (default: gather k overlaps multiply k+1)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the all-gather even with one rank (rehearsal)")
     return ap.parse_args()
 
 
@@ -174,8 +178,10 @@ def main():
         sys.exit("bench.py: no GPU visible; this benchmark has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- workload: this rank's rows, global x ------------------------------------------
@@ -199,7 +205,8 @@ def main():
     algo = {"auto": capi.CSR_AUTO, "scalar": capi.CSR_SCALAR, "vector": capi.CSR_VECTOR,
             "adaptive": capi.CSR_ADAPTIVE, "wavetile": capi.CSR_WAVETILE}[args.algorithm]
     flags = (capi.FLAG_XCD_REMAP if args.xcd_remap else 0) | args.flags
-    op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags)
+    op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
+                                   overlap=not args.no_overlap)
     local_rows, local_nnz = end - begin, int(p[-1])
     local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
     torch.cuda.synchronize()
@@ -230,7 +237,7 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -238,17 +245,21 @@ def main():
         ev0[k].record()
         op.multiply_local()
         ev1[k].record()
-        if world > 1:
-            op.gather()
+        if use_dist:
+            if op.overlap:
+                op.gather_async()
+            else:
+                op.gather()
+    op.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
 
     stats = torch.tensor([elapsed, float(kernel_ms.mean())], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = stats.tolist()
 
@@ -267,8 +278,9 @@ def main():
                        "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
                        "algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
                        "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
-                       "partition": "rows/%d static chunks, x replicated, 1 all-gather(y)/step" % world
-                       if world > 1 else "single GPU"},
+                       "partition": ("rows/%d static chunks, x replicated, 1 all-gather(y)/step%s" % (
+                           world, ", gather k overlaps multiply k+1" if op.overlap else ""))
+                       if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "csr_%s" % capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
@@ -289,7 +301,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -60,7 +60,8 @@ extern "C" {
 #define SPMV_HIP_FLAG_XCD_REMAP 0x1u   /* give each XCD one contiguous run of tiles instead of the round-robin
                                            deal (measured SLOWER on MI355X for streaming SpMV: off by default) */
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
-#define SPMV_HIP_FLAG_NT_LOADS 0x4u     /* wavetile: non-temporal loads for the once-read column/value streams */
+#define SPMV_HIP_FLAG_NT_STORE 0x4u     /* wavetile: non-temporal store of y (non-temporal LOADS of the column/value
+                                           streams measured slower, 298 vs 267 us, and were removed) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;

@@ -385,7 +385,7 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
-            const bool nt = (pl->flags & SPMV_HIP_FLAG_NT_LOADS) != 0;
+            const bool nt = (pl->flags & SPMV_HIP_FLAG_NT_STORE) != 0;
 #define SPMV_WT_LAUNCH(T, N, X)                                                                      \
     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, N, X>), dim3(pl->workgroups), dim3(256), 0, s,  \
                        pl->ntiles, pl->d_tiles, p, j, a, x, y, pl->nnz, xcd, exact)
@@ -479,8 +479,46 @@ int spmv_hip_triad(int64_t n, double * a, const double * b, const double * c, do
     if (!aligned16(a) || !aligned16(b) || !aligned16(c))
         return fail(SPMV_HIP_ERR_ALIGN, "triad arrays must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for((n / 2 + 3) / 4, kBlock, kCUs * 8);
-    hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(grid), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+    // one 16-byte element per lane over a flat grid, non-temporal stores: measured 6.15 TB/s against
+    // 4.9 TB/s for a grid-stride loop with 4 loads in flight (profiles/r01_triad_variants.log)
+    const long long n2 = n / 2;
+    if (n2 > 0) {
+        const long long grid = (n2 + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL((spmv::triad_flat_kernel<kBlock, true>), dim3((unsigned) grid), dim3(kBlock), 0, s, n2, a, b, c, q);
+    }
+    if (n & 1)
+        hipLaunchKernelGGL((spmv::triad_kernel<64, 1>), dim3(1), dim3(64), 0, s, 1LL, a + (n - 1), b + (n - 1), c + (n - 1), q);
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+/* Not in the header: A/B variants of the triad for tools/kernel_sweep.py.
+ * 0 = grid-stride unroll 4 on 8 workgroups per CU, 1 = one element per lane (flat grid),
+ * 2 = flat + non-temporal stores (the shipped kernel),
+ * 3 = grid-stride unroll 4 on 16 workgroups per CU, 4 = unroll 8. */
+int spmv_hip_triad_variant(int64_t n, double * a, const double * b, const double * c, double q,
+                           void * stream, int variant)
+{
+    if (n & 1)
+        return spmv_hip_triad(n, a, b, c, q, stream);
+    if (variant == 0) {
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(kCUs * 8), dim3(kBlock), 0, static_cast<hipStream_t>(stream), (long long) n, a, b, c, q);
+        HIP_TRY(hipGetLastError());
+        return SPMV_HIP_OK;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n2 = n / 2;
+    if (variant == 1 || variant == 2) {
+        const long long grid = (n2 + kBlock - 1) / kBlock;
+        if (variant == 1)
+            hipLaunchKernelGGL((spmv::triad_flat_kernel<kBlock, false>), dim3((unsigned) grid), dim3(kBlock), 0, s, n2, a, b, c, q);
+        else
+            hipLaunchKernelGGL((spmv::triad_flat_kernel<kBlock, true>), dim3((unsigned) grid), dim3(kBlock), 0, s, n2, a, b, c, q);
+    } else if (variant == 3) {
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(kCUs * 16), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+    } else {
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 8>), dim3(kCUs * 8), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+    }
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
 }

@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         for (int q = 0; q < QUADS; ++q) {
             int o = 256 * q + 4 * lane;
             o = o < last ? o : last;
-            c[q] = stream_load<v4i, NT>(reinterpret_cast<const v4i *>(jt + o));
-            va[q] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(at + o));
-            vb[q] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(at + o + 2));
+            c[q] = stream_load<v4i, false>(reinterpret_cast<const v4i *>(jt + o));
+            va[q] = stream_load<v2d, false>(reinterpret_cast<const v2d *>(at + o));
+            vb[q] = stream_load<v2d, false>(reinterpret_cast<const v2d *>(at + o + 2));
         }
         // (3) gather x and park the rounded products; entries of neighbouring tiles that
         // share the first/last quad are multiplied as well and never read back
@@ -381,8 +381,12 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
         default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
         }
-        if (sub < nrows && part == 0)
-            yt[sub] = yv + z;
+        if (sub < nrows && part == 0) {
+            if (NT)
+                __builtin_nontemporal_store(yv + z, yt + sub);
+            else
+                yt[sub] = yv + z;
+        }
     } else if (!partial && k1 - kb <= TILE) {
         // ---- stream tile at the ragged end of the arrays, or a tile of empty rows: scalar
         // loads, one lane per row
@@ -570,6 +574,24 @@ __global__ __launch_bounds__(BLOCK) void triad_kernel(
     }
     if ((n & 1) && gid == 0)
         a[n - 1] = b[n - 1] + q * c[n - 1];
+}
+
+// Experiment variants of the triad (tools/kernel_sweep.py --triad-variants): not part of the ABI.
+template <int BLOCK, bool NT_STORE>
+__global__ __launch_bounds__(BLOCK) void triad_flat_kernel(
+    long long n2, double * __restrict__ a, const double * __restrict__ b,
+    const double * __restrict__ c, double q)
+{
+    const long long i = (long long) blockIdx.x * BLOCK + threadIdx.x; // one 16-byte element per lane
+    if (i < n2) {
+        const v2d vb = reinterpret_cast<const v2d *>(b)[i];
+        const v2d vc = reinterpret_cast<const v2d *>(c)[i];
+        const v2d r = v2d{vb.x + q * vc.x, vb.y + q * vc.y};
+        if (NT_STORE)
+            __builtin_nontemporal_store(r, reinterpret_cast<v2d *>(a) + i);
+        else
+            reinterpret_cast<v2d *>(a)[i] = r;
+    }
 }
 
 } // namespace spmv

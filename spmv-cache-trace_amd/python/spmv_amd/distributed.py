@@ -9,6 +9,11 @@ Segments are padded to the common chunk length so the collective is a plain
 equal-count all-gather; because chunks are contiguous and only the last one is
 short, the first `rows` entries of the gathered buffer are y itself.
 
+With ``overlap=True`` the gather of multiply k runs on the collective's stream while
+multiply k+1 runs on the compute stream: the segment is snapshotted into a send buffer
+(the kernels accumulate into y_local, so it cannot be sent from in place), and the next
+snapshot waits for the previous gather.  Every multiply is still gathered exactly once.
+
 The local multiply is injected (``local_spmv``) so the partition / gather logic can
 be exercised with gloo on CPU tensors; the product constructor
 ``DistributedCsrSpmv.on_gpu`` wires in the HIP path and has no other option.
@@ -21,7 +26,7 @@ from . import capi, partition
 
 
 class DistributedCsrSpmv:
-    def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None):
+    def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None, overlap=False):
         self.rows, self.cols = rows, cols
         self.rank, self.world = rank, world
         self.chunk = partition.row_chunk(rows, world)
@@ -33,10 +38,13 @@ class DistributedCsrSpmv:
         # padded local segment and the gathered vector (world * chunk >= rows)
         self.y_local = torch.zeros(self.chunk, dtype=torch.float64, device=device)
         self.y_full = torch.zeros(self.chunk * world, dtype=torch.float64, device=device)
+        self.overlap = overlap
+        self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device) if overlap else None
+        self.pending = None
 
     @classmethod
     def on_gpu(cls, rows, cols, rank, world, device, p_local, c_local, v_local, x_host,
-               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None):
+               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False):
         """Product path: local slice uploaded to `device`, multiplied by the HIP kernel
         on torch's current stream.  Raises if the HIP library or the GPU is missing."""
         local_rows = len(p_local) - 1
@@ -50,7 +58,7 @@ class DistributedCsrSpmv:
             plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_local.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
 
-        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group)
+        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group, overlap)
         self.plan = plan
         self._keep = (tp, tc, tv, tx)
         return self
@@ -61,15 +69,33 @@ class DistributedCsrSpmv:
 
     def gather(self):
         """The one collective of the path: equal-count all-gather of the y segments."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             self.y_full.copy_(self.y_local)
         else:
             dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
 
+    def gather_async(self):
+        """Snapshot y_local and start its all-gather without waiting for it; the previous one
+        must have finished with the send buffer first."""
+        if self.pending is not None:
+            self.pending.wait()
+        self.send_buf.copy_(self.y_local)
+        self.pending = dist.all_gather_into_tensor(self.y_full, self.send_buf, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for the last outstanding gather (no-op without overlap)."""
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
     def step(self):
         self.multiply_local()
-        self.gather()
+        if self.overlap and (self.world > 1 or dist.is_initialized()):
+            self.gather_async()
+        else:
+            self.gather()
 
     def y(self):
         """The assembled y (first `rows` entries of the gathered buffer)."""
+        self.finish()
         return self.y_full[:self.rows]

@@ -46,7 +46,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, overlap=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -70,11 +70,11 @@ def _worker(rank, world, port, steps, out_dir):
         y = y_local.numpy()
         y[:e - b] = O.csr_spmv(e - b, pl, cl, vl, x, y=y[:e - b])
 
-    op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv)
+    op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, overlap=overlap)
     for _ in range(steps):
         op.step()
     want = O.csr_spmv(rows, p, c, v, x, runs=steps)
-    got = op.y().numpy()
+    got = op.y().numpy()  # y() waits for the outstanding gather
     ok = np.array_equal(got, want) and op.y_full.numel() == partition.row_chunk(rows, world) * world
     # every rank must hold the whole y after the gather
     open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")
@@ -82,10 +82,10 @@ def _worker(rank, world, port, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_spmv_with_allgather_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
+def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 3, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 3, str(tmp_path), overlap), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"

@@ -215,8 +215,8 @@ def test_adaptive_short_rows_bitexact(ctx, oracle, name, gen):
         c2.close()
 
 
-@pytest.mark.parametrize("flags", [capi.FLAG_NT_LOADS, capi.FLAG_BIG_TILE,
-                                   capi.FLAG_NT_LOADS | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
+@pytest.mark.parametrize("flags", [capi.FLAG_NT_STORE, capi.FLAG_BIG_TILE,
+                                   capi.FLAG_NT_STORE | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
 def test_wavetile_variants(oracle, flags):
     """The tuning switches of the wave-tile kernel change speed only, never y."""
     c2 = capi.Context(0, flags=flags)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="")
+    ap.add_argument("--triad-variants", action="store_true")
     ap.add_argument("--formats", default="csr", help="comma list of csr,coo,coo_shuffled,ell")
     args = ap.parse_args()
     import torch
@@ -55,10 +56,10 @@ def main():
         "adaptive_exact": (capi.CSR_ADAPTIVE, 0, capi.FLAG_EXACT_ORDER),
         "wavetile": (capi.CSR_WAVETILE, 0, 0),
         "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
-        "wavetile_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_LOADS),
+        "wavetile_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE),
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
-        "wavetile_big_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | capi.FLAG_NT_LOADS),
-        "wavetile_nt_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_LOADS | capi.FLAG_XCD_REMAP),
+        "wavetile_big_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | capi.FLAG_NT_STORE),
+        "wavetile_nt_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE | capi.FLAG_XCD_REMAP),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
@@ -89,6 +90,35 @@ def main():
         torch.cuda.synchronize()
         if rnd > 0:
             tt.append(e0.elapsed_time(e1) / args.reps * 1e3)
+    if args.triad_variants:
+        import ctypes as C
+        fn = capi.load().spmv_hip_triad_variant
+        fn.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        for var in range(5):
+            tv = []
+            for rnd in range(args.rounds + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    fn(nt, ta.data_ptr(), tb.data_ptr(), tcv.data_ptr(), 3.1, stream, var)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    tv.append(e0.elapsed_time(e1) / args.reps * 1e3)
+            print("triad variant %d: median %.2f us = %.1f GB/s" % (var, float(np.median(tv)), 24.0 * nt / float(np.median(tv)) / 1e3))
+        # read-only and copy rates with torch's own kernels, for orientation
+        for name, fn2, nbytes_ in (("torch copy", lambda: ta.copy_(tb), 16.0 * nt), ("torch sum", lambda: tb.sum(), 8.0 * nt)):
+            tv = []
+            for rnd in range(args.rounds + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    fn2()
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    tv.append(e0.elapsed_time(e1) / args.reps * 1e3)
+            print("%s: median %.2f us = %.1f GB/s" % (name, float(np.median(tv)), nbytes_ / float(np.median(tv)) / 1e3))
     triad_gbs = 24.0 * nt / float(np.median(tt)) / 1e3
     print("triad (3 x 512 MiB): median %.2f us = %.1f GB/s (%.1f%% of 8 TB/s)" % (
         float(np.median(tt)), triad_gbs, triad_gbs / 80))
