@@ -102,6 +102,7 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     the figure is only reported when the summary was taken on the same kernel and workload."""
     import glob
     best = None
+    seq = -1
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
@@ -109,7 +110,8 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
             if rl.get("algorithmic_bytes_per_launch") != algorithmic_bytes:
                 continue
             for k in d["kernels"]:
-                if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k:
+                if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k and d.get("sequence", 0) > seq:
+                    seq = d.get("sequence", 0)
                     best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f))
         except (OSError, ValueError, KeyError):
             continue
@@ -278,6 +280,7 @@ def main():
                        "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
                        "algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
                        "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
+                       "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
                        "partition": ("rows/%d static chunks, x replicated, 1 all-gather(y)/step%s" % (
                            world, ", gather k overlaps multiply k+1" if op.overlap else ""))
                        if use_dist else "single GPU"},

@@ -62,6 +62,7 @@ extern "C" {
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
 #define SPMV_HIP_FLAG_NT_STORE 0x4u     /* wavetile: non-temporal store of y (non-temporal LOADS of the column/value
                                            streams measured slower, 298 vs 267 us, and were removed) */
+#define SPMV_HIP_FLAG_NO_INDEX_COMPRESSION 0x10u /* ctx: keep 32-bit column indices for every tile */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -135,7 +136,7 @@ int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
 /* Descriptive numbers for JSON output / tests.  out[] receives up to n of:
  * [0] format (0 none, 1 csr, 2 coo, 3 ell, 4 hybrid)  [1] rows  [2] cols  [3] stored entries
  * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
- * [7] row blocks (adaptive)  [8] long-row blocks (adaptive)  [9] device bytes held */
+ * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================
@@ -150,9 +151,17 @@ int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
                       const int32_t *host_row_ptr, int algorithm, int lanes_per_row,
                       unsigned flags);
+/* Optional second planning step for the wave-tile algorithm (done automatically by
+ * spmv_hip_upload_csr): wherever all columns of a tile lie within 65536 of its smallest column,
+ * keep them as 16-bit offsets in a plan-owned index stream (2 extra bytes per entry of device
+ * memory), so that those tiles read 10 instead of 12 bytes per entry.  Results are unchanged bit
+ * for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
+ * pointer silently falls back to the 32-bit indices).  Synchronises `stream`. */
+int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);
 /* out[]: [0] algorithm  [1] lanes per row  [2] workgroups  [3] row blocks
- *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device */
+ *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device
+ *        [8] tiles with 16-bit column offsets (after spmv_hip_plan_csr_compress) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

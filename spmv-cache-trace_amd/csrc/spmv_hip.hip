@@ -78,6 +78,9 @@ struct spmv_hip_plan {
     int4 * d_tiles = nullptr; // wavetile descriptors {first row | partial flag, first entry, longest row, log2 lanes/row}
     int ntiles = 0;
     int tile = 0;
+    uint16_t * d_col16 = nullptr;       // 16-bit column offsets of the narrow tiles (index compression)
+    const int32_t * compressed_from = nullptr; // the column array d_col16 was derived from
+    int narrow_tiles = 0;
     size_t meta_bytes = 0;
 };
 
@@ -259,7 +262,7 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                     for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
                         desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
                 } else {
-                    desc.push_back(make_int4(r, p[r], (int) std::min<long long>(len, INT32_MAX), 0));
+                    desc.push_back(make_int4(r, p[r], 0, 0));
                 }
                 r1 = r + 1;
             } else {
@@ -272,7 +275,7 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 if (!exact)
                     while ((2 << lanes_log2) <= cap && (8 << lanes_log2) <= avg)
                         ++lanes_log2;
-                desc.push_back(make_int4(r, p[r], maxlen, lanes_log2));
+                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16), 0));
             }
             r = r1;
         }
@@ -340,16 +343,54 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_blk_row);
     if (pl->d_tiles)
         (void) hipFree(pl->d_tiles);
+    if (pl->d_col16)
+        (void) hipFree(pl->d_col16);
     delete pl;
+}
+
+int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0 || pl->nnz == 0)
+        return SPMV_HIP_OK; // nothing to compress for the other algorithms
+    if (!d_column_index)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (pl->d_col16)
+        return fail(SPMV_HIP_ERR_STATE, "plan is already compressed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
+    int * d_count = nullptr;
+    HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
+    hipError_t e = hipMalloc((void **) &d_count, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
+                           pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&pl->narrow_tiles, d_count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_count)
+        (void) hipFree(d_count);
+    if (e != hipSuccess) {
+        (void) hipFree(pl->d_col16);
+        pl->d_col16 = nullptr;
+        return fail_hip(e, "index compression");
+    }
+    pl->meta_bytes += bytes;
+    pl->compressed_from = d_column_index;
+    return SPMV_HIP_OK;
 }
 
 int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[8] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
-                          pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes};
-    for (int i = 0; i < n && i < 8; ++i)
+    const int64_t v[9] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+                          pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles};
+    for (int i = 0; i < n && i < 9; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -385,18 +426,20 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
-            const bool nt = (pl->flags & SPMV_HIP_FLAG_NT_STORE) != 0;
-#define SPMV_WT_LAUNCH(T, N, X)                                                                      \
-    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, N, X>), dim3(pl->workgroups), dim3(256), 0, s,  \
-                       pl->ntiles, pl->d_tiles, p, j, a, x, y, pl->nnz, xcd, exact)
+            const int nt = (pl->flags & SPMV_HIP_FLAG_NT_STORE) ? 1 : 0;
+            // the 16-bit index stream is only valid for the column array it was derived from
+            const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
+#define SPMV_WT_LAUNCH(T, C, X)                                                                      \
+    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X>), dim3(pl->workgroups), dim3(256), 0, s,  \
+                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, xcd, exact, nt)
             // x below 4 GiB: 32-bit gather offsets from a scalar base
             const bool x32 = pl->cols < (1 << 29);
             if (pl->tile == 1024) {
-                if (nt) { if (x32) SPMV_WT_LAUNCH(1024, true, true); else SPMV_WT_LAUNCH(1024, true, false); }
-                else    { if (x32) SPMV_WT_LAUNCH(1024, false, true); else SPMV_WT_LAUNCH(1024, false, false); }
+                if (c16) { if (x32) SPMV_WT_LAUNCH(1024, true, true); else SPMV_WT_LAUNCH(1024, true, false); }
+                else     { if (x32) SPMV_WT_LAUNCH(1024, false, true); else SPMV_WT_LAUNCH(1024, false, false); }
             } else {
-                if (nt) { if (x32) SPMV_WT_LAUNCH(512, true, true); else SPMV_WT_LAUNCH(512, true, false); }
-                else    { if (x32) SPMV_WT_LAUNCH(512, false, true); else SPMV_WT_LAUNCH(512, false, false); }
+                if (c16) { if (x32) SPMV_WT_LAUNCH(512, true, true); else SPMV_WT_LAUNCH(512, true, false); }
+                else     { if (x32) SPMV_WT_LAUNCH(512, false, true); else SPMV_WT_LAUNCH(512, false, false); }
             }
 #undef SPMV_WT_LAUNCH
         }
@@ -612,6 +655,9 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
+        if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
+    }
     c->format = 1;
     return SPMV_HIP_OK;
 }
@@ -824,7 +870,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
 {
     if (!c || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
-    int64_t v[10] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes};
+    int64_t v[11] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0};
     if (c->plan) {
         v[4] = c->plan->algorithm;
         v[5] = c->plan->lanes_per_row;
@@ -832,8 +878,9 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         v[7] = c->plan->nblk;
         v[8] = c->plan->long_blocks;
         v[9] += (int64_t) c->plan->meta_bytes;
+        v[10] = c->plan->narrow_tiles;
     }
-    for (int i = 0; i < n && i < 10; ++i)
+    for (int i = 0; i < n && i < 11; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

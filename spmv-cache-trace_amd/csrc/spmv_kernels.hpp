@@ -230,8 +230,9 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 //
 // The host cuts the rows into tiles owned by ONE wave: up to 64 consecutive rows
 // holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
-// described by an int4 {first row | flags, first entry, longest row, lanes per row};
-// tile w ends where tile w+1 starts.  A wave reads its descriptor pair with scalar
+// described by an int4 {first row | flags, first entry, meta, column base} with
+// meta = longest row | log2(lanes per row) << 16 | narrow << 24; tile w ends where tile
+// w+1 starts.  A wave reads its descriptor pair with scalar
 // loads and then has everything it needs to issue ALL its independent loads back to
 // back -- the row_ptr pair and old y of the lane's row, then the column/value quads
 // (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs three
@@ -248,11 +249,20 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // divisions done once on the host (descriptor .z/.w), and a row loop whose trip count
 // is wave-uniform (the tile's longest row).
 //
+// Compressed column indices: when all columns of a tile lie within 65536 of the tile's
+// smallest column (any banded matrix), the plan keeps them as 16-bit offsets from that
+// base in a second index stream, and the tile reads 2 instead of 4 bytes per entry
+// (10 instead of 12 with the value) and gathers x through a scalar base + 32-bit offset.
+// Entries of neighbouring tiles that share a boundary quad decode against the wrong base;
+// their offset is clamped into x so that the (never used) gather stays in bounds.
+//
 // A row longer than TILE is a tile by itself (the wave strides it); rows longer than
 // kSplitThreshold (2048 entries) are cut into chunks spread over several waves (bit 31 of the row
 // field), each adding its partial sum with one fp64 atomic.
 // ---------------------------------------------------------------------------------
 constexpr int kTileFlagPartial = (int) 0x80000000u;
+constexpr int kTileMetaLanesShift = 16;
+constexpr int kTileMetaNarrow = 1 << 24;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -290,12 +300,79 @@ __device__ __forceinline__ double tile_row_sum(const double * prod, int s, int e
     return group_sum<L>(z);
 }
 
-template <int TILE, bool NT, bool X32>
+// Products of one quad-set with 32-bit column indices.
+template <int QUADS, bool X32>
+__device__ __forceinline__ void tile_products_wide(
+    double * prod, const int32_t * __restrict__ jt, const double * __restrict__ at,
+    const double * __restrict__ x, int last, int lane)
+{
+    v4i c[QUADS];
+    v2d va[QUADS], vb[QUADS];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last; // lanes past the tile's end re-read its last quad
+        c[q] = *reinterpret_cast<const v4i *>(jt + o);
+        va[q] = *reinterpret_cast<const v2d *>(at + o);
+        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+    }
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
+            const double q0 = va[q].x * gather_x<X32>(x, c[q].x);
+            const double q1 = va[q].y * gather_x<X32>(x, c[q].y);
+            const double q2 = vb[q].x * gather_x<X32>(x, c[q].z);
+            const double q3 = vb[q].y * gather_x<X32>(x, c[q].w);
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+}
+
+// The same with 16-bit column offsets from the tile's base: xt = x + base (scalar), limit =
+// last valid offset from the base (cols - 1 - base).
+template <int QUADS>
+__device__ __forceinline__ void tile_products_narrow(
+    double * prod, const uint16_t * __restrict__ jt, const double * __restrict__ at,
+    const double * __restrict__ xt, unsigned limit, int last, int lane)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u c[QUADS];
+    v2d va[QUADS], vb[QUADS];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last;
+        c[q] = *reinterpret_cast<const v2u *>(jt + o); // four 16-bit offsets
+        va[q] = *reinterpret_cast<const v2d *>(at + o);
+        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+    }
+    const char * xb = reinterpret_cast<const char *>(xt);
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
+            const unsigned c0 = min(c[q].x & 0xFFFFu, limit), c1 = min(c[q].x >> 16, limit);
+            const unsigned c2 = min(c[q].y & 0xFFFFu, limit), c3 = min(c[q].y >> 16, limit);
+            const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c0 << 3));
+            const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
+            const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
+            const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c3 << 3));
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+}
+
+template <int TILE, bool C16, bool X32>
 __global__ __launch_bounds__(256) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
-    const int32_t * __restrict__ j, const double * __restrict__ a,
-    const double * __restrict__ x, double * __restrict__ y, int nnz_total, int xcd_aware,
-    int exact_order)
+    const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
+    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
+    int nnz_total, int cols, int xcd_aware, int exact_order, int nt_store)
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
@@ -313,8 +390,10 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
     const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
-    const int maxlen = __builtin_amdgcn_readfirstlane(d0.z);
-    const int lanes_log2 = __builtin_amdgcn_readfirstlane(d0.w);
+    const int meta = __builtin_amdgcn_readfirstlane(d0.z);
+    const int maxlen = meta & 0xFFFF;
+    const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0xFF;
+    const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
     const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
     const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
     const int nrows = r1 - r0;
@@ -334,35 +413,14 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         const int ps = pt[rowi];
         const int pe = pt[rowi + 1];
         const double yv = yt[rowi];
-        // (2) the tile's column/value quads; lanes past the tile's end re-read its last quad
-        const int32_t * jt = j + kb;
-        const double * at = a + kb;
+        // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
+        // of neighbouring tiles that share the first/last quad are multiplied as well and never
+        // read back
         const int last = (k1 - 1 - kb) & ~3;
-        v4i c[QUADS];
-        v2d va[QUADS], vb[QUADS];
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            int o = 256 * q + 4 * lane;
-            o = o < last ? o : last;
-            c[q] = stream_load<v4i, false>(reinterpret_cast<const v4i *>(jt + o));
-            va[q] = stream_load<v2d, false>(reinterpret_cast<const v2d *>(at + o));
-            vb[q] = stream_load<v2d, false>(reinterpret_cast<const v2d *>(at + o + 2));
-        }
-        // (3) gather x and park the rounded products; entries of neighbouring tiles that
-        // share the first/last quad are multiplied as well and never read back
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            const int o = 256 * q + 4 * lane;
-            if (o <= last) {
-                const double q0 = va[q].x * gather_x<X32>(x, c[q].x);
-                const double q1 = va[q].y * gather_x<X32>(x, c[q].y);
-                const double q2 = vb[q].x * gather_x<X32>(x, c[q].z);
-                const double q3 = vb[q].y * gather_x<X32>(x, c[q].w);
-                v2d * dst = reinterpret_cast<v2d *>(prod + o);
-                dst[0] = v2d{q0, q1};
-                dst[1] = v2d{q2, q3};
-            }
-        }
+        if (C16 && (meta & kTileMetaNarrow))
+            tile_products_narrow<QUADS>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
+        else
+            tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
         // same-wave LDS operations execute in order; the fences only pin the compiler
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -382,7 +440,7 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
         }
         if (sub < nrows && part == 0) {
-            if (NT)
+            if (nt_store)
                 __builtin_nontemporal_store(yv + z, yt + sub);
             else
                 yt[sub] = yv + z;
@@ -442,6 +500,45 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         }
         if (lane == 0)
             y[r0] += z;
+    }
+}
+
+// Plan-time pass (one wave per tile): find the tile's column range; if it fits 16 bits, store
+// the offsets from the smallest column in j16 and mark the tile narrow.  `narrow_count`
+// receives the number of narrow tiles.
+__global__ __launch_bounds__(256) void csr_tile_compress_kernel(
+    int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
+    uint16_t * __restrict__ j16, int * __restrict__ narrow_count)
+{
+    const int wave = (int) threadIdx.x >> 6;
+    const int lane = (int) __lane_id();
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= ntiles)
+        return;
+    const int4 d0 = desc[w];
+    const int k0 = d0.y, k1 = desc[w + 1].y;
+    if ((d0.x & kTileFlagPartial) || k1 <= k0 || k1 - (k0 & ~3) > tile)
+        return; // long rows and empty tiles keep 32-bit indices
+    int cmin = 0x7FFFFFFF, cmax = -1;
+    for (int k = k0 + lane; k < k1; k += kWave) {
+        const int c = j[k];
+        cmin = c < cmin ? c : cmin;
+        cmax = c > cmax ? c : cmax;
+    }
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int omin = __shfl_xor(cmin, d), omax = __shfl_xor(cmax, d);
+        cmin = omin < cmin ? omin : cmin;
+        cmax = omax > cmax ? omax : cmax;
+    }
+    if (cmin < 0 || cmax - cmin >= 65536)
+        return;
+    for (int k = k0 + lane; k < k1; k += kWave)
+        j16[k] = (uint16_t) (j[k] - cmin);
+    if (lane == 0) {
+        desc[w].z = d0.z | kTileMetaNarrow;
+        desc[w].w = cmin;
+        atomicAdd(narrow_count, 1);
     }
 }
 

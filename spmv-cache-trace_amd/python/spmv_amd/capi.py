@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
 CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
-FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_NT_STORE, FLAG_BIG_TILE = 0x1, 0x2, 0x4, 0x8
+FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_NT_STORE, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION = 0x1, 0x2, 0x4, 0x8, 0x10
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -45,6 +45,7 @@ SIGNATURES = {
     "spmv_hip_last_run_ns": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_plan_csr": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _i32p, C.c_int, C.c_int, C.c_uint]),
+    "spmv_hip_plan_csr_compress": (C.c_int, [_vp, _vp, _vp]),
     "spmv_hip_plan_destroy": (None, [_vp]),
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -223,10 +224,10 @@ class Context:
         return ns.value
 
     def info(self):
-        out = np.zeros(10, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 10))
+        out = np.zeros(11, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 11))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
-                "row_blocks", "long_blocks", "device_bytes"]
+                "row_blocks", "long_blocks", "device_bytes", "narrow_tiles"]
         return dict(zip(keys, out.tolist()))
 
 
@@ -252,11 +253,15 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(8, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 8))
+        out = np.zeros(9, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 9))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes"]
+                "nnz", "meta_bytes", "narrow_tiles"]
         return dict(zip(keys, out.tolist()))
+
+    def compress(self, d_col, stream=0):
+        """16-bit column offsets for the tiles that allow it (wave-tile algorithm only)."""
+        check(self.lib.spmv_hip_plan_csr_compress(self.h, d_col, stream))
 
     def spmv(self, d_row_ptr, d_col, d_val, d_x, d_y, stream=0):
         """All arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""

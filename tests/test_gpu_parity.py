@@ -215,6 +215,71 @@ def test_adaptive_short_rows_bitexact(ctx, oracle, name, gen):
         c2.close()
 
 
+def test_index_compression_narrow_and_wide_tiles(oracle):
+    """16-bit column offsets: chosen per tile; y is unchanged bit for bit; wide tiles (column range
+    >= 65536) and the boundary quads shared with them keep working."""
+    rng = np.random.default_rng(3)
+    cols = 400000
+    # rows 0..999 banded (narrow tiles), 1000..1999 random over all columns (wide), then banded again
+    # right at the far end of x (clamping of foreign boundary entries must stay inside x)
+    lens = rng.integers(1, 9, size=3000)
+    p = np.zeros(3001, dtype=np.int32)
+    p[1:] = np.cumsum(lens)
+    c = np.zeros(p[-1], dtype=np.int32)
+    for r in range(3000):
+        n = lens[r]
+        if r < 1000:
+            c[p[r]:p[r + 1]] = np.sort(rng.choice(np.arange(max(0, r - 50), r + 51), size=n, replace=False))
+        elif r < 2000:
+            c[p[r]:p[r + 1]] = np.sort(rng.choice(cols, size=n, replace=False))
+        else:
+            c[p[r]:p[r + 1]] = np.sort(rng.choice(np.arange(cols - 100, cols), size=n, replace=False))
+    v = rng.uniform(-1, 1, p[-1])
+    x = synth.x_vector(cols)
+    want = oracle.csr_spmv(3000, p, c, v, x)
+    for flags in (0, capi.FLAG_NO_INDEX_COMPRESSION, capi.FLAG_BIG_TILE):
+        c2 = capi.Context(0, flags=flags)
+        try:
+            got = gpu_csr(c2, 3000, cols, p, c, v, x, algo=capi.CSR_WAVETILE)
+            info = c2.info()
+        finally:
+            c2.close()
+        assert_bitexact(got, want, "compression flags %x" % flags)  # rows < 16 entries: reference order
+        if flags & capi.FLAG_NO_INDEX_COMPRESSION:
+            assert info["narrow_tiles"] == 0
+        else:
+            assert 0 < info["narrow_tiles"] < info["row_blocks"]
+
+
+def test_index_compression_level2(oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    rows, cols, p, c, v = synth.poisson2d(300)
+    x = synth.x_vector(cols)
+    want = oracle.csr_spmv(rows, p, c, v, x)
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE)
+    plan.compress(tc.data_ptr(), stream)
+    assert plan.info()["narrow_tiles"] == plan.info()["row_blocks"]  # banded: every tile qualifies
+    ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+    plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_bitexact(ty.cpu().numpy(), want, "compressed plan")
+    # another copy of the column array: the plan falls back to the 32-bit indices it is given
+    tc2 = tc.clone()
+    tc2[0:3] = torch.tensor([5, 6, 7], dtype=torch.int32, device=dev)  # rows 0's columns moved
+    c_mod = c.copy()
+    c_mod[0:3] = [5, 6, 7]
+    ty.zero_()
+    plan.spmv(tp.data_ptr(), tc2.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_bitexact(ty.cpu().numpy(), oracle.csr_spmv(rows, p, c_mod, v, x), "fallback to the given indices")
+    with pytest.raises(capi.SpmvHipError):
+        plan.compress(tc.data_ptr(), stream)  # already compressed
+    plan.close()
+
+
 @pytest.mark.parametrize("flags", [capi.FLAG_NT_STORE, capi.FLAG_BIG_TILE,
                                    capi.FLAG_NT_STORE | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
 def test_wavetile_variants(oracle, flags):

@@ -58,12 +58,17 @@ def main():
         "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
         "wavetile_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE),
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
+        "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100),  # 0x100: sweep-local marker = compress the plan
+        "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100),
         "wavetile_big_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | capi.FLAG_NT_STORE),
         "wavetile_nt_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE | capi.FLAG_XCD_REMAP),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
-    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f) for k, (a, l, f) in variants.items()}
+    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0xFF) for k, (a, l, f) in variants.items()}
+    for k, (a, l, f) in variants.items():
+        if f & 0x100:
+            plans[k].compress(tc.data_ptr(), stream)
     times = {k: [] for k in plans}
     for rnd in range(args.rounds + 1):
         for k, plan in plans.items():
