@@ -60,8 +60,6 @@ extern "C" {
 #define SPMV_HIP_FLAG_XCD_REMAP 0x1u   /* give each XCD one contiguous run of tiles instead of the round-robin
                                            deal (measured SLOWER on MI355X for streaming SpMV: off by default) */
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
-#define SPMV_HIP_FLAG_NT_STORE 0x4u     /* wavetile: non-temporal store of y (non-temporal LOADS of the column/value
-                                           streams measured slower, 298 vs 267 us, and were removed) */
 #define SPMV_HIP_FLAG_NO_INDEX_COMPRESSION 0x10u /* ctx: keep 32-bit column indices for every tile */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 

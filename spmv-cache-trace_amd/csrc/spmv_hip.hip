@@ -275,7 +275,9 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 if (!exact)
                     while ((2 << lanes_log2) <= cap && (8 << lanes_log2) <= avg)
                         ++lanes_log2;
-                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16), 0));
+                // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
+                const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0), 0));
             }
             r = r1;
         }
@@ -426,21 +428,22 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
-            const int nt = (pl->flags & SPMV_HIP_FLAG_NT_STORE) ? 1 : 0;
             // the 16-bit index stream is only valid for the column array it was derived from
             const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
-#define SPMV_WT_LAUNCH(T, C, X)                                                                      \
-    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X>), dim3(pl->workgroups), dim3(256), 0, s,  \
-                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, xcd, exact, nt)
             // x below 4 GiB: 32-bit gather offsets from a scalar base
             const bool x32 = pl->cols < (1 << 29);
+#define SPMV_WT_LAUNCH(T, C, X, R)                                                                    \
+    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X, R>), dim3(pl->workgroups), dim3(256), 0, s, \
+                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact)
+#define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
+#define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             if (pl->tile == 1024) {
-                if (c16) { if (x32) SPMV_WT_LAUNCH(1024, true, true); else SPMV_WT_LAUNCH(1024, true, false); }
-                else     { if (x32) SPMV_WT_LAUNCH(1024, false, true); else SPMV_WT_LAUNCH(1024, false, false); }
+                if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
             } else {
-                if (c16) { if (x32) SPMV_WT_LAUNCH(512, true, true); else SPMV_WT_LAUNCH(512, true, false); }
-                else     { if (x32) SPMV_WT_LAUNCH(512, false, true); else SPMV_WT_LAUNCH(512, false, false); }
+                if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
             }
+#undef SPMV_WT_C
+#undef SPMV_WT_X
 #undef SPMV_WT_LAUNCH
         }
         break;

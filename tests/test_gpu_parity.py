@@ -280,8 +280,8 @@ def test_index_compression_level2(oracle):
     plan.close()
 
 
-@pytest.mark.parametrize("flags", [capi.FLAG_NT_STORE, capi.FLAG_BIG_TILE,
-                                   capi.FLAG_NT_STORE | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
+@pytest.mark.parametrize("flags", [capi.FLAG_XCD_REMAP, capi.FLAG_BIG_TILE,
+                                   capi.FLAG_NO_INDEX_COMPRESSION | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
 def test_wavetile_variants(oracle, flags):
     """The tuning switches of the wave-tile kernel change speed only, never y."""
     c2 = capi.Context(0, flags=flags)

@@ -56,12 +56,9 @@ def main():
         "adaptive_exact": (capi.CSR_ADAPTIVE, 0, capi.FLAG_EXACT_ORDER),
         "wavetile": (capi.CSR_WAVETILE, 0, 0),
         "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
-        "wavetile_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE),
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
         "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100),  # 0x100: sweep-local marker = compress the plan
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100),
-        "wavetile_big_nt": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | capi.FLAG_NT_STORE),
-        "wavetile_nt_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_NT_STORE | capi.FLAG_XCD_REMAP),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
