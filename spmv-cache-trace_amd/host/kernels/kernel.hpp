@@ -43,6 +43,9 @@ public:
     // Additive hooks (not in the reference): device time of the last run, 0 if not measured,
     // and the result vector for parity checks (the reference never exposes y).
     virtual std::uint64_t last_device_ns() const { return 0; }
+    // flops and algorithmic bytes of one run() (SURVEY 8d formulas), 0 if not defined
+    virtual double flops_per_run() const { return 0.0; }
+    virtual double bytes_per_run() const { return 0.0; }
     virtual std::vector<double> result() const = 0;
     // Replace x (default: all ones, src/kernels/csr-spmv.cpp:35) before prepare().
     virtual void set_x(std::vector<double> const & x) = 0;

@@ -97,6 +97,8 @@ public:
     {
         return print_common(o, name(), matrix_path, "csr", A.rows, A.columns, A.num_entries, A.size()) << "\n}";
     }
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * A.row_ptr[(std::size_t) A.rows] + 4.0 * (A.rows + 1.0) + 16.0 * A.rows + 8.0 * A.columns; }
     std::vector<double> result() const override { return std::vector<double>(y.begin(), y.end()); }
     void set_x(std::vector<double> const & v) override
     {
@@ -151,6 +153,8 @@ public:
     {
         return print_common(o, name(), matrix_path, "coo", A.rows, A.columns, A.num_entries, A.size()) << "\n}";
     }
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 16.0 * A.num_entries + 16.0 * A.rows + 8.0 * A.columns; }
     std::vector<double> result() const override { return std::vector<double>(y.begin(), y.end()); }
     void set_x(std::vector<double> const & v) override
     {
@@ -188,6 +192,8 @@ public:
     {
         return print_common(o, name(), matrix_path, "ell", A.rows, A.columns, A.num_entries, A.size()) << "\n}";
     }
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * (double) A.rows * A.row_length + 16.0 * A.rows + 8.0 * A.columns; }
     std::vector<double> result() const override { return std::vector<double>(y.begin(), y.end()); }
     void set_x(std::vector<double> const & v) override
     {
@@ -232,6 +238,8 @@ public:
     MemoryReferenceString memory_reference_string(TraceConfig const &, int, int) const override { no_reference_string(); }
     std::string name() const override { return "hybrid-spmv"; }
     std::ostream & print(std::ostream & o) const override { return print_hybrid(o, name(), matrix_path, A) << "\n}"; }
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * (double) A.num_ell_entries + 16.0 * A.num_coo_entries + 16.0 * A.rows + 8.0 * A.columns; }
     std::vector<double> result() const override { return std::vector<double>(y.begin(), y.end()); }
     void set_x(std::vector<double> const & v) override
     {
@@ -383,6 +391,9 @@ public:
         return print_device(o) << "\n}";
     }
 
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * A.row_ptr[(std::size_t) A.rows] + 4.0 * (A.rows + 1.0) + 16.0 * A.rows + 8.0 * A.columns; }
+
 private:
     csr_matrix::Matrix A;
 };
@@ -408,6 +419,9 @@ public:
         print_common(o, name(), matrix_path, "coo", A.rows, A.columns, A.num_entries, A.size());
         return print_device(o) << "\n}";
     }
+
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 16.0 * A.num_entries + 16.0 * A.rows + 8.0 * A.columns; }
 
 private:
     coo_matrix::Matrix A;
@@ -435,6 +449,9 @@ public:
         return print_device(o) << "\n}";
     }
 
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * (double) A.rows * A.row_length + 16.0 * A.rows + 8.0 * A.columns; }
+
 private:
     ell_matrix::Matrix A;
 };
@@ -461,6 +478,9 @@ public:
         hybrid_spmv_kernel::print_hybrid(o, name(), matrix_path, A);
         return print_device(o) << "\n}";
     }
+
+    double flops_per_run() const override { return 2.0 * A.num_entries; }
+    double bytes_per_run() const override { return 12.0 * (double) A.num_ell_entries + 16.0 * A.num_coo_entries + 16.0 * A.rows + 8.0 * A.columns; }
 
 private:
     hybrid_matrix::Matrix A;

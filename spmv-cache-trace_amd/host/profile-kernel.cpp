@@ -176,5 +176,19 @@ std::ostream & operator<<(std::ostream & o, Profiling const & profiling)
         o << ",\n\"device_time\": ";
         print_sample(o, profiling.device_time(), "ns");
     }
-    return o << ",\n\"profiling_events\": []" << profiling.extra() << "\n}";
+    o << ",\n\"profiling_events\": []";
+    // additive: rates derived from the median wall time and, for GPU kernels, the median device time
+    double const flops = profiling.kernel().flops_per_run(), bytes = profiling.kernel().bytes_per_run();
+    if (flops > 0.0 && !profiling.execution_time().empty()) {
+        auto const wall = sample_stats(profiling.execution_time());
+        o << ",\n\"throughput\": {\"flops_per_run\": " << flops << ", \"algorithmic_bytes_per_run\": " << bytes
+          << ", \"gflops_median\": " << flops / wall.median << ", \"gbs_median\": " << bytes / wall.median;
+        if (!profiling.device_time().empty()) {
+            auto const dev = sample_stats(profiling.device_time());
+            o << ", \"device_gflops_median\": " << flops / dev.median << ", \"device_gbs_median\": " << bytes / dev.median
+              << ", \"device_fraction_of_8TBs\": " << bytes / dev.median / 8000.0;
+        }
+        o << "}";
+    }
+    return o << profiling.extra() << "\n}";
 }

@@ -544,3 +544,35 @@ def test_cli_hip_kernels(tmp_path, golden):
     rc, out, err = hostlib.run_cli("--threads", 1, "--triad", 1 << 22, "--device", "hip", "-p", 3)
     assert rc == 0, err
     assert json.loads(out)["kernel"]["name"] == "hip-triad"
+
+
+def test_x_larger_than_4GiB(oracle):
+    """cols >= 2^29: x no longer fits 32-bit byte offsets; the kernels switch to 64-bit gather
+    addresses (wide tiles) while narrow tiles keep a scalar base + 16-bit offsets."""
+    cols = (1 << 29) + 4096
+    rng = np.random.default_rng(17)
+    rows = 3000
+    lens = rng.integers(1, 12, size=rows)
+    p = np.zeros(rows + 1, dtype=np.int32)
+    p[1:] = np.cumsum(lens)
+    c = np.zeros(p[-1], dtype=np.int32)
+    for r in range(rows):
+        n = lens[r]
+        if r % 2:   # anywhere in x, also beyond the 4 GiB mark
+            c[p[r]:p[r + 1]] = np.sort(rng.choice(cols, size=n, replace=False))
+        else:       # a band at the far end
+            c[p[r]:p[r + 1]] = np.sort(cols - 1 - rng.choice(2000, size=n, replace=False))
+    v = rng.uniform(-1, 1, p[-1])
+    x = np.full(cols, 0.25)
+    x[c] = rng.uniform(-1, 1, len(c))
+    want = oracle.csr_spmv(rows, p, c, v, x)
+    ctx = capi.Context(0)
+    try:
+        for algo in (capi.CSR_WAVETILE, capi.CSR_ADAPTIVE, capi.CSR_VECTOR, capi.CSR_SCALAR):
+            got = gpu_csr(ctx, rows, cols, p, c, v, x, algo=algo)
+            if algo in (capi.CSR_WAVETILE, capi.CSR_SCALAR):
+                assert_bitexact(got, want, "big x, algo %d" % algo)
+            else:
+                assert_close(got, want, abs_products(rows, p, c, v, x), what="big x, algo %d" % algo)
+    finally:
+        ctx.close()

@@ -360,7 +360,10 @@ def test_cli_config0_plumbing():
     rc, out, err = hostlib.run_cli("--trace-config", TC1, "--spmv-format", "csr", "-m", BUS, "--profile=7")
     assert rc == 0, err
     doc = json.loads(out)
-    assert list(doc.keys()) == ["trace_config", "kernel", "execution_time", "profiling_events"]
+    # the reference's four members, in its order; "throughput" is additive
+    assert list(doc.keys()) == ["trace_config", "kernel", "execution_time", "profiling_events", "throughput"]
+    assert doc["throughput"]["flops_per_run"] == 2 * 2596
+    assert doc["throughput"]["algorithmic_bytes_per_run"] == 12 * 2596 + 4 * 1139 + 16 * 1138 + 8 * 1138
     k = doc["kernel"]
     # field for field the reference's csr kernel object (src/kernels/csr-spmv.cpp:97-112);
     # the symmetric file is NOT expanded: 2596 stored entries, matrix_size as in README.md:106
