@@ -62,36 +62,33 @@ Matrix from_matrix_market_row_aligned(matrix_market::Matrix const & m, index_typ
         throw matrix::matrix_error("Expected a positive row alignment");
 
     // entries in (row, column) order; duplicates are kept as separate entries
-    auto const order = matrix_market::row_major_order(m);
-    auto const & ci = m.column_indices();
-    auto const va = m.values_real();
+    matrix_market::RowMajorEntries const e = matrix_market::row_major_entries(m);
     index_type const rows = m.rows();
-    for (auto c : ci)
-        if (c < 1 || c > m.columns())
-            throw matrix::matrix_error("Column index out of bounds: " + std::to_string(c));
 
     // padded row lengths -> row_ptr
-    auto const len = m.row_lengths();
     size_array_type row_ptr((std::size_t) rows + 1, 0);
     long long k = 0;
     for (index_type r = 0; r < rows; ++r) {
-        k += len[(std::size_t) r];
+        k += (long long) (e.start[(std::size_t) r + 1] - e.start[(std::size_t) r]);
         k = ((k + (row_alignment - 1)) / row_alignment) * row_alignment;
         if (k > INT32_MAX)
             throw matrix::matrix_error("Failed to convert to CSR: Integer overflow when computing number of non-zeros");
         row_ptr[(std::size_t) r + 1] = (size_type) k;
     }
 
-    index_array_type column_index((std::size_t) k, 0);
-    value_array_type value((std::size_t) k, 0.0);
-    std::size_t l = 0; // position in the sorted entry order
-    for (index_type r = 0; r < rows; ++r) {
+    index_array_type column_index((std::size_t) k);
+    value_array_type value((std::size_t) k);
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < (long long) rows; ++r) {
         std::size_t dst = (std::size_t) row_ptr[(std::size_t) r];
-        for (index_type e = 0; e < len[(std::size_t) r]; ++e, ++l, ++dst) {
-            column_index[dst] = ci[(std::size_t) order[l]] - 1;
-            value[dst] = va[(std::size_t) order[l]];
+        for (std::size_t q = e.start[(std::size_t) r]; q < e.start[(std::size_t) r + 1]; ++q, ++dst) {
+            column_index[dst] = e.col[q];
+            value[dst] = e.val[q];
         }
-        // alignment padding: column 0, value 0.0 (already there from the fill constructor)
+        for (; dst < (std::size_t) row_ptr[(std::size_t) r + 1]; ++dst) { // alignment padding
+            column_index[dst] = 0;
+            value[dst] = 0.0;
+        }
     }
     return Matrix(rows, m.columns(), m.num_entries(), row_alignment, std::move(row_ptr),
                   std::move(column_index), std::move(value));

@@ -48,26 +48,27 @@ Matrix from_matrix_market(matrix_market::Matrix const & m, bool skip_padding)
         throw matrix::matrix_error(
             "Failed to convert to ELLPACK: Integer overflow when computing number of non-zeros");
 
-    auto const order = matrix_market::row_major_order(m);
-    auto const & ci = m.column_indices();
-    auto const va = m.values_real();
-    for (auto c : ci)
-        if (c < 1 || c > m.columns())
-            throw matrix::matrix_error("Column index out of bounds: " + std::to_string(c));
+    matrix_market::RowMajorEntries const e = matrix_market::row_major_entries(m);
 
     index_array_type column_index((std::size_t) padded, 0);
     value_array_type value((std::size_t) padded, 0.0);
-    std::size_t k = 0; // consumed entries, in (row, column) order
-    index_type last_column = 0;
-    for (index_type r = 0; r < rows; ++r) {
+    // the pad column of a row is the column of the last entry BEFORE the padding in (row, column)
+    // order: the row's own last entry, or that of the nearest non-empty row above it
+    std::vector<index_type> last_before((std::size_t) rows + 1, 0);
+    for (index_type r = 0; r < rows; ++r)
+        last_before[(std::size_t) r + 1] = e.start[(std::size_t) r + 1] > e.start[(std::size_t) r]
+            ? e.col[e.start[(std::size_t) r + 1] - 1] : last_before[(std::size_t) r];
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < (long long) rows; ++r) {
         std::size_t dst = (std::size_t) r * (std::size_t) row_length;
-        for (index_type e = 0; e < len[(std::size_t) r]; ++e, ++k, ++dst) {
-            last_column = ci[(std::size_t) order[k]] - 1;
-            column_index[dst] = last_column;
-            value[dst] = va[(std::size_t) order[k]];
+        std::size_t const b = e.start[(std::size_t) r], n = e.start[(std::size_t) r + 1] - b;
+        for (std::size_t q = 0; q < n; ++q, ++dst) {
+            column_index[dst] = e.col[b + q];
+            value[dst] = e.val[b + q];
         }
-        for (index_type e = len[(std::size_t) r]; e < row_length; ++e, ++dst)
-            column_index[dst] = skip_padding ? std::numeric_limits<index_type>::max() : last_column;
+        index_type const pad = skip_padding ? std::numeric_limits<index_type>::max() : last_before[(std::size_t) r + 1];
+        for (std::size_t q = n; q < (std::size_t) row_length; ++q, ++dst)
+            column_index[dst] = pad;
     }
     return Matrix(rows, m.columns(), m.num_entries(), row_length, std::move(column_index),
                   std::move(value), skip_padding);

@@ -45,13 +45,7 @@ Matrix from_matrix_market(matrix_market::Matrix const & m, bool ell_skip_padding
     for (index_type l = width + 1; l <= longest; ++l)
         n_coo += (long long) hist[(std::size_t) l] * (l - width);
 
-    auto const order = matrix_market::row_major_order(m);
-    auto const & ri = m.row_indices();
-    auto const & ci = m.column_indices();
-    auto const va = m.values_real();
-    for (auto c : ci)
-        if (c < 1 || c > m.columns())
-            throw matrix::matrix_error("Column index out of bounds: " + std::to_string(c));
+    matrix_market::RowMajorEntries const e = matrix_market::row_major_entries(m);
 
     Matrix A;
     A.rows = rows;
@@ -67,24 +61,25 @@ Matrix from_matrix_market(matrix_market::Matrix const & m, bool ell_skip_padding
     A.coo_column_index.assign((std::size_t) n_coo, 0);
     A.coo_value.assign((std::size_t) n_coo, 0.0);
 
-    std::size_t k = 0, spill = 0; // consumed entries; COO entries written
-    index_type last_column = 0;   // column of the entry consumed last (0 before the first)
+    std::size_t spill = 0;      // COO entries written
+    index_type last_column = 0; // column of the entry consumed last (0 before the first)
     for (index_type r = 0; r < rows; ++r) {
         std::size_t dst = (std::size_t) r * (std::size_t) width;
+        std::size_t const b = e.start[(std::size_t) r];
         index_type const n = len[(std::size_t) r];
         index_type const in_ell = std::min(n, width);
-        for (index_type e = 0; e < in_ell; ++e, ++k, ++dst) {
-            last_column = ci[(std::size_t) order[k]] - 1;
+        for (index_type q = 0; q < in_ell; ++q, ++dst) {
+            last_column = e.col[b + (std::size_t) q];
             A.ell_column_index[dst] = last_column;
-            A.ell_value[dst] = va[(std::size_t) order[k]];
+            A.ell_value[dst] = e.val[b + (std::size_t) q];
         }
-        for (index_type e = in_ell; e < width; ++e, ++dst)
+        for (index_type q = in_ell; q < width; ++q, ++dst)
             A.ell_column_index[dst] = ell_skip_padding ? std::numeric_limits<index_type>::max() : last_column;
-        for (index_type e = width; e < n; ++e, ++k, ++spill) {
-            last_column = ci[(std::size_t) order[k]] - 1;
-            A.coo_row_index[spill] = ri[(std::size_t) order[k]] - 1;
+        for (index_type q = width; q < n; ++q, ++spill) {
+            last_column = e.col[b + (std::size_t) q];
+            A.coo_row_index[spill] = r;
             A.coo_column_index[spill] = last_column;
-            A.coo_value[spill] = va[(std::size_t) order[k]];
+            A.coo_value[spill] = e.val[b + (std::size_t) q];
         }
     }
     return A;

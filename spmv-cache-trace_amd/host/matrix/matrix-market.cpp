@@ -567,6 +567,98 @@ std::vector<T> permuted(std::vector<T> const & v, std::vector<size_type> const &
 
 } // namespace
 
+RowMajorEntries row_major_entries(Matrix const & m)
+{
+    RowMajorEntries out;
+    index_type const rows = m.rows();
+    auto const & ri = m.row_indices();
+    auto const & ci = m.column_indices();
+    std::size_t const N = ri.size();
+    bool const pattern = m.field() == Field::pattern;
+    std::vector<real_type> const ones;
+    auto const & va = m.a_;
+
+    auto const len = m.row_lengths(); // validates the row indices
+    for (auto c : ci)
+        if (c < 1 || c > m.columns())
+            throw matrix_error("Column index out of bounds: " + std::to_string(c));
+    out.start.assign((std::size_t) rows + 1, 0);
+    for (index_type r = 0; r < rows; ++r)
+        out.start[(std::size_t) r + 1] = out.start[(std::size_t) r] + (std::size_t) len[(std::size_t) r];
+    out.col.resize(N);
+    out.val.resize(N);
+    std::vector<std::size_t> cursor(out.start.begin(), out.start.end() - 1);
+
+#ifdef _OPENMP
+    int const threads = std::max(1, omp_get_max_threads());
+#else
+    int const threads = 1;
+#endif
+    // every thread owns a contiguous range of rows holding ~N/threads entries, reads the whole
+    // entry list and places the entries of its rows: no atomics, writes stay inside its range
+    std::vector<index_type> bound((std::size_t) threads + 1, rows);
+    bound[0] = 0;
+    for (int t = 1; t < threads; ++t) {
+        std::size_t const target = N / (std::size_t) threads * (std::size_t) t;
+        bound[(std::size_t) t] = (index_type) (std::lower_bound(out.start.begin(), out.start.end(), target) - out.start.begin());
+        bound[(std::size_t) t] = std::min(bound[(std::size_t) t], rows);
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; ++t) {
+        index_type const lo = bound[(std::size_t) t], hi = bound[(std::size_t) t + 1];
+        if (lo >= hi)
+            continue;
+        for (std::size_t k = 0; k < N; ++k) {
+            index_type const r = ri[k] - 1;
+            if (r >= lo && r < hi) {
+                std::size_t const dst = cursor[(std::size_t) r]++;
+                out.col[dst] = ci[k] - 1;
+                out.val[dst] = pattern ? 1.0 : va[k];
+            }
+        }
+    }
+    // order each row by column; rows arrive in file order, so already-sorted rows are common
+#pragma omp parallel for schedule(dynamic, 2048)
+    for (long long r = 0; r < (long long) rows; ++r) {
+        std::size_t const b = out.start[(std::size_t) r], e = out.start[(std::size_t) r + 1];
+        bool sorted = true;
+        for (std::size_t k = b + 1; k < e; ++k)
+            if (out.col[k] < out.col[k - 1]) {
+                sorted = false;
+                break;
+            }
+        if (sorted)
+            continue;
+        if (e - b <= 64) { // stable insertion sort of (column, value) pairs
+            for (std::size_t k = b + 1; k < e; ++k) {
+                index_type const c = out.col[k];
+                real_type const v = out.val[k];
+                std::size_t q = k;
+                while (q > b && out.col[q - 1] > c) {
+                    out.col[q] = out.col[q - 1];
+                    out.val[q] = out.val[q - 1];
+                    --q;
+                }
+                out.col[q] = c;
+                out.val[q] = v;
+            }
+        } else {
+            std::vector<std::size_t> idx(e - b);
+            std::iota(idx.begin(), idx.end(), b);
+            std::stable_sort(idx.begin(), idx.end(), [&](std::size_t p, std::size_t q) { return out.col[p] < out.col[q]; });
+            std::vector<index_type> c2(e - b);
+            std::vector<real_type> v2(e - b);
+            for (std::size_t k = 0; k < e - b; ++k) {
+                c2[k] = out.col[idx[k]];
+                v2[k] = out.val[idx[k]];
+            }
+            std::copy(c2.begin(), c2.end(), out.col.begin() + (std::ptrdiff_t) b);
+            std::copy(v2.begin(), v2.end(), out.val.begin() + (std::ptrdiff_t) b);
+        }
+    }
+    return out;
+}
+
 std::vector<size_type> row_major_order(Matrix const & m)
 {
     return two_key_order(m.row_indices(), m.column_indices(), m.rows(), "Row");

@@ -46,6 +46,8 @@ struct Size
     size_type num_entries = 0;
 };
 
+struct RowMajorEntries;
+
 class Matrix
 {
 public:
@@ -77,6 +79,7 @@ private:
     friend Matrix sort_matrix_row_major(Matrix const &);
     friend Matrix sort_matrix_column_major(Matrix const &);
     friend Matrix expand_symmetry(Matrix const &);
+    friend struct RowMajorEntries row_major_entries(Matrix const &);
     Header header_;
     std::vector<std::string> comments_;
     Size size_;
@@ -95,6 +98,17 @@ Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose = fa
 // The named member of a gzip'ed tar archive (what load_matrix does for *.tar.gz after it has
 // derived the member name from the path).
 Matrix load_tar_gz_member(std::string const & path, std::string const & member);
+
+// The entries grouped by row and ordered by column inside each row (stable: duplicate (i, j) keep
+// their file order), built by all OpenMP threads: what every row-major format converter starts from.
+// start[r] .. start[r+1] are the entries of row r; col is 0-based; val follows values_real().
+struct RowMajorEntries
+{
+    std::vector<std::size_t> start;
+    std::vector<index_type> col;
+    std::vector<real_type> val;
+};
+RowMajorEntries row_major_entries(Matrix const & m);
 
 // Stable permutation that orders the entries by (row, column) / (column, row).
 std::vector<size_type> row_major_order(Matrix const & m);
