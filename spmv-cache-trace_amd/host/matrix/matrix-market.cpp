@@ -1,6 +1,7 @@
 #include "matrix-market.hpp"
 
 #include "matrix-error.hpp"
+#include "matrix-reorder.hpp"
 
 #include <zlib.h>
 
@@ -470,16 +471,10 @@ Matrix load_tar_gz_member(std::string const & path, std::string const & member)
     return fromBuffer(tar.data.data(), tar.data.size());
 }
 
-Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
-{
-    // The reference strips "__RCM" / "__GP<n>" suffixes here and reorders the matrix
-    // (src/matrix/matrix-market.cpp:782-802).  Reordering is outside this engine's scope: such
-    // paths are refused rather than silently loaded unordered.
-    if (path.rfind("__RCM") != std::string::npos || path.rfind("__GP") != std::string::npos)
-        throw matrix_error("matrix reordering (__RCM / __GP path suffixes) is not supported");
-    if (verbose)
-        o << "Loading matrix from " << path << '\n';
+namespace {
 
+Matrix load_file(std::string const & path, std::ostream & o, bool verbose)
+{
     std::ifstream f(path, std::ios::binary);
     if (!f)
         throw matrix_error(std::strerror(errno));
@@ -516,6 +511,42 @@ Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
         text.resize((std::size_t) f.gcount());
     }
     return fromBuffer(text.data(), text.size());
+}
+
+} // namespace
+
+Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
+{
+    // "<file>__RCM" / "<file>__GP<n>": load <file>, then reorder it
+    // (src/matrix/matrix-market.cpp:782-802)
+    std::string file = path;
+    bool rcm = false, gp = false;
+    int nparts = 0;
+    auto pos = file.rfind("__RCM");
+    if (pos != std::string::npos) {
+        rcm = true;
+        file.erase(pos);
+    }
+    pos = file.rfind("__GP");
+    if (pos != std::string::npos) {
+        gp = true;
+        if (pos + 4 < file.size())
+            nparts = std::atoi(file.c_str() + pos + 4);
+        file.erase(pos);
+    }
+    if (verbose) {
+        o << "Loading matrix from " << file << '\n';
+        if (rcm)
+            o << "The input matrix will be reordered using reverse Cuthill-McKee\n";
+        if (gp)
+            o << "The input matrix will be reordered using graph partitioning\n";
+    }
+    Matrix m = load_file(file, o, verbose);
+    if (rcm)
+        m = permute(m, find_new_order_RCM(m, o, verbose));
+    if (gp)
+        m = permute(m, find_new_order_GP(m, nparts, o, verbose));
+    return m;
 }
 
 // ------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 //   * the symmetry word is parsed and KEPT, but entries are never mirrored: a symmetric file
 //     yields only the triangle it stores unless expand_symmetry() is asked for
 //   * a tarball named <name>.tar.gz is searched for the member <name>/<name>.mtx (:746-775)
+//   * a path ending in "__RCM" / "__GP<n>" loads the file before the suffix and reorders it
+//     (:782-802; matrix-reorder.hpp)
 //
 // New here: entries live in structure-of-arrays form (no AoS -> SoA copies), the text is
 // tokenised in memory by all OpenMP threads, and sorting is a counting sort on the row index.

@@ -34,6 +34,20 @@ def main():
         rows, cols, p, c, v = synth.stencil27_like(160, 160, 160)
     elif args.workload == "random":
         rows, cols, p, c, v = synth.random_uniform(2000000, 2000000, 24, seed=3)
+    elif args.workload in ("scrambled", "scrambled_rcm"):
+        # a 27-point stencil whose unknowns were numbered at random, and the same matrix after reverse
+        # Cuthill-McKee (scipy's here, to avoid a text round trip; the product's RCM is
+        # host/matrix/matrix-reorder.cpp behind the "__RCM" path suffix): what reordering buys the gather
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        rows, cols, p, c, v = synth.stencil27_like(100, 100, 100)
+        perm = np.random.default_rng(11).permutation(rows)
+        A = sp.csr_matrix((v, c, p), shape=(rows, cols))[perm][:, perm].tocsr()
+        if args.workload == "scrambled_rcm":
+            order = reverse_cuthill_mckee(A, symmetric_mode=True)
+            A = A[order][:, order].tocsr()
+        A.sort_indices()
+        p, c, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
     elif args.workload == "queen":  # ~80 entries/row, banded-ish
         rows, cols, p, c, v = synth.banded(2000000, list(range(-40, 41)), seed=5)
     else:
