@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each all-gather before the next multiply (default: gather k overlaps multiply k+1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo is for rehearsing N > 1 on a box with one GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: every rank uses device 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the all-gather even with one rank (rehearsal)")
     return ap.parse_args()
@@ -188,13 +192,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; this benchmark has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collective
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- workload: this rank's rows, global x ------------------------------------------
     t_setup = time.perf_counter()
@@ -265,6 +274,26 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = stats.tolist()
 
+    # N > 1: the gathered y must hold what the OTHER ranks computed.  Rank 0 recomputes a strip of
+    # the last rank's rows on its own GPU (product kernel, one multiply) and compares it with the
+    # gathered segment, which has accumulated warm-up + K multiplies.
+    gather_check = None
+    if use_dist and world > 1 and rank == 0 and args.workload == "poisson2d":
+        ob, oe = partition.row_range(rows, world - 1, world)
+        strip = min(4096, oe - ob)
+        _, _, ps, cs, vs = synth.poisson2d(args.grid, ob, ob + strip)
+        tps, tcs, tvs = (torch.from_numpy(t).to(device) for t in (ps, cs, vs))
+        ys = torch.zeros(strip, dtype=torch.float64, device=device)
+        plan_s = capi.CsrPlan(strip, cols, ps, algo, args.lanes, flags)
+        plan_s.spmv(tps.data_ptr(), tcs.data_ptr(), tvs.data_ptr(), op._keep[3].data_ptr(), ys.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = ys * float(args.steps + args.warmup)
+        got = op.y()[ob:ob + strip]
+        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-300))
+        gather_check = {"rows_checked": strip, "of_rank": world - 1, "max_rel_err": err, "pass": bool(err <= 1e-10)}
+        plan_s.close()
+
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
         gflops = 2.0 * nnz * args.steps / elapsed_max / 1e9
@@ -283,7 +312,8 @@ def main():
                        "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
                        "partition": ("rows/%d static chunks, x replicated, 1 all-gather(y)/step%s" % (
                            world, ", gather k overlaps multiply k+1" if op.overlap else ""))
-                       if use_dist else "single GPU"},
+                       if use_dist else "single GPU", "backend": args.backend if use_dist else None,
+                       "rehearsal_shared_gpu": bool(args.share_gpu)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "csr_%s" % capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
@@ -293,6 +323,11 @@ def main():
             "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
             "setup_s": round(setup_s, 1),
         }
+        if gather_check:
+            out["gather_check"] = gather_check
+            if not gather_check["pass"]:
+                print(json.dumps(out), flush=True)
+                sys.exit("bench.py: gathered y does not match the owning rank's rows")
         tr = pmc_traffic(out["roofline"]["kernel"], int(local_bytes))
         if tr:
             out["roofline"]["traffic"] = tr[0]
