@@ -61,6 +61,7 @@ extern "C" {
                                            deal (measured SLOWER on MI355X for streaming SpMV: off by default) */
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
 #define SPMV_HIP_FLAG_NO_INDEX_COMPRESSION 0x10u /* ctx: keep 32-bit column indices for every tile */
+#define SPMV_HIP_FLAG_COO_KEEP_ORDER 0x20u /* ctx: keep COO triplets in file order on the device */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -174,6 +175,14 @@ int spmv_hip_csr_spmv(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
 int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t *d_row_index,
                       const int32_t *d_column_index, const double *d_value,
                       const double *d_x, double *d_y, void *stream);
+
+/* Stable sort of COO triplets by row index, in place on the device (entries of a row keep their
+ * file order, so every row is still summed in file order).  Done automatically by
+ * spmv_hip_upload_coo / _hybrid when the triplets are not row-sorted (unless
+ * SPMV_HIP_FLAG_COO_KEEP_ORDER): in column-major file order -- what SuiteSparse ships -- every
+ * entry would cost its own atomic.  Allocates temporaries, synchronises `stream`. */
+int spmv_hip_coo_sort_by_row(int32_t rows, int32_t nnz, int32_t *d_row_index, int32_t *d_column_index,
+                             double *d_value, void *stream);
 
 /* Row-major (reference layout) -> column-major (k = l*rows + i) on the device. */
 int spmv_hip_ell_to_column_major(int32_t rows, int32_t row_length,

@@ -39,6 +39,10 @@ int fail_hip(hipError_t e, const char * call)
     return SPMV_HIP_ERR_HIP;
 }
 
+} // namespace
+int spmv_hip_internal_fail_hip(hipError_t e, const char * call) { return fail_hip(e, call); }
+namespace {
+
 #define HIP_TRY(call)                                   \
     do {                                                \
         hipError_t e_ = (call);                         \
@@ -98,6 +102,7 @@ struct spmv_hip_ctx {
     int32_t *d_ptr = nullptr, *d_idx = nullptr, *d_col = nullptr, *d_col2 = nullptr;
     double *d_val = nullptr, *d_val2 = nullptr, *d_x = nullptr, *d_y = nullptr;
     size_t bytes = 0;
+    bool coo_sorted_on_device = false;
 };
 
 namespace {
@@ -132,6 +137,7 @@ void free_ctx_matrix(spmv_hip_ctx * c)
     c->d_val = c->d_val2 = c->d_x = c->d_y = nullptr;
     c->format = 0;
     c->rows = c->cols = c->nnz = c->row_length = c->nnz2 = 0;
+    c->coo_sorted_on_device = false;
     c->bytes = 0;
 }
 
@@ -672,9 +678,13 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
-    for (int32_t k = 0; k < nnz; ++k)
+    bool row_sorted = true;
+    for (int32_t k = 0; k < nnz; ++k) {
         if (row_index[k] < 0 || row_index[k] >= rows || column_index[k] < 0 || column_index[k] >= cols)
             return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+        if (k > 0 && row_index[k] < row_index[k - 1])
+            row_sorted = false;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_ctx_matrix(c);
@@ -692,6 +702,10 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!row_sorted && !(c->flags & SPMV_HIP_FLAG_COO_KEEP_ORDER)) {
+        if ((rc = spmv_hip_coo_sort_by_row(rows, nnz, c->d_idx, c->d_col, c->d_val, c->stream)) != 0) return rc;
+        c->coo_sorted_on_device = true;
+    }
     c->format = 2;
     return SPMV_HIP_OK;
 }

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
 CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
-FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION = 0x1, 0x2, 0x8, 0x10
+FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER = 0x1, 0x2, 0x8, 0x10, 0x20
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -50,6 +50,7 @@ SIGNATURES = {
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_coo_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_coo_sort_by_row": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_to_column_major": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_triad": (C.c_int, [C.c_int64, _vp, _vp, _vp, C.c_double, _vp]),
@@ -270,6 +271,11 @@ class CsrPlan:
 
 def coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream=0):
     check(load().spmv_hip_coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream))
+
+
+def coo_sort_by_row(rows, nnz, d_row, d_col, d_val, stream=0):
+    """Stable in-place sort of device COO triplets by row index."""
+    check(load().spmv_hip_coo_sort_by_row(rows, nnz, d_row, d_col, d_val, stream))
 
 
 def ell_to_column_major(rows, row_length, d_col_rm, d_val_rm, d_col_cm, d_val_cm, stream=0):

@@ -576,3 +576,33 @@ def test_x_larger_than_4GiB(oracle):
                 assert_close(got, want, abs_products(rows, p, c, v, x), what="big x, algo %d" % algo)
     finally:
         ctx.close()
+
+
+def test_coo_sort_by_row_is_stable_and_automatic(oracle):
+    """Unsorted (e.g. column-major) COO is sorted by row on upload, stably: every row is still summed
+    in file order.  The flag keeps file order on the device (one atomic per entry)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rows, cols, p, c, v = synth.random_uniform(5000, 7000, 9, seed=12)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    order = np.lexsort((i, j))  # column-major file order, as SuiteSparse ships
+    r, cc, vv = (i[order] - 1).astype(np.int32), (j[order] - 1).astype(np.int32), a[order]
+    # level 2: explicit sort of caller-owned arrays
+    tr, tc, tv = torch.from_numpy(r).to(dev), torch.from_numpy(cc).to(dev), torch.from_numpy(vv).to(dev)
+    capi.coo_sort_by_row(rows, len(vv), tr.data_ptr(), tc.data_ptr(), tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    sr, sc, sv = tr.cpu().numpy(), tc.cpu().numpy(), tv.cpu().numpy()
+    stable = np.argsort(r, kind="stable")
+    assert np.array_equal(sr, r[stable]) and np.array_equal(sc, cc[stable]) and np.array_equal(sv, vv[stable])
+    # level 1: automatic, result within tolerance of the reference's serial file-order loop
+    x = synth.x_vector(cols)
+    want = oracle.coo_spmv(rows, r, cc, vv, x)
+    scale = abs_products(rows, p, c, v, x)
+    for flags in (0, capi.FLAG_COO_KEEP_ORDER):
+        c2 = capi.Context(0, flags=flags)
+        try:
+            c2.upload_coo(rows, cols, r, cc, vv)
+            c2.set_x(x)
+            c2.run()
+            assert_close(c2.get_y(), want, scale, what="coo flags %x" % flags)
+        finally:
+            c2.close()

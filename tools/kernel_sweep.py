@@ -182,6 +182,17 @@ def main():
             others[name] = {"us_median": round(med, 2), "gbs": round(cb / med / 1e3, 1), "gflops": round(2 * nnz / med / 1e3, 1)}
             print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [bytes %.3f GB]" % (
                 name, med, cb / med / 1e3, cb / med / 1e3 / 80, 2 * nnz / med / 1e3, cb / 1e9))
+            if name == "coo_shuffled":  # what the upload does by default: stable sort by row, once
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                capi.coo_sort_by_row(rows, nnz, tr.data_ptr(), tcc.data_ptr(), tvv.data_ptr(), stream)
+                e1.record()
+                torch.cuda.synchronize()
+                med = time_it(lambda: capi.coo_spmv(rows, nnz, tr.data_ptr(), tcc.data_ptr(), tvv.data_ptr(),
+                                                    tx.data_ptr(), ty.data_ptr(), stream))
+                others["coo_shuffled_sorted"] = {"us_median": round(med, 2), "sort_ms": round(e0.elapsed_time(e1), 2)}
+                print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  after a one-time %.1f ms sort by row" % (
+                    "coo_shuf_sorted", med, cb / med / 1e3, cb / med / 1e3 / 80, e0.elapsed_time(e1)))
             del tr, tcc, tvv
     if "ell" in fmts:
         L = int(np.diff(p).max())
