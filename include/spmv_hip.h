@@ -62,6 +62,8 @@ extern "C" {
 #define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
 #define SPMV_HIP_FLAG_NO_INDEX_COMPRESSION 0x10u /* ctx: keep 32-bit column indices for every tile */
 #define SPMV_HIP_FLAG_COO_KEEP_ORDER 0x20u /* ctx: keep COO triplets in file order on the device */
+#define SPMV_HIP_FLAG_READ_ROW_PTR 0x40u /* wavetile: read row_ptr even for tiles whose rows are all equally long
+                                            (by default their row bounds come from the tile descriptor) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -160,7 +162,8 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_inde
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);
 /* out[]: [0] algorithm  [1] lanes per row  [2] workgroups  [3] row blocks
  *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device
- *        [8] tiles with 16-bit column offsets (after spmv_hip_plan_csr_compress) */
+ *        [8] tiles with 16-bit column offsets (after spmv_hip_plan_csr_compress)
+ *        [9] uniform tiles (all rows equally long: row_ptr not read) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

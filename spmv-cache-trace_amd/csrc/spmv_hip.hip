@@ -85,6 +85,7 @@ struct spmv_hip_plan {
     uint16_t * d_col16 = nullptr;       // 16-bit column offsets of the narrow tiles (index compression)
     const int32_t * compressed_from = nullptr; // the column array d_col16 was derived from
     int narrow_tiles = 0;
+    int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     size_t meta_bytes = 0;
 };
 
@@ -256,9 +257,10 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
         while (r < rows) {
             const int32_t kb = p[r] & ~3;
             int32_t r1 = r;
-            int32_t maxlen = 0;
+            int32_t maxlen = 0, minlen = INT32_MAX;
             while (r1 < rows && (r1 - r) < 64 && (long long) p[r1 + 1] - kb <= tile) {
                 maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
+                minlen = std::min(minlen, p[r1 + 1] - p[r1]);
                 ++r1;
             }
             if (r1 == r) { // one row longer than a tile
@@ -283,7 +285,11 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                         ++lanes_log2;
                 // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
                 const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
-                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0), 0));
+                const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
+                if (uniform)
+                    pl->uniform_tiles++;
+                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
+                                                      (uniform ? (1 << 26) : 0), 0));
             }
             r = r1;
         }
@@ -396,9 +402,10 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[9] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
-                          pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles};
-    for (int i = 0; i < n && i < 9; ++i)
+    const int64_t v[10] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+                           pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
+                           pl->uniform_tiles};
+    for (int i = 0; i < n && i < 10; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

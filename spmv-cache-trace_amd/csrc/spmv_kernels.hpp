@@ -231,8 +231,9 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // The host cuts the rows into tiles owned by ONE wave: up to 64 consecutive rows
 // holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
 // described by an int4 {first row | flags, first entry, meta, column base} with
-// meta = longest row | log2(lanes per row) << 16 | narrow << 24; tile w ends where tile
-// w+1 starts.  A wave reads its descriptor pair with scalar
+// meta = longest row | log2(lanes per row) << 16 | narrow << 24 | fast << 25 | uniform << 26;
+// tile w ends where tile w+1 starts.  In a uniform tile (all rows equally long, e.g. the interior
+// of a stencil) the row bounds follow from the descriptor and row_ptr is not read.  A wave reads its descriptor pair with scalar
 // loads and then has everything it needs to issue ALL its independent loads back to
 // back -- the row_ptr pair and old y of the lane's row, then the column/value quads
 // (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs three
@@ -264,6 +265,7 @@ constexpr int kTileFlagPartial = (int) 0x80000000u;
 constexpr int kTileMetaLanesShift = 16;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
+constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -410,10 +412,18 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         const int sub = lane >> lanes_log2;
         const int part = lane & ((1 << lanes_log2) - 1);
         const int rowi = sub < nrows ? sub : nrows - 1; // clamp instead of branching
-        const int32_t * pt = p + r0;
         double * yt = y + r0;
-        const int ps = pt[rowi];
-        const int pe = pt[rowi + 1];
+        int ps, pe;
+        if (meta & kTileMetaUniform) {
+            // all rows equally long (the interior of any stencil): row bounds follow from the
+            // descriptor, row_ptr is not read at all
+            ps = k0 + rowi * maxlen;
+            pe = ps + maxlen;
+        } else {
+            const int32_t * pt = p + r0;
+            ps = pt[rowi];
+            pe = pt[rowi + 1];
+        }
         const double yv = yt[rowi];
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
 CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
-FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER = 0x1, 0x2, 0x8, 0x10, 0x20
+FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER, FLAG_READ_ROW_PTR = 0x1, 0x2, 0x8, 0x10, 0x20, 0x40
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -254,10 +254,10 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(9, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 9))
+        out = np.zeros(10, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 10))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes", "narrow_tiles"]
+                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

@@ -73,6 +73,7 @@ def main():
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
         "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100),  # 0x100: sweep-local marker = compress the plan
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100),
+        "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
