@@ -64,6 +64,9 @@ extern "C" {
 #define SPMV_HIP_FLAG_COO_KEEP_ORDER 0x20u /* ctx: keep COO triplets in file order on the device */
 #define SPMV_HIP_FLAG_READ_ROW_PTR 0x40u /* wavetile: read row_ptr even for tiles whose rows are all equally long
                                             (by default their row bounds come from the tile descriptor) */
+#define SPMV_HIP_FLAG_ROWS64 0x80u       /* wavetile: at most 64 rows per tile ... */
+#define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
+                                            exceeds ~768 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;

@@ -258,7 +258,13 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             const int32_t kb = p[r] & ~3;
             int32_t r1 = r;
             int32_t maxlen = 0, minlen = INT32_MAX;
-            while (r1 < rows && (r1 - r) < 64 && (long long) p[r1 + 1] - kb <= tile) {
+            // rows per tile: 128 (two short rows per lane, fuller quads) pays once the matrix streams from
+            // HBM; while it still fits the 256 MiB Infinity Cache more, smaller tiles win (measured:
+            // Poisson 4096^2 223 vs 238 us, Poisson 2048^2 57 vs 50 us)
+            const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
+            const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
+                : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 768e6 ? 128 : 64);
+            while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
                 maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
                 minlen = std::min(minlen, p[r1 + 1] - p[r1]);
                 ++r1;
@@ -450,7 +456,12 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
                        pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact)
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
-            if (pl->tile == 1024) {
+            const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
+            if (abl && c16 && x32 && pl->tile == 512) {
+                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+            } else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);

@@ -228,8 +228,8 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // ---------------------------------------------------------------------------------
 // CSR, wave tiles ("wavetile"): per-wavefront row ownership, no workgroup barrier.
 //
-// The host cuts the rows into tiles owned by ONE wave: up to 64 consecutive rows
-// holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
+// The host cuts the rows into tiles owned by ONE wave: up to 128 consecutive rows
+// (two per lane when rows are short) holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
 // described by an int4 {first row | flags, first entry, meta, column base} with
 // meta = longest row | log2(lanes per row) << 16 | narrow << 24 | fast << 25 | uniform << 26;
 // tile w ends where tile w+1 starts.  In a uniform tile (all rows equally long, e.g. the interior
@@ -339,7 +339,7 @@ __device__ __forceinline__ void tile_products_wide(
 
 // The same with 16-bit column offsets from the tile's base: xt = x + base (scalar), limit =
 // last valid offset from the base (cols - 1 - base).
-template <int QUADS>
+template <int QUADS, int ABL>
 __device__ __forceinline__ void tile_products_narrow(
     double * prod, const uint16_t * __restrict__ jt, const double * __restrict__ at,
     const double * __restrict__ xt, unsigned limit, int last, int lane)
@@ -360,8 +360,11 @@ __device__ __forceinline__ void tile_products_narrow(
     for (int q = 0; q < QUADS; ++q) {
         const int o = 256 * q + 4 * lane;
         if (o <= last) {
-            const unsigned c0 = min(c[q].x & 0xFFFFu, limit), c1 = min(c[q].x >> 16, limit);
-            const unsigned c2 = min(c[q].y & 0xFFFFu, limit), c3 = min(c[q].y >> 16, limit);
+            unsigned c0 = min(c[q].x & 0xFFFFu, limit), c1 = min(c[q].x >> 16, limit);
+            unsigned c2 = min(c[q].y & 0xFFFFu, limit), c3 = min(c[q].y >> 16, limit);
+            if (ABL & 1) { // timing experiment only: every lane gathers the same four x entries
+                c0 &= 1; c1 &= 1; c2 &= 1; c3 &= 1;
+            }
             const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c0 << 3));
             const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
             const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
@@ -373,7 +376,9 @@ __device__ __forceinline__ void tile_products_narrow(
     }
 }
 
-template <int TILE, bool C16, bool X32, bool XCD>
+// ABL: timing experiments that switch parts of the work off (results are wrong by design):
+// 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0>
 __global__ __launch_bounds__(256) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
@@ -425,12 +430,27 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
             pe = pt[rowi + 1];
         }
         const double yv = yt[rowi];
+        // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
+        const bool second = nrows > kWave; // wave-uniform; implies one lane per row
+        int psB = 0, peB = 0;
+        double yvB = 0.0;
+        if (second) {
+            const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
+            if (meta & kTileMetaUniform) {
+                psB = k0 + rowB * maxlen;
+                peB = psB + maxlen;
+            } else {
+                psB = p[r0 + rowB];
+                peB = p[r0 + rowB + 1];
+            }
+            yvB = yt[rowB];
+        }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         const int last = (k1 - 1 - kb) & ~3;
         if (C16 && (meta & kTileMetaNarrow))
-            tile_products_narrow<QUADS>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
+            tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
         else
             tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
         // same-wave LDS operations execute in order; the fences only pin the compiler
@@ -441,7 +461,9 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         const int s = ps - kb;
         const int e_row = pe - kb;
         double z;
-        if (lanes_log2 == 0) { // short rows: one lane per row, the reference's order
+        if (ABL & 2) {
+            z = prod[s];
+        } else if (lanes_log2 == 0) { // short rows: one lane per row, the reference's order
             z = tile_row_sum<1>(prod, s, e_row, 0, maxlen);
         } else {
             const int trips = (maxlen + (1 << lanes_log2) - 1) >> lanes_log2;
@@ -456,6 +478,11 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         }
         if (sub < nrows && part == 0)
             yt[sub] = yv + z;
+        if (second) {
+            const double zB = (ABL & 2) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
+            if (lane + kWave < nrows)
+                yt[lane + kWave] = yvB + zB;
+        }
     } else if (!partial && k1 - kb <= TILE) {
         // ---- stream tile at the ragged end of the arrays, or a tile of empty rows: scalar
         // loads, one lane per row
@@ -464,12 +491,12 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < nrows) {
-            const int s = p[r0 + lane] - kb, e_row = p[r0 + lane + 1] - kb;
+        for (int r = lane; r < nrows; r += kWave) {
+            const int s = p[r0 + r] - kb, e_row = p[r0 + r + 1] - kb;
             double z = 0.0;
             for (int k = s; k < e_row; ++k)
                 z += prod[k];
-            y[r0 + lane] += z;
+            y[r0 + r] += z;
         }
     } else if (!exact_order) {
         // ---- one long row, or one chunk of a very long row: the wave strides it ----------

@@ -280,7 +280,7 @@ def test_index_compression_level2(oracle):
     plan.close()
 
 
-@pytest.mark.parametrize("flags", [capi.FLAG_XCD_REMAP, capi.FLAG_BIG_TILE, capi.FLAG_READ_ROW_PTR,
+@pytest.mark.parametrize("flags", [capi.FLAG_XCD_REMAP, capi.FLAG_BIG_TILE, capi.FLAG_READ_ROW_PTR, capi.FLAG_ROWS64, capi.FLAG_ROWS128,
                                    capi.FLAG_NO_INDEX_COMPRESSION | capi.FLAG_BIG_TILE | capi.FLAG_XCD_REMAP])
 def test_wavetile_variants(oracle, flags):
     """The tuning switches of the wave-tile kernel change speed only, never y."""

@@ -71,15 +71,21 @@ def main():
         "wavetile": (capi.CSR_WAVETILE, 0, 0),
         "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
-        "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100),  # 0x100: sweep-local marker = compress the plan
-        "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100),
-        "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100),
+        "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100000),  # 0x100000: sweep-local marker = compress the plan
+        "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
+        "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
+        "wavetile_c16_rows64": (capi.CSR_WAVETILE, 0, capi.FLAG_ROWS64 | 0x100000),
+        "wavetile_c16_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_ROWS128 | 0x100000),
+        # timing experiments (wrong results by design): where the time of a tile goes
+        "abl_no_gather": (capi.CSR_WAVETILE, 0, 0x10000 | 0x100000),
+        "abl_no_rowsum": (capi.CSR_WAVETILE, 0, 0x20000 | 0x100000),
+        "abl_neither": (capi.CSR_WAVETILE, 0, 0x30000 | 0x100000),
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
-    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0xFF) for k, (a, l, f) in variants.items()}
+    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0x3FFFF) for k, (a, l, f) in variants.items()}
     for k, (a, l, f) in variants.items():
-        if f & 0x100:
+        if f & 0x100000:
             plans[k].compress(tc.data_ptr(), stream)
     times = {k: [] for k in plans}
     for rnd in range(args.rounds + 1):
