@@ -67,6 +67,9 @@ extern "C" {
 #define SPMV_HIP_FLAG_ROWS64 0x80u       /* wavetile: at most 64 rows per tile ... */
 #define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
                                             exceeds ~768 MB (streams from HBM), 64 while it is cache-resident */
+#define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
+                                                kernel (default only for row_length >= 16; shorter rows run in place
+                                                as uniform wave tiles) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -109,7 +112,9 @@ int spmv_hip_upload_coo(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t n
                         const double *value);
 
 /* ELLPACK in the reference's ROW-MAJOR padded layout, k = i*row_length + l
- * (src/matrix/ell-matrix.cpp:253-256); transposed to column-major on the device. */
+ * (src/matrix/ell-matrix.cpp:253-256).  With row_length < 16 the arrays are used in place as
+ * uniform wave tiles (one lane per row, padding multiplied like real entries); longer rows are
+ * transposed to column-major on the device.  Either way the sums keep the reference's order. */
 int spmv_hip_upload_ell(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t row_length,
                         const int32_t *column_index, const double *value);
 

@@ -104,6 +104,7 @@ struct spmv_hip_ctx {
     double *d_val = nullptr, *d_val2 = nullptr, *d_x = nullptr, *d_y = nullptr;
     size_t bytes = 0;
     bool coo_sorted_on_device = false;
+    bool ell_as_tiles = false; // ELLPACK with short rows runs as uniform CSR tiles (row-major, in place)
 };
 
 namespace {
@@ -139,6 +140,7 @@ void free_ctx_matrix(spmv_hip_ctx * c)
     c->format = 0;
     c->rows = c->cols = c->nnz = c->row_length = c->nnz2 = 0;
     c->coo_sorted_on_device = false;
+    c->ell_as_tiles = false;
     c->bytes = 0;
 }
 
@@ -753,7 +755,26 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     int rc;
     if ((rc = dev_alloc(c, &c->d_col, (size_t) n)) != 0) return rc;
     if ((rc = dev_alloc(c, &c->d_val, (size_t) n)) != 0) return rc;
-    if (n > 0) {
+    // Short rows (row_length < 16): the row-major ELLPACK arrays ARE a CSR matrix with
+    // row_ptr[i] = i*row_length, every tile of which is uniform (row bounds from the descriptor, no
+    // row_ptr traffic), one lane per row -- the reference's order -- and eligible for 16-bit columns:
+    // run them through the wave-tile kernel in place, no transposed copy.  Longer rows take the
+    // column-major one-lane-per-row kernel, which keeps the order for any row length.
+    c->ell_as_tiles = n > 0 && row_length < 16 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR);
+    if (c->ell_as_tiles) {
+        std::vector<int32_t> row_ptr((size_t) rows + 1);
+        for (int32_t i = 0; i <= rows; ++i)
+            row_ptr[(size_t) i] = i * row_length;
+        if ((rc = spmv_hip_plan_csr(&c->plan, rows, cols, row_ptr.data(), SPMV_HIP_CSR_WAVETILE, 0, c->flags)) != 0)
+            return rc;
+        if ((rc = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr.data(), ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION))
+            if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
+    } else if (n > 0) {
         int32_t * t_col = nullptr;
         double * t_val = nullptr;
         HIP_TRY(hipMalloc((void **) &t_col, (size_t) n * sizeof(int32_t)));
@@ -866,9 +887,15 @@ int spmv_hip_run(spmv_hip_ctx * c)
     switch (c->format) {
     case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
     case 2: rc = spmv_hip_coo_spmv(c->rows, c->nnz, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
-    case 3: rc = spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 3:
+        rc = c->ell_as_tiles
+            ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
+            : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+        break;
     case 4:
-        rc = spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+        rc = c->ell_as_tiles
+            ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
+            : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
         if (rc == 0)
             rc = spmv_hip_coo_spmv(c->rows, c->nnz2, c->d_idx, c->d_col2, c->d_val2, c->d_x, c->d_y, c->stream);
         break;

@@ -315,6 +315,33 @@ def test_synthetic_coo_sorted_and_shuffled(ctx, oracle, name, gen):
         assert_close(ctx.get_y(), want, scale, what="%s/coo/%s" % (name, order))
 
 
+@pytest.mark.parametrize("flags", [0, capi.FLAG_ELL_COLUMN_MAJOR, capi.FLAG_NO_INDEX_COMPRESSION | capi.FLAG_ROWS128])
+def test_ell_paths_bitexact(oracle, golden, flags):
+    """Short rows run in place as uniform wave tiles, long rows column-major: same bits either way."""
+    c2 = capi.Context(0, flags=flags)
+    try:
+        for name, gen in SYNTH[:4] + SYNTH[6:7]:
+            rows, cols, p, c, v = gen()
+            i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+            rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+            x = synth.x_vector(cols)
+            y0 = synth.x_vector(rows, seed=6)
+            c2.upload_ell(rows, cols, L, ec, ev)
+            c2.set_x(x)
+            c2.set_y(y0)
+            c2.run(2)
+            assert_bitexact(c2.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2), "%s/ell/flags%x" % (name, flags))
+        for case in golden["cases"]:
+            rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+            rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+            c2.upload_ell(rows, cols, L, ec, ev)
+            c2.set_x(unhex(case["x"]))
+            c2.run(case["runs"])
+            assert_bitexact(c2.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell/flags%x" % flags)
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("name,gen", SYNTH[:2] + SYNTH[2:4] + SYNTH[6:7])
 def test_synthetic_ell_bitexact(ctx, oracle, name, gen):
     rows, cols, p, c, v = gen()
