@@ -147,6 +147,7 @@ def cpu_baseline(args, rows, cols, p, c, v, x, y_gpu=None):
         per = max(float(np.median(ns)) * 1e-9, 1e-4)
         runs = int(max(3, min(200, (budget - (time.perf_counter() - t)) / per)))
         ns, _ = R.csr_spmv_timed(A, x, threads, runs)
+        ns1, _ = R.csr_spmv_timed(A, x, 1, 3)  # one thread, as BASELINE configs[0] is defined
         y_cpu = R.csr_spmv(A, x, num_threads=threads) if y_gpu is not None else None
         R.csr_free(A)
         kind = "reference"
@@ -161,6 +162,12 @@ def cpu_baseline(args, rows, cols, p, c, v, x, y_gpu=None):
             O.csr_spmv_inplace(rows, p, c, v, x, y, threads)
             ns.append(time.perf_counter_ns() - t0)
         ns = np.array(ns)
+        ns1 = []
+        for _ in range(3):
+            t0 = time.perf_counter_ns()
+            O.csr_spmv_inplace(rows, p, c, v, x, y, 1)
+            ns1.append(time.perf_counter_ns() - t0)
+        ns1 = np.array(ns1)
         y_cpu = O.csr_spmv(rows, p, c, v, x, num_threads=threads) if y_gpu is not None else None
         kind = "port"
     med = float(np.median(ns)) * 1e-9
@@ -173,7 +180,8 @@ def cpu_baseline(args, rows, cols, p, c, v, x, y_gpu=None):
     return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
             "sample": "full workload, %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
                       % (len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
-            "gbs": round((12.0 * nnz + 4 * (rows + 1) + 16.0 * rows + 8.0 * cols) / med / 1e9, 2)}, parity
+            "gbs": round((12.0 * nnz + 4 * (rows + 1) + 16.0 * rows + 8.0 * cols) / med / 1e9, 2),
+            "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3)}, parity
 
 
 def main():

@@ -633,3 +633,37 @@ def test_coo_sort_by_row_is_stable_and_automatic(oracle):
             assert_close(c2.get_y(), want, scale, what="coo flags %x" % flags)
         finally:
             c2.close()
+
+
+def test_large_stencil27_properties(oracle):
+    """Stand-in for BASELINE configs[3] (nlpkkt200: ~27 entries per row) at 160^3 = 4.1 M rows,
+    110 M entries: row slices against the oracle, linearity, accumulate."""
+    import torch
+    rows, cols, p, c, v = synth.stencil27_like(160, 160, 160, seed=2)
+    dev = torch.device("cuda:0")
+    tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO)
+    plan.compress(tc.data_ptr(), stream)
+    info = plan.info()
+    assert info["narrow_tiles"] == info["row_blocks"] - info["long_blocks"]  # banded: every tile qualifies
+
+    def mul(xh, y0=None, runs=1):
+        tx = torch.from_numpy(xh).to(dev)
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev) if y0 is None else torch.from_numpy(y0).to(dev)
+        for _ in range(runs):
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return ty.cpu().numpy()
+
+    x, z = synth.x_vector(cols, seed=1), synth.x_vector(cols, seed=2)
+    yx, yz = mul(x), mul(z)
+    scale = np.full(rows, 27.0)
+    assert_close(mul(0.5 * x - 2.0 * z), 0.5 * yx - 2.0 * yz, scale=scale, what="linearity")
+    assert_close(mul(x, y0=z.copy(), runs=3), z + 3.0 * yx, scale=3 * scale, what="accumulate")
+    for lo in (0, 1234567, rows - 50000):  # first rows, interior, last rows
+        hi = lo + 50000
+        ps = (p[lo:hi + 1] - p[lo]).astype(np.int32)
+        want = oracle.csr_spmv(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x, num_threads=4)
+        assert_close(yx[lo:hi], want, abs_products(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x), what="slice %d" % lo)
+    plan.close()
