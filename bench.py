@@ -282,6 +282,22 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = stats.tolist()
 
+    # N > 1: the collective on its own (after the timed region, not part of `value`): a few
+    # blocking all-gathers, max over ranks, so the line shows where a step's time goes.
+    gather_us = None
+    if use_dist:
+        times = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            dist.all_gather_into_tensor(op.y_full, op.send_buf if op.overlap else op.y_local, group=op.group)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - g0)
+        gt = torch.tensor([float(np.median(times))], dtype=torch.float64, device=device)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_us = gt.item() * 1e6
+
     # N > 1: the gathered y must hold what the OTHER ranks computed.  Rank 0 recomputes a strip of
     # the last rank's rows on its own GPU (product kernel, one multiply) and compares it with the
     # gathered segment, which has accumulated warm-up + K multiplies.
@@ -332,6 +348,13 @@ def main():
             "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
             "setup_s": round(setup_s, 1),
         }
+        if gather_us is not None:
+            recv = 8.0 * op.chunk * (world - 1)
+            out["multi_gpu"] = {"local_kernel_us": round(kern_s * 1e6, 2), "all_gather_us": round(gather_us, 2),
+                                "all_gather_bytes_received_per_rank": int(recv),
+                                "all_gather_gbs_received_per_rank": round(recv / (gather_us * 1e-6) / 1e9, 1) if world > 1 else None,
+                                "overlap": bool(op.overlap),
+                                "note": "all_gather_us: blocking collective alone, median of 5 after the timed region"}
         if gather_check:
             out["gather_check"] = gather_check
             if not gather_check["pass"]:

@@ -85,6 +85,7 @@ struct spmv_hip_plan {
     uint16_t * d_col16 = nullptr;       // 16-bit column offsets of the narrow tiles (index compression)
     const int32_t * compressed_from = nullptr; // the column array d_col16 was derived from
     int narrow_tiles = 0;
+    int shifted_tiles = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     size_t meta_bytes = 0;
 };
@@ -384,16 +385,20 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
     int * d_count = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
-    hipError_t e = hipMalloc((void **) &d_count, sizeof(int));
+    int counts[2] = {0, 0};
+    hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
-                           pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count);
+                           pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
+                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&pl->narrow_tiles, d_count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    pl->narrow_tiles = counts[0];
+    pl->shifted_tiles = counts[1];
     if (d_count)
         (void) hipFree(d_count);
     if (e != hipSuccess) {
@@ -410,10 +415,10 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[10] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[11] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
-                           pl->uniform_tiles};
-    for (int i = 0; i < n && i < 10; ++i)
+                           pl->uniform_tiles, pl->shifted_tiles};
+    for (int i = 0; i < n && i < 11; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

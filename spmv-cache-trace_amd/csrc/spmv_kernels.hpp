@@ -266,6 +266,9 @@ constexpr int kTileMetaLanesShift = 16;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
+// narrow + uniform + every row has the columns of the tile's first row shifted by its distance
+// from it (the interior of a stencil, a band matrix): only the first row's offsets are read
+constexpr int kTileMetaShifted = 1 << 27;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -376,6 +379,55 @@ __device__ __forceinline__ void tile_products_narrow(
     }
 }
 
+// A "shifted" tile: entry t of the tile (row t / len, position t % len) has column offset
+// first_row[t % len] + t / len, so the 2 bytes per entry of column offsets shrink to the first
+// row's `len` offsets, held one per lane and fetched with ds_bpermute.  t / len uses a 16-bit
+// reciprocal, exact for t < 1024 and len <= 64 (t * (magic * len - 65536) < 65536).
+template <int QUADS>
+__device__ __forceinline__ void tile_products_shifted(
+    double * prod, const uint16_t * __restrict__ first_row, const double * __restrict__ at,
+    const double * __restrict__ xt, unsigned limit, int last, int lane, int len, int lead)
+{
+    static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
+    v2d va[QUADS], vb[QUADS];
+    const int tab = first_row[lane < len ? lane : len - 1];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last;
+        va[q] = *reinterpret_cast<const v2d *>(at + o);
+        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+    }
+    const unsigned magic = (65536u + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
+    const char * xb = reinterpret_cast<const char *>(xt);
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        // all lanes take part in the bpermute (it returns 0 from lanes that are switched off), so
+        // the columns are formed before the branch; lanes past the tile's end get a clamped one
+        unsigned c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // entries in front of the tile (they share its first quad) are multiplied and never
+            // read back, like the ones behind its end; both only need a valid column
+            const int ti = o + i - lead;
+            const unsigned t = ti > 0 ? (unsigned) ti : 0u;
+            const unsigned r = (t * magic) >> 16;
+            const unsigned pos = t - r * (unsigned) len;
+            c[i] = min((unsigned) __builtin_amdgcn_ds_bpermute((int) (pos << 2), tab) + r, limit);
+        }
+        if (o <= last) {
+            const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c[0] << 3));
+            const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c[1] << 3));
+            const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c[2] << 3));
+            const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c[3] << 3));
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+}
+
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0>
@@ -449,7 +501,10 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         const int last = (k1 - 1 - kb) & ~3;
-        if (C16 && (meta & kTileMetaNarrow))
+        if (C16 && (meta & kTileMetaShifted))
+            tile_products_shifted<QUADS>(prod, j16 + k0, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
+                                         maxlen, k0 - kb);
+        else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
         else
             tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
@@ -543,10 +598,13 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
 
 // Plan-time pass (one wave per tile): find the tile's column range; if it fits 16 bits, store
 // the offsets from the smallest column in j16 and mark the tile narrow.  `narrow_count`
-// receives the number of narrow tiles.
+// receives the number of narrow tiles.  A narrow tile of equally long rows (at most 64 entries)
+// whose rows all repeat the first row's columns, shifted by the row distance, is marked
+// "shifted" as well (counts[1]); its 16-bit offsets are still written, the kernel just does not
+// read them beyond the first row.
 __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ j16, int * __restrict__ narrow_count)
+    uint16_t * __restrict__ j16, int * __restrict__ narrow_count, int detect_shifted)
 {
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
@@ -573,10 +631,23 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         return;
     for (int k = k0 + lane; k < k1; k += kWave)
         j16[k] = (uint16_t) (j[k] - cmin);
+    const int len = d0.z & 0xFFFF;
+    int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1 && len <= kWave
+                  && k1 - (k0 & ~3) <= 1024;
+    if (shifted) {
+        int ok = 1;
+        for (int k = k0 + lane; k < k1; k += kWave) {
+            const int t = k - k0, r = t / len;
+            ok &= (j[k] == j[k0 + (t - r * len)] + r);
+        }
+        shifted = __all(ok);
+    }
     if (lane == 0) {
-        desc[w].z = d0.z | kTileMetaNarrow;
+        desc[w].z = d0.z | kTileMetaNarrow | (shifted ? kTileMetaShifted : 0);
         desc[w].w = cmin;
         atomicAdd(narrow_count, 1);
+        if (shifted)
+            atomicAdd(narrow_count + 1, 1);
     }
 }
 

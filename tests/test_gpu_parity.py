@@ -667,3 +667,39 @@ def test_large_stencil27_properties(oracle):
         want = oracle.csr_spmv(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x, num_threads=4)
         assert_close(yx[lo:hi], want, abs_products(hi - lo, ps, c[p[lo]:p[hi]], v[p[lo]:p[hi]], x), what="slice %d" % lo)
     plan.close()
+
+
+@pytest.mark.parametrize("name", ["poisson2d", "banded", "stencil27", "random", "powerlaw"])
+def test_shifted_tiles_bit_identical(name):
+    """Tiles that read only their first row's column offsets (stencil interiors, bands) must give
+    the very bits of the plan that reads every offset; detection must not fire on random columns."""
+    import torch
+    rows, cols, p, c, v = {
+        "poisson2d": lambda: synth.poisson2d(300),
+        "banded": lambda: synth.banded(40000, range(-15, 16), seed=3),
+        "stencil27": lambda: synth.stencil27_like(40, 40, 40, seed=2),
+        "random": lambda: synth.random_uniform(50000, 50000, 9, seed=1),
+        "powerlaw": lambda: synth.powerlaw(60000, 60000, seed=4),
+    }[name]()
+    x = synth.x_vector(cols, seed=5)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    ys, infos = [], []
+    for flags in (0, capi.FLAG_NO_SHIFTED_TILES, capi.FLAG_ROWS128, capi.FLAG_ROWS128 | capi.FLAG_NO_SHIFTED_TILES):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        ty = torch.from_numpy(synth.x_vector(rows, seed=6)).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ys.append(ty.cpu().numpy())
+        infos.append(plan.info())
+        plan.close()
+    assert infos[1]["shifted_tiles"] == 0 and infos[3]["shifted_tiles"] == 0
+    if name in ("poisson2d", "banded", "stencil27"):
+        assert infos[0]["shifted_tiles"] > 0.5 * infos[0]["row_blocks"], infos[0]
+        assert infos[2]["shifted_tiles"] > 0.5 * infos[2]["row_blocks"], infos[2]
+    if name == "random":
+        assert infos[0]["shifted_tiles"] == 0
+    assert np.array_equal(ys[0].view(np.uint64), ys[1].view(np.uint64))
+    assert np.array_equal(ys[2].view(np.uint64), ys[3].view(np.uint64))

@@ -72,6 +72,8 @@ def main():
         "wavetile_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP),
         "wavetile_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE),
         "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100000),  # 0x100000: sweep-local marker = compress the plan
+        "wavetile_c16_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | 0x100000),
+        "wavetile_c16_noshift_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_ROWS128 | 0x100000),
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
         "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
         "wavetile_c16_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP | 0x100000),
