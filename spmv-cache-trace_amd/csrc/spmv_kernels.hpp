@@ -381,16 +381,20 @@ __device__ __forceinline__ void tile_products_narrow(
 
 // A "shifted" tile: entry t of the tile (row t / len, position t % len) has column offset
 // first_row[t % len] + t / len, so the 2 bytes per entry of column offsets shrink to the first
-// row's `len` offsets, held one per lane and fetched with ds_bpermute.  t / len uses a 16-bit
-// reciprocal, exact for t < 1024 and len <= 64 (t * (magic * len - 65536) < 65536).
+// row's `len` offsets, parked in the wave's LDS table (len <= TILE / 2).  Holding them one per
+// lane and fetching with ds_bpermute measured the same (profiles/r01_sweep_shifted_*.log) and
+// stops at 64.  t / len uses a 22-bit reciprocal, exact while t * len < 2^22 (t < 1024,
+// len <= 512), with t * magic < 2^32.
 template <int QUADS>
 __device__ __forceinline__ void tile_products_shifted(
-    double * prod, const uint16_t * __restrict__ first_row, const double * __restrict__ at,
-    const double * __restrict__ xt, unsigned limit, int last, int lane, int len, int lead)
+    double * prod, uint16_t * tab, const uint16_t * __restrict__ first_row,
+    const double * __restrict__ at, const double * __restrict__ xt, unsigned limit, int last, int lane,
+    int len, int lead)
 {
     static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
     v2d va[QUADS], vb[QUADS];
-    const int tab = first_row[lane < len ? lane : len - 1];
+    for (int i = lane; i < len; i += kWave)
+        tab[i] = first_row[i];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         int o = 256 * q + 4 * lane;
@@ -398,25 +402,25 @@ __device__ __forceinline__ void tile_products_shifted(
         va[q] = *reinterpret_cast<const v2d *>(at + o);
         vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
     }
-    const unsigned magic = (65536u + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
     const char * xb = reinterpret_cast<const char *>(xt);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         const int o = 256 * q + 4 * lane;
-        // all lanes take part in the bpermute (it returns 0 from lanes that are switched off), so
-        // the columns are formed before the branch; lanes past the tile's end get a clamped one
-        unsigned c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // entries in front of the tile (they share its first quad) are multiplied and never
-            // read back, like the ones behind its end; both only need a valid column
-            const int ti = o + i - lead;
-            const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-            const unsigned r = (t * magic) >> 16;
-            const unsigned pos = t - r * (unsigned) len;
-            c[i] = min((unsigned) __builtin_amdgcn_ds_bpermute((int) (pos << 2), tab) + r, limit);
-        }
         if (o <= last) {
+            unsigned c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // entries in front of the tile (they share its first quad) are multiplied and never
+                // read back, like the ones behind its end; both only need a valid column
+                const int ti = o + i - lead;
+                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
+                const unsigned r = (t * magic) >> 22;
+                c[i] = min((unsigned) tab[t - r * (unsigned) len] + r, limit);
+            }
             const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c[0] << 3));
             const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c[1] << 3));
             const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c[2] << 3));
@@ -431,7 +435,7 @@ __device__ __forceinline__ void tile_products_shifted(
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0>
-__global__ __launch_bounds__(256) void csr_wavetile_kernel(
+__global__ __launch_bounds__(256, 8) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
+    __shared__ uint16_t first_row_all[C16 ? 4 : 1][C16 ? TILE / 2 : 1]; // shifted tiles with rows longer than a wave
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
         // read back
         const int last = (k1 - 1 - kb) & ~3;
         if (C16 && (meta & kTileMetaShifted))
-            tile_products_shifted<QUADS>(prod, j16 + k0, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
+            tile_products_shifted<QUADS>(prod, first_row_all[C16 ? wave : 0], j16 + k0, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
                                          maxlen, k0 - kb);
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256) void csr_wavetile_kernel(
 
 // Plan-time pass (one wave per tile): find the tile's column range; if it fits 16 bits, store
 // the offsets from the smallest column in j16 and mark the tile narrow.  `narrow_count`
-// receives the number of narrow tiles.  A narrow tile of equally long rows (at most 64 entries)
+// receives the number of narrow tiles.  A narrow tile of at least two equally long rows
 // whose rows all repeat the first row's columns, shifted by the row distance, is marked
 // "shifted" as well (counts[1]); its 16-bit offsets are still written, the kernel just does not
 // read them beyond the first row.
@@ -632,8 +637,9 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     for (int k = k0 + lane; k < k1; k += kWave)
         j16[k] = (uint16_t) (j[k] - cmin);
     const int len = d0.z & 0xFFFF;
-    int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1 && len <= kWave
-                  && k1 - (k0 & ~3) <= 1024;
+    // at least two rows, or there is nothing to save; the first row must fit the kernel's table
+    int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
+                  && 2 * len <= tile && k1 - k0 >= 2 * len && tile <= 1024;
     if (shifted) {
         int ok = 1;
         for (int k = k0 + lane; k < k1; k += kWave) {
