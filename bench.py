@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores visible to this process")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--events", choices=["launch", "region"], default="region",
+                    help="one HIP event pair around the K timed launches (default; mean launch duration = span / K, "
+                         "launch gaps included), or a pair around every launch (adds ~5 us of gap per step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each all-gather before the next multiply (default: gather k overlaps multiply k+1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -260,22 +263,34 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # with a collective in the step the compute stream also carries the snapshot copy and the wait
+    # for the previous gather, so the span is no longer K launches: time every launch there
+    per_launch = args.events == "launch" or use_dist
+    if not per_launch:
+        ev0[0].record()
     for k in range(args.steps):
-        ev0[k].record()
+        if per_launch:
+            ev0[k].record()
         op.multiply_local()
-        ev1[k].record()
+        if per_launch:
+            ev1[k].record()
         if use_dist:
             if op.overlap:
                 op.gather_async()
             else:
                 op.gather()
+    if not per_launch:
+        ev1[0].record()
     op.finish()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+    if per_launch:
+        kernel_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+    else:
+        kernel_ms = np.array([ev0[0].elapsed_time(ev1[0]) / args.steps])
 
     stats = torch.tensor([elapsed, float(kernel_ms.mean())], dtype=torch.float64, device=device)
     if use_dist:
@@ -342,7 +357,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "csr_%s" % capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
-                         "kernel_us": round(kern_s * 1e6, 2), "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2),
+                         "kernel_us": round(kern_s * 1e6, 2), "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
+                         "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
                          "algorithmic_bytes_per_launch": int(local_bytes),
                          "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)},
             "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
