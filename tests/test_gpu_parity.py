@@ -707,3 +707,80 @@ def test_shifted_tiles_bit_identical(name):
         assert infos[0]["shifted_tiles"] == 0
     assert np.array_equal(ys[0].view(np.uint64), ys[1].view(np.uint64))
     assert np.array_equal(ys[2].view(np.uint64), ys[3].view(np.uint64))
+
+
+def patchwork_matrix(seed, cols=200000):
+    """Adversarial structure for the tile classifier: blocks of rows that repeat the first row's
+    columns shifted by the row distance (any row length up to 257), the same with one entry knocked
+    out of place, equally long rows with unrelated columns, ragged and empty rows, rows longer than
+    a tile and longer than the split threshold, blocks ending at the last column."""
+    rng = np.random.default_rng(seed)
+    lens, colparts = [], []
+
+    def add_rows(cmat):  # cmat: list of 1-D int arrays, one per row
+        for r in cmat:
+            lens.append(len(r))
+            colparts.append(np.asarray(r, dtype=np.int64))
+
+    for _ in range(40):
+        kind = rng.integers(0, 7)
+        if kind <= 2:  # shifted block (kind 1: one entry perturbed, kind 2: hugging the last column)
+            ln = int(rng.choice([1, 2, 3, 5, 7, 27, 63, 64, 65, 100, 200, 255, 256, 257]))
+            nr = int(rng.integers(1, 300))
+            width = int(rng.integers(ln, 60000))
+            pat = np.sort(rng.choice(width, size=ln, replace=False))
+            c0 = cols - width - nr if kind == 2 else int(rng.integers(0, cols - width - nr))
+            block = [pat + c0 + r for r in range(nr)]
+            if kind == 1 and nr >= 2:
+                r, e = int(rng.integers(1, nr)), int(rng.integers(0, ln))
+                block[r] = block[r].copy()
+                block[r][e] = min(block[r][e] + 1 + int(rng.integers(0, 3)), cols - 1)
+            add_rows(block)
+        elif kind == 3:  # equally long rows, unrelated columns in a narrow or a wide window
+            ln, nr = int(rng.integers(1, 40)), int(rng.integers(1, 200))
+            lo = int(rng.integers(0, cols - 70000))
+            hi = lo + 60000 if rng.integers(0, 2) else cols
+            add_rows([np.sort(rng.integers(lo, hi, size=ln)) for _ in range(nr)])
+        elif kind == 4:  # ragged, with empty rows
+            add_rows([np.sort(rng.integers(0, cols, size=int(rng.integers(0, 40)))) for _ in range(int(rng.integers(1, 200)))])
+        elif kind == 5:
+            add_rows([np.zeros(0, dtype=np.int64)] * int(rng.integers(1, 150)))
+        else:  # a row longer than a tile / than the split threshold
+            add_rows([np.sort(rng.integers(0, cols, size=int(rng.choice([513, 700, 2047, 2048, 2049, 5000]))))])
+    p = np.zeros(len(lens) + 1, dtype=np.int32)
+    np.cumsum(lens, out=p[1:])
+    c = np.concatenate(colparts).astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=c.shape[0])
+    return len(lens), cols, p, c, v
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("flags", [0, capi.FLAG_ROWS128, capi.FLAG_BIG_TILE])
+def test_patchwork_structures(oracle, seed, flags):
+    import torch
+    rows, cols, p, c, v = patchwork_matrix(seed)
+    x = synth.x_vector(cols, seed=seed + 100)
+    y0 = synth.x_vector(rows, seed=seed + 200)
+    want = y0.copy()
+    want += oracle.csr_spmv(rows, p, c, v, x, num_threads=1)  # y0 + z, as the kernels form it
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    seen_shifted = 0
+    for f in (flags, flags | capi.FLAG_EXACT_ORDER, flags | capi.FLAG_NO_SHIFTED_TILES):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, f)
+        plan.compress(tc.data_ptr(), stream)
+        ty = torch.from_numpy(y0).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = ty.cpu().numpy()
+        info = plan.info()
+        plan.close()
+        if f & capi.FLAG_EXACT_ORDER:
+            assert_bitexact(got, want, "patchwork seed %d flags %x" % (seed, f))
+        else:
+            assert_close(got, want, scale, what="patchwork seed %d flags %x" % (seed, f))
+        if not (f & capi.FLAG_NO_SHIFTED_TILES):
+            seen_shifted += info["shifted_tiles"]
+    assert seen_shifted > 0
