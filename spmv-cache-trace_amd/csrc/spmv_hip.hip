@@ -490,6 +490,11 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
     return SPMV_HIP_OK;
 }
 
+/* Not part of the ABI (tools/kernel_sweep.py, tests): 0 = default choice, 1 = always the
+ * 64-entries-per-wave kernel. */
+static int g_coo_variant = 0;
+void spmv_hip_coo_variant(int variant) { g_coo_variant = variant; }
+
 int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32_t * ci,
                       const double * v, const double * x, double * y, void * stream)
 {
@@ -500,8 +505,14 @@ int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32
     if (!ri || !ci || !v || !x || !y)
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(nnz, kBlock, kCUs * 16);
-    hipLaunchKernelGGL((spmv::coo_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, nnz, ri, ci, v, x, y);
+    if (aligned16(ri) && aligned16(ci) && aligned16(v) && g_coo_variant == 0) {
+        // 16-byte loads, 256 entries per wave
+        const unsigned grid = (unsigned) (((long long) nnz + 1023) / 1024);
+        hipLaunchKernelGGL(spmv::coo_wide_kernel, dim3(grid), dim3(256), 0, s, nnz, ri, ci, v, x, y);
+    } else {
+        const int grid = grid_for(nnz, kBlock, kCUs * 16);
+        hipLaunchKernelGGL((spmv::coo_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, nnz, ri, ci, v, x, y);
+    }
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
 }

@@ -435,7 +435,7 @@ __device__ __forceinline__ void tile_products_shifted(
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0>
-__global__ __launch_bounds__(256, 8) void csr_wavetile_kernel(
+__global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
@@ -698,6 +698,93 @@ __global__ __launch_bounds__(BLOCK) void coo_kernel(
         if (valid && tail)
             unsafeAtomicAdd(y + r, s);
     }
+}
+
+// The same semantics with 256 consecutive entries per wave, four per lane (one 16-byte load of
+// each index stream and two of the values per lane).  A lane first adds its own entries run by
+// run; runs that begin and end inside the lane are complete.  Across lanes only one (row, sum)
+// pair per lane takes part in the segmented scan: the lane's last run.  A lane's first run is
+// closed by that lane (carry of the preceding lanes + its own part), its last run by the lane
+// where the row changes next.  Row-sorted input with 5 entries per row thus issues one atomic
+// instruction with ~51 active lanes per 256 entries instead of four with ~13: fp64 atomics are
+// paid per wave instruction (MI355X_MICROARCH.md, "Global float atomics").
+// Entries past nnz (last wave only) are loaded one by one and carry row -1.
+__global__ __launch_bounds__(256) void coo_wide_kernel(
+    int nnz, const int32_t * __restrict__ ri, const int32_t * __restrict__ ci,
+    const double * __restrict__ v, const double * __restrict__ x, double * __restrict__ y)
+{
+    const int lane = (int) __lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    const long long base = ((long long) blockIdx.x * 4 + wave) * 256;
+    if (base >= nnz)
+        return; // whole wave
+    const int o = 4 * lane;
+    int r[4];
+    double q[4];
+    if (base + 256 <= nnz) {
+        const v4i rr = *reinterpret_cast<const v4i *>(ri + base + o);
+        const v4i cc = *reinterpret_cast<const v4i *>(ci + base + o);
+        const v2d va = *reinterpret_cast<const v2d *>(v + base + o);
+        const v2d vb = *reinterpret_cast<const v2d *>(v + base + o + 2);
+        r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
+        q[0] = va.x * x[cc.x];
+        q[1] = va.y * x[cc.y];
+        q[2] = vb.x * x[cc.z];
+        q[3] = vb.y * x[cc.w];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long k = base + o + i;
+            const bool valid = k < nnz;
+            r[i] = valid ? ri[k] : -1;
+            q[i] = valid ? v[k] * x[ci[k]] : 0.0;
+        }
+    }
+    // runs inside the lane
+    const int r_first = r[0];
+    int r_cur = r[0];
+    double s_cur = q[0], s_first = 0.0;
+    bool multi = false;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        if (r[i] == r_cur) {
+            s_cur += q[i];
+        } else {
+            if (!multi) {
+                s_first = s_cur;
+                multi = true;
+            } else if (r_cur >= 0) {
+                unsafeAtomicAdd(y + r_cur, s_cur); // began and ended in this lane
+            }
+            r_cur = r[i];
+            s_cur = q[i];
+        }
+    }
+    // segmented inclusive scan over the lanes' last runs
+    const int r_last = r_cur;
+    const int r_prev = lane_up(r_last, 1);
+    const bool cont = lane > 0 && r_prev == r_first; // my first run continues the previous lane's last
+    int head = multi || !cont;
+    double s = s_cur;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const double sp = lane_up(s, d);
+        const int hp = lane_up(head, d);
+        if (lane >= d && !head) {
+            s += sp;
+            head |= hp;
+        }
+    }
+    const double s_prev = lane_up(s, 1);
+    const int next_cont = lane_down1((int) cont);
+    const bool tail = lane == kWave - 1 || !next_cont;
+    // one (row, sum) per lane in the common case: the end of its first run, or of its only run
+    const int r_out = multi ? r_first : (tail ? r_last : -1);
+    const double s_out = multi ? (cont ? s_prev + s_first : s_first) : s;
+    if (r_out >= 0)
+        unsafeAtomicAdd(y + r_out, s_out);
+    if (multi && tail && r_last >= 0)
+        unsafeAtomicAdd(y + r_last, s);
 }
 
 // ---------------------------------------------------------------------------------

@@ -274,6 +274,14 @@ def coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream=0):
     check(load().spmv_hip_coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream))
 
 
+def coo_variant(variant):
+    """Test / sweep hook, not part of the C ABI: 1 = always the 64-entries-per-wave COO kernel."""
+    lib = load()
+    lib.spmv_hip_coo_variant.argtypes = [C.c_int]
+    lib.spmv_hip_coo_variant.restype = None
+    lib.spmv_hip_coo_variant(variant)
+
+
 def coo_sort_by_row(rows, nnz, d_row, d_col, d_val, stream=0):
     """Stable in-place sort of device COO triplets by row index."""
     check(load().spmv_hip_coo_sort_by_row(rows, nnz, d_row, d_col, d_val, stream))

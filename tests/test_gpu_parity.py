@@ -784,3 +784,42 @@ def test_patchwork_structures(oracle, seed, flags):
         if not (f & capi.FLAG_NO_SHIFTED_TILES):
             seen_shifted += info["shifted_tiles"]
     assert seen_shifted > 0
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("order", ["row", "file-shuffled", "column"])
+def test_coo_kernels_on_device_pointers(oracle, variant, order):
+    """Both COO kernels (256 entries per wave with 16-byte loads; 64 per wave) through the level-2
+    entry, in row order, column order and shuffled, with entry counts that are no multiple of 4
+    or 256, empty rows, single-entry rows and rows far longer than a wave's share."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.coo_variant(variant)
+    try:
+        for name, gen, cut in [("poisson", lambda: synth.poisson2d(97), 3), ("powerlaw", lambda: synth.powerlaw(30000, 30000, seed=4), 1),
+                               ("banded", lambda: synth.banded(5000, range(-13, 14), seed=3), 2), ("tiny", lambda: synth.poisson2d(3), 0),
+                               ("diag", lambda: synth.banded(1000, [0], seed=1), 1)]:
+            rows, cols, p, c, v = gen()
+            i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+            n = len(a) - cut  # drop a few entries: ragged last quad / last wave
+            r, cc, vv = (i[:n] - 1).astype(np.int32), (j[:n] - 1).astype(np.int32), a[:n].copy()
+            if order == "file-shuffled":
+                perm = np.random.default_rng(7).permutation(n)
+            elif order == "column":
+                perm = np.lexsort((r, cc))
+            else:
+                perm = np.arange(n)
+            r, cc, vv = np.ascontiguousarray(r[perm]), np.ascontiguousarray(cc[perm]), np.ascontiguousarray(vv[perm])
+            x = synth.x_vector(cols, seed=11)
+            y0 = synth.x_vector(rows, seed=12)
+            want = y0 + oracle.coo_spmv(rows, r, cc, vv, x)
+            scale = np.zeros(rows)
+            np.add.at(scale, r, np.abs(vv) * np.abs(x[cc]))
+            tr, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (r, cc, vv, x))
+            ty = torch.from_numpy(y0).to(dev)
+            capi.coo_spmv(rows, n, tr.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
+    finally:
+        capi.coo_variant(0)

@@ -193,6 +193,13 @@ def main():
             others[name] = {"us_median": round(med, 2), "gbs": round(cb / med / 1e3, 1), "gflops": round(2 * nnz / med / 1e3, 1)}
             print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [bytes %.3f GB]" % (
                 name, med, cb / med / 1e3, cb / med / 1e3 / 80, 2 * nnz / med / 1e3, cb / 1e9))
+            capi.coo_variant(1)  # the 64-entries-per-wave kernel, same arrays, same process
+            med1 = time_it(lambda: capi.coo_spmv(rows, nnz, tr.data_ptr(), tcc.data_ptr(), tvv.data_ptr(),
+                                                 tx.data_ptr(), ty.data_ptr(), stream))
+            capi.coo_variant(0)
+            others[name + "_64_per_wave"] = {"us_median": round(med1, 2), "gbs": round(cb / med1 / 1e3, 1)}
+            print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  [64 entries per wave]" % (
+                name + "_64", med1, cb / med1 / 1e3, cb / med1 / 1e3 / 80))
             if name == "coo_shuffled":  # what the upload does by default: stable sort by row, once
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
