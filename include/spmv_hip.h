@@ -68,8 +68,8 @@ extern "C" {
 #define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
                                             exceeds ~768 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
-                                                kernel (default only for row_length >= 16; shorter rows run in place
-                                                as uniform wave tiles) */
+                                                kernel (default only for row_length > 256; shorter rows run in place
+                                                as uniform wave tiles, one lane per row) */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
@@ -115,7 +115,7 @@ int spmv_hip_upload_coo(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t n
                         const double *value);
 
 /* ELLPACK in the reference's ROW-MAJOR padded layout, k = i*row_length + l
- * (src/matrix/ell-matrix.cpp:253-256).  With row_length < 16 the arrays are used in place as
+ * (src/matrix/ell-matrix.cpp:253-256).  With row_length <= 256 the arrays are used in place as
  * uniform wave tiles (one lane per row, padding multiplied like real entries); longer rows are
  * transposed to column-major on the device.  Either way the sums keep the reference's order. */
 int spmv_hip_upload_ell(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t row_length,

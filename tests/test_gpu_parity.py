@@ -823,3 +823,33 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
             assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
     finally:
         capi.coo_variant(0)
+
+
+@pytest.mark.parametrize("L", [1, 16, 27, 255, 256, 257, 300, 600])
+def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
+    """ELLPACK rows up to half a tile run in place as wave tiles, longer ones through the
+    column-major kernel; both keep the reference's order (bit-exact), padding included."""
+    rng = np.random.default_rng(L)
+    rows, cols = 3000, 5000
+    lens = rng.integers(0, L + 1, size=rows)
+    lens[0] = max(1, lens[0])  # the reference cannot pad an empty first row
+    lens[rng.integers(1, rows)] = L
+    i = np.repeat(np.arange(1, rows + 1), lens).astype(np.int32)
+    j = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) + 1 for n in lens]).astype(np.int32)
+    a = rng.uniform(-1, 1, size=len(i))
+    rc, Lr, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+    assert rc == 0 and Lr == L
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2)
+    for flags in (0, capi.FLAG_ELL_COLUMN_MAJOR):
+        c2 = capi.Context(0, flags=flags)
+        try:
+            c2.upload_ell(rows, cols, L, ec, ev)
+            c2.set_x(x)
+            c2.set_y(y0)
+            c2.run()
+            c2.run()
+            assert_bitexact(c2.get_y(), want, "ell L=%d flags %x" % (L, flags))
+        finally:
+            c2.close()

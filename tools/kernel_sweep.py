@@ -230,13 +230,14 @@ def main():
                              "gflops": round(2 * nnz / med / 1e3, 1)}
             print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [L=%d, bytes %.3f GB]" % (
                 "ell", med, eb / med / 1e3, eb / med / 1e3 / 80, 2 * nnz / med / 1e3, L, eb / 1e9))
-            if L < 16:  # what the ctx does for short rows: the row-major arrays in place, as uniform wave tiles
+            if L <= 256:  # what the ctx does for these rows: the row-major arrays in place, as uniform wave tiles
                 del tec, tev
                 ter = torch.from_numpy(np.ascontiguousarray(ec)).to(dev)
                 tvr = torch.from_numpy(np.ascontiguousarray(ev)).to(dev)
                 pe = (np.arange(rows + 1, dtype=np.int64) * L).astype(np.int32)
                 tpe = torch.from_numpy(pe).to(dev)
-                plan_e = capi.CsrPlan(rows, cols, pe, capi.CSR_WAVETILE)
+                # one lane per row (the reference's order) whatever the row length
+                plan_e = capi.CsrPlan(rows, cols, pe, capi.CSR_WAVETILE, 0, capi.FLAG_EXACT_ORDER)
                 plan_e.compress(ter.data_ptr(), stream)
                 med = time_it(lambda: plan_e.spmv(tpe.data_ptr(), ter.data_ptr(), tvr.data_ptr(), tx.data_ptr(),
                                                   ty.data_ptr(), stream))
