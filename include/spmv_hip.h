@@ -73,6 +73,9 @@ extern "C" {
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
+#define SPMV_HIP_FLAG_NO_X_WINDOW 0x800u /* wavetile: never stage x through LDS.  Default after plan_csr_compress: when most
+                                            tiles' columns span < 256 (narrow bands) each tile reads its window of x once,
+                                            coalesced, into LDS instead of gathering it */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -175,7 +178,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device
  *        [8] tiles with 16-bit column offsets (after spmv_hip_plan_csr_compress)
  *        [9] uniform tiles (all rows equally long: row_ptr not read)
- *        [10] shifted tiles (column offsets read for the first row only) */
+ *        [10] shifted tiles (column offsets read for the first row only)
+ *        [11] tiles whose column range fits a 256-entry window of x (x staged through LDS when most tiles qualify) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

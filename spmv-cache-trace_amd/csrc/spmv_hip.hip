@@ -86,6 +86,7 @@ struct spmv_hip_plan {
     const int32_t * compressed_from = nullptr; // the column array d_col16 was derived from
     int narrow_tiles = 0;
     int shifted_tiles = 0;
+    int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     size_t meta_bytes = 0;
 };
@@ -385,7 +386,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
     int * d_count = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
-    int counts[2] = {0, 0};
+    int counts[3] = {0, 0, 0};
     hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
@@ -399,6 +400,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     pl->narrow_tiles = counts[0];
     pl->shifted_tiles = counts[1];
+    pl->xwin_tiles = counts[2];
     if (d_count)
         (void) hipFree(d_count);
     if (e != hipSuccess) {
@@ -415,10 +417,10 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[11] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[12] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
-                           pl->uniform_tiles, pl->shifted_tiles};
-    for (int i = 0; i < n && i < 11; ++i)
+                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles};
+    for (int i = 0; i < n && i < 12; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -464,7 +466,14 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
-            if (abl && c16 && x32 && pl->tile == 512) {
+            // x staged through LDS when most tiles' columns fit the window (narrow bands); with one lane
+            // per row (EXACT_ORDER, the in-place ELLPACK path) the long row sums want the occupancy more
+            // than the gather wants the window (L = 81: 347 vs 338 us), so not there
+            if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && !exact && c16 && x32 && pl->tile == 512 && !xcd
+                && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
+                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
+                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+            } else if (abl && c16 && x32 && pl->tile == 512) {
                 if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
                 else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
                 else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);

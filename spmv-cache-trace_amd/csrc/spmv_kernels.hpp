@@ -269,6 +269,10 @@ constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `
 // narrow + uniform + every row has the columns of the tile's first row shifted by its distance
 // from it (the interior of a stencil, a band matrix): only the first row's offsets are read
 constexpr int kTileMetaShifted = 1 << 27;
+// narrow, and the tile's whole column range fits the x window of the XW kernel variant:
+// bits 29-30 hold the number of 64-entry chunks of x to stage, minus one
+constexpr int kTileMetaXWin = 1 << 28;
+constexpr int kTileMetaXChunksShift = 29;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -432,10 +436,82 @@ __device__ __forceinline__ void tile_products_shifted(
     }
 }
 
+// x staged through LDS (kernel variant XW > 0, tiles marked kTileMetaXWin): the tile's column
+// range [base, base + 64 * chunks) is read once with coalesced loads into the wave's window and the
+// products take x from there (ds_read_b64) instead of gathering it through the vector L1.  All
+// global loads -- window, column offsets or first row, values -- are issued before the first wait.
+template <int QUADS, int XW>
+__device__ __forceinline__ void tile_products_xwin(
+    double * prod, double * xw, uint16_t * tab, const uint16_t * __restrict__ jt,
+    const uint16_t * __restrict__ first_row, const double * __restrict__ at,
+    const double * __restrict__ xt, unsigned limit, int last, int lane, int chunks, bool shifted,
+    int len, int lead)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
+    double xs[XW / 64];
+#pragma unroll
+    for (int ch = 0; ch < XW / 64; ++ch)
+        if (ch < chunks)
+            xs[ch] = xt[min((unsigned) (64 * ch + lane), limit)];
+    v2u c[QUADS];
+    v2d va[QUADS], vb[QUADS];
+    if (shifted) {
+        for (int i = lane; i < len; i += kWave)
+            tab[i] = first_row[i];
+    }
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last;
+        if (!shifted)
+            c[q] = *reinterpret_cast<const v2u *>(jt + o);
+        va[q] = *reinterpret_cast<const v2d *>(at + o);
+        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+    }
+#pragma unroll
+    for (int ch = 0; ch < XW / 64; ++ch)
+        if (ch < chunks)
+            xw[64 * ch + lane] = xs[ch];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len;
+    const unsigned wlimit = (unsigned) (64 * chunks - 1); // garbage entries of shared quads stay inside the window
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
+            unsigned cc[4];
+            if (shifted) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ti = o + i - lead;
+                    const unsigned t = ti > 0 ? (unsigned) ti : 0u;
+                    const unsigned r = (t * magic) >> 22;
+                    cc[i] = min((unsigned) tab[t - r * (unsigned) len] + r, wlimit);
+                }
+            } else {
+                cc[0] = min(c[q].x & 0xFFFFu, wlimit);
+                cc[1] = min(c[q].x >> 16, wlimit);
+                cc[2] = min(c[q].y & 0xFFFFu, wlimit);
+                cc[3] = min(c[q].y >> 16, wlimit);
+            }
+            const double q0 = va[q].x * xw[cc[0]];
+            const double q1 = va[q].y * xw[cc[1]];
+            const double q2 = vb[q].x * xw[cc[2]];
+            const double q3 = vb[q].y * xw[cc[3]];
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+}
+
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0>
-__global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kernel(
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0>
+__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
@@ -443,7 +519,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
-    __shared__ uint16_t first_row_all[C16 ? 4 : 1][C16 ? TILE / 2 : 1]; // shifted tiles with rows longer than a wave
+    __shared__ uint16_t first_row_all[C16 ? 4 : 1][C16 ? TILE / 2 : 1]; // shifted tiles: the first row's offsets
+    __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
@@ -506,7 +583,12 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         const int last = (k1 - 1 - kb) & ~3;
-        if (C16 && (meta & kTileMetaShifted))
+        if (XW > 0 && C16 && (meta & kTileMetaXWin))
+            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j16 + k0,
+                                      a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
+                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
+                                      maxlen > 0 ? maxlen : 1, k0 - kb);
+        else if (C16 && (meta & kTileMetaShifted))
             tile_products_shifted<QUADS>(prod, first_row_all[C16 ? wave : 0], j16 + k0, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
                                          maxlen, k0 - kb);
         else if (C16 && (meta & kTileMetaNarrow))
@@ -648,12 +730,17 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         }
         shifted = __all(ok);
     }
+    int xwin = 0;
+    if (cmax - cmin < 256)
+        xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
     if (lane == 0) {
-        desc[w].z = d0.z | kTileMetaNarrow | (shifted ? kTileMetaShifted : 0);
+        desc[w].z = d0.z | kTileMetaNarrow | (shifted ? kTileMetaShifted : 0) | xwin;
         desc[w].w = cmin;
         atomicAdd(narrow_count, 1);
         if (shifted)
             atomicAdd(narrow_count + 1, 1);
+        if (xwin)
+            atomicAdd(narrow_count + 2, 1);
     }
 }
 

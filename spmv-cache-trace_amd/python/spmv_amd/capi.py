@@ -18,6 +18,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALI
 CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
 FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER, FLAG_READ_ROW_PTR, FLAG_ROWS64, FLAG_ROWS128, FLAG_ELL_COLUMN_MAJOR = 0x1, 0x2, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 FLAG_NO_SHIFTED_TILES = 0x400
+FLAG_NO_X_WINDOW = 0x800
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -255,10 +256,10 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(11, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 11))
+        out = np.zeros(12, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 12))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles"]
+                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

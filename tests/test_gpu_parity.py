@@ -853,3 +853,47 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             assert_bitexact(c2.get_y(), want, "ell L=%d flags %x" % (L, flags))
         finally:
             c2.close()
+
+
+@pytest.mark.parametrize("name", ["band31", "band81", "band200", "tridiagonal", "poisson2d", "ragged_band"])
+def test_x_window_variant_bit_identical(name):
+    """Staging x through LDS (the default when most tiles' columns span < 256) changes where x is
+    read from, not a bit of y; SPMV_HIP_FLAG_NO_X_WINDOW keeps the gather."""
+    import torch
+    if name == "ragged_band":
+        rng = np.random.default_rng(5)
+        rows = cols = 30000
+        lens = rng.integers(0, 40, size=rows)
+        p = np.zeros(rows + 1, dtype=np.int32)
+        np.cumsum(lens, out=p[1:])
+        c = np.concatenate([np.sort(rng.choice(np.arange(max(0, r - 60), min(cols, r + 60)), size=n, replace=False))
+                            for r, n in enumerate(lens)]).astype(np.int32)
+        v = rng.uniform(-1, 1, size=len(c))
+    else:
+        rows, cols, p, c, v = {
+            "band31": lambda: synth.banded(40000, range(-15, 16), seed=3),
+            "band81": lambda: synth.banded(20000, range(-40, 41), seed=3),
+            "band200": lambda: synth.banded(9000, range(-100, 100), seed=3),
+            "tridiagonal": lambda: synth.banded(100000, [-1, 0, 1], seed=2),
+            "poisson2d": lambda: synth.poisson2d(300),
+        }[name]()
+    x = synth.x_vector(cols, seed=5)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    ys, infos = [], []
+    for flags in (capi.FLAG_NO_X_WINDOW, 0, capi.FLAG_NO_SHIFTED_TILES, capi.FLAG_ROWS128):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        ty = torch.from_numpy(synth.x_vector(rows, seed=6)).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ys.append(ty.cpu().numpy())
+        infos.append(plan.info())
+        plan.close()
+    if name == "poisson2d":
+        assert infos[1]["xwin_tiles"] < 0.1 * infos[1]["row_blocks"]  # columns span two grid lines
+    else:
+        assert infos[1]["xwin_tiles"] > 0.9 * infos[1]["row_blocks"], infos[1]
+    for k in (1, 2, 3):
+        assert np.array_equal(ys[0].view(np.uint64), ys[k].view(np.uint64)), k

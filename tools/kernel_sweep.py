@@ -74,6 +74,8 @@ def main():
         "wavetile_c16": (capi.CSR_WAVETILE, 0, 0x100000),  # 0x100000: sweep-local marker = compress the plan
         "wavetile_c16_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_noshift_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_ROWS128 | 0x100000),
+        "wavetile_c16_noxwin": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | 0x100000),
+        "wavetile_c16_noxwin_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
         "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
         "wavetile_c16_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP | 0x100000),
@@ -244,6 +246,14 @@ def main():
                 others["ell_as_tiles"] = {"us_median": round(med, 2), "gbs": round(eb / med / 1e3, 1)}
                 print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  %7.1f GFLOP/s  [row-major in place]" % (
                     "ell_as_tiles", med, eb / med / 1e3, eb / med / 1e3 / 80, 2 * nnz / med / 1e3))
+                plan_n = capi.CsrPlan(rows, cols, pe, capi.CSR_WAVETILE, 0, capi.FLAG_EXACT_ORDER | capi.FLAG_NO_X_WINDOW)
+                plan_n.compress(ter.data_ptr(), stream)
+                if plan_n.info()["xwin_tiles"] * 2 > plan_n.info()["row_blocks"]:
+                    med = time_it(lambda: plan_n.spmv(tpe.data_ptr(), ter.data_ptr(), tvr.data_ptr(), tx.data_ptr(),
+                                                      ty.data_ptr(), stream))
+                    others["ell_as_tiles_no_x_window"] = {"us_median": round(med, 2), "gbs": round(eb / med / 1e3, 1)}
+                    print("%-16s median %9.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)  [row-major in place, x gathered]" % (
+                        "ell_tiles_noxw", med, eb / med / 1e3, eb / med / 1e3 / 80))
         else:
             print("ell: skipped (rows*row_length = %d x %d too large)" % (rows, L))
     res["other_formats"] = others
