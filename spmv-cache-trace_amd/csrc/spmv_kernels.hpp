@@ -273,6 +273,10 @@ constexpr int kTileMetaShifted = 1 << 27;
 // bits 29-30 hold the number of 64-entry chunks of x to stage, minus one
 constexpr int kTileMetaXWin = 1 << 28;
 constexpr int kTileMetaXChunksShift = 29;
+// shifted tile whose x entries -- `len` runs of `rows` consecutive entries, runs that touch or
+// overlap merged -- fit the window: the plan keeps, in the tile's unused 16-bit column slots,
+// the window position of every first-row column and the x offset of every window slot
+constexpr int kTileMetaXSeg = (int) 0x80000000u;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -508,6 +512,74 @@ __device__ __forceinline__ void tile_products_xwin(
     }
 }
 
+// x window of a shifted tile whose columns are too far apart for one contiguous window (any
+// stencil in 2 or 3 dimensions): entry (row r, position pos) reads x[base + first_row[pos] + r],
+// i.e. the tile needs `len` runs of `rows` consecutive x entries; runs that touch or overlap are
+// merged by the plan, which stores where each position's run starts in the window (xoff, after
+// the first row in the tile's 16-bit slots) and which x entry each window slot holds (src, after
+// xoff).  Round trip 1: xoff, src, values; round trip 2: the window, one load per 64 slots
+// (27-point stencil: 180 slots in 9 runs instead of 486 gathered entries touching ~50 lines per
+// instruction); then the products read x from LDS.
+template <int QUADS, int XW>
+__device__ __forceinline__ void tile_products_xseg(
+    double * prod, double * xw, uint16_t * tab, const uint16_t * __restrict__ xoff,
+    const double * __restrict__ at, const double * __restrict__ xt, unsigned limit, int last, int lane,
+    int chunks, int len, int lead)
+{
+    static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
+    const uint16_t * __restrict__ src = xoff + len;
+    unsigned so[XW / 64];
+#pragma unroll
+    for (int ch = 0; ch < XW / 64; ++ch)
+        if (ch < chunks)
+            so[ch] = src[64 * ch + lane];
+    const unsigned xo = xoff[lane < len ? lane : len - 1]; // len <= 64 for these tiles
+    v2d va[QUADS], vb[QUADS];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last;
+        va[q] = *reinterpret_cast<const v2d *>(at + o);
+        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+    }
+    double xs[XW / 64];
+#pragma unroll
+    for (int ch = 0; ch < XW / 64; ++ch)
+        if (ch < chunks)
+            xs[ch] = xt[min(so[ch], limit)];
+    tab[lane] = (uint16_t) xo;
+#pragma unroll
+    for (int ch = 0; ch < XW / 64; ++ch)
+        if (ch < chunks)
+            xw[64 * ch + lane] = xs[ch];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len;
+    const unsigned wlimit = (unsigned) (64 * chunks - 1);
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
+            unsigned cc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ti = o + i - lead;
+                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
+                const unsigned r = (t * magic) >> 22;
+                cc[i] = min((unsigned) tab[t - r * (unsigned) len] + r, wlimit);
+            }
+            const double q0 = va[q].x * xw[cc[0]];
+            const double q1 = va[q].y * xw[cc[1]];
+            const double q2 = vb[q].x * xw[cc[2]];
+            const double q3 = vb[q].y * xw[cc[3]];
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+}
+
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0>
@@ -583,7 +655,11 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         const int last = (k1 - 1 - kb) & ~3;
-        if (XW > 0 && C16 && (meta & kTileMetaXWin))
+        if (XW > 0 && C16 && (meta & kTileMetaXSeg))
+            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + k0 + maxlen,
+                                      a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
+                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
+        else if (XW > 0 && C16 && (meta & kTileMetaXWin))
             tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j16 + k0,
                                       a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
@@ -730,9 +806,44 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         }
         shifted = __all(ok);
     }
+    // A window pays when each of its slots is used at least twice (measured: 81/row band 5.6 uses
+    // per slot 284 -> 257 us, 27-point stencil 2.7 uses 216 -> 199 us, 5-point stencil 1.65 uses
+    // 44.9 -> 51.3 us on a cache-resident 2048^2 grid); it costs LDS, hence occupancy.
     int xwin = 0;
-    if (cmax - cmin < 256)
-        xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
+    if (cmax - cmin < 256) {
+        if (k1 - k0 >= 2 * (cmax - cmin + 1))
+            xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
+    } else if (shifted && len <= kWave) {
+        // x window by runs (kTileMetaXSeg): lane = position in the row
+        const int nrows = (k1 - k0) / len;
+        const int col = lane < len ? j[k0 + lane] - cmin : 0;
+        const int d = col - __shfl_up(col, 1);
+        const int fresh = lane == 0 || d < 0 || d > nrows;       // this position starts a new run
+        int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
+#pragma unroll
+        for (int s = 1; s < kWave; s <<= 1) {
+            const int up = __shfl_up(xo, s);
+            if (lane >= s)
+                xo += up;
+        }
+        const int total = __shfl(xo, len - 1) + nrows;
+        if (total <= 256 && 2 * total <= k1 - k0 && 2 * len + 64 * ((total + 63) / 64) <= k1 - k0) {
+            __threadfence(); // the offsets written above land before these slots are reused
+            const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
+            uint16_t * xoff = j16 + k0 + len;
+            uint16_t * src = xoff + len;
+            const int slots = 64 * ((total + 63) / 64);
+            for (int i = total + lane; i < slots; i += kWave)
+                src[i] = 0; // padding of the last chunk: any valid x entry
+            if (lane < len) {
+                xoff[lane] = (uint16_t) xo;
+                const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
+                for (int i = 0; i < cnt; ++i)
+                    src[xo + i] = (uint16_t) (col + i);
+            }
+            xwin = kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift);
+        }
+    }
     if (lane == 0) {
         desc[w].z = d0.z | kTileMetaNarrow | (shifted ? kTileMetaShifted : 0) | xwin;
         desc[w].w = cmin;

@@ -855,7 +855,7 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.close()
 
 
-@pytest.mark.parametrize("name", ["band31", "band81", "band200", "tridiagonal", "poisson2d", "ragged_band"])
+@pytest.mark.parametrize("name", ["band31", "band81", "band200", "tridiagonal", "poisson2d", "ragged_band", "stencil27", "stencil7"])
 def test_x_window_variant_bit_identical(name):
     """Staging x through LDS (the default when most tiles' columns span < 256) changes where x is
     read from, not a bit of y; SPMV_HIP_FLAG_NO_X_WINDOW keeps the gather."""
@@ -876,6 +876,9 @@ def test_x_window_variant_bit_identical(name):
             "band200": lambda: synth.banded(9000, range(-100, 100), seed=3),
             "tridiagonal": lambda: synth.banded(100000, [-1, 0, 1], seed=2),
             "poisson2d": lambda: synth.poisson2d(300),
+            # stencils in three dimensions: the window is a handful of merged runs, not one range
+            "stencil27": lambda: synth.stencil27_like(40, 40, 40, seed=2),
+            "stencil7": lambda: synth.banded(64000, [-1600, -40, -3, -2, -1, 0, 1, 2, 3, 40, 1600], seed=4),
         }[name]()
     x = synth.x_vector(cols, seed=5)
     dev = torch.device("cuda:0")
@@ -891,9 +894,38 @@ def test_x_window_variant_bit_identical(name):
         ys.append(ty.cpu().numpy())
         infos.append(plan.info())
         plan.close()
-    if name == "poisson2d":
-        assert infos[1]["xwin_tiles"] < 0.1 * infos[1]["row_blocks"]  # columns span two grid lines
+    if name in ("poisson2d", "band200"):
+        # too few uses per window slot: 5-point rows reach two grid lines away, 200/row leaves two rows per tile
+        assert infos[1]["xwin_tiles"] < 0.1 * infos[1]["row_blocks"]
     else:
         assert infos[1]["xwin_tiles"] > 0.9 * infos[1]["row_blocks"], infos[1]
     for k in (1, 2, 3):
         assert np.array_equal(ys[0].view(np.uint64), ys[k].view(np.uint64)), k
+
+
+def test_x_window_kernel_with_minority_of_other_tiles(oracle):
+    """The x-window kernel variant is chosen per matrix; tiles that do not qualify (wide or ragged
+    columns, long rows, empty rows) must run through it unchanged."""
+    import torch
+    r1, cols, p1, c1, v1 = synth.banded(200000, range(-15, 16), seed=3)
+    r2, _, p2, c2, v2 = patchwork_matrix(3, cols=cols)
+    rows = r1 + r2
+    p = np.concatenate([p1, p1[-1] + p2[1:]]).astype(np.int32)
+    c = np.concatenate([c1, c2])
+    v = np.concatenate([v1, v2])
+    x = synth.x_vector(cols, seed=8)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    scale = abs_products(rows, p, c, v, x)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    for flags in (0, capi.FLAG_NO_X_WINDOW):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        info = plan.info()
+        assert 0.5 * info["row_blocks"] < info["xwin_tiles"] < info["row_blocks"]
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_close(ty.cpu().numpy(), want, scale, what="mixed flags %x" % flags)
+        plan.close()

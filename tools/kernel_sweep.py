@@ -83,6 +83,9 @@ def main():
         "wavetile_c16_rows64": (capi.CSR_WAVETILE, 0, capi.FLAG_ROWS64 | 0x100000),
         "wavetile_c16_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_ROWS128 | 0x100000),
         # timing experiments (wrong results by design): where the time of a tile goes
+        "abl_noshift_no_gather": (capi.CSR_WAVETILE, 0, 0x10000 | 0x100000 | capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_NO_X_WINDOW),
+        "abl_noshift_no_rowsum": (capi.CSR_WAVETILE, 0, 0x20000 | 0x100000 | capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_NO_X_WINDOW),
+        "abl_noshift_neither": (capi.CSR_WAVETILE, 0, 0x30000 | 0x100000 | capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_NO_X_WINDOW),
         "abl_no_gather": (capi.CSR_WAVETILE, 0, 0x10000 | 0x100000),
         "abl_no_rowsum": (capi.CSR_WAVETILE, 0, 0x20000 | 0x100000),
         "abl_neither": (capi.CSR_WAVETILE, 0, 0x30000 | 0x100000),
