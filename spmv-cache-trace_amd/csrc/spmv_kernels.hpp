@@ -387,22 +387,25 @@ __device__ __forceinline__ void tile_products_narrow(
     }
 }
 
-// A "shifted" tile: entry t of the tile (row t / len, position t % len) has column offset
-// first_row[t % len] + t / len, so the 2 bytes per entry of column offsets shrink to the first
-// row's `len` offsets, parked in the wave's LDS table (len <= TILE / 2).  Holding them one per
-// lane and fetching with ds_bpermute measured the same (profiles/r01_sweep_shifted_*.log) and
-// stops at 64.  t / len uses a 22-bit reciprocal, exact while t * len < 2^22 (t < 1024,
-// len <= 512), with t * magic < 2^32.
-template <int QUADS>
+// A "shifted" tile: entry t of the tile (row t / len, position t % len) has column
+// first_row[t % len] + t / len, so the column stream shrinks to the first row's `len` columns,
+// read from the original 32-bit array (the tile's columns may span any range: a 253^3 grid's
+// 27-point rows reach 128 K columns) and parked in the wave's LDS table (len <= 128).  Holding
+// them one per lane and fetching with ds_bpermute measured the same
+// (profiles/r01_sweep_shifted_*.log) and stops at 64.  t / len uses a 22-bit reciprocal, exact
+// while t * len < 2^22 (t < 1024, len <= 512), with t * magic < 2^32.
+constexpr int kShiftedMaxLen = 128;
+
+template <int QUADS, bool X32>
 __device__ __forceinline__ void tile_products_shifted(
-    double * prod, uint16_t * tab, const uint16_t * __restrict__ first_row,
-    const double * __restrict__ at, const double * __restrict__ xt, unsigned limit, int last, int lane,
+    double * prod, uint32_t * tab, const int32_t * __restrict__ first_row,
+    const double * __restrict__ at, const double * __restrict__ x, unsigned limit, int last, int lane,
     int len, int lead)
 {
     static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
     v2d va[QUADS], vb[QUADS];
     for (int i = lane; i < len; i += kWave)
-        tab[i] = first_row[i];
+        tab[i] = (uint32_t) first_row[i];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         int o = 256 * q + 4 * lane;
@@ -414,7 +417,6 @@ __device__ __forceinline__ void tile_products_shifted(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
-    const char * xb = reinterpret_cast<const char *>(xt);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         const int o = 256 * q + 4 * lane;
@@ -427,12 +429,12 @@ __device__ __forceinline__ void tile_products_shifted(
                 const int ti = o + i - lead;
                 const unsigned t = ti > 0 ? (unsigned) ti : 0u;
                 const unsigned r = (t * magic) >> 22;
-                c[i] = min((unsigned) tab[t - r * (unsigned) len] + r, limit);
+                c[i] = min(tab[t - r * (unsigned) len] + r, limit);
             }
-            const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c[0] << 3));
-            const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c[1] << 3));
-            const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c[2] << 3));
-            const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c[3] << 3));
+            const double q0 = va[q].x * gather_x<X32>(x, (int) c[0]);
+            const double q1 = va[q].y * gather_x<X32>(x, (int) c[1]);
+            const double q2 = vb[q].x * gather_x<X32>(x, (int) c[2]);
+            const double q3 = vb[q].y * gather_x<X32>(x, (int) c[3]);
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
             dst[0] = v2d{q0, q1};
             dst[1] = v2d{q2, q3};
@@ -446,9 +448,9 @@ __device__ __forceinline__ void tile_products_shifted(
 // global loads -- window, column offsets or first row, values -- are issued before the first wait.
 template <int QUADS, int XW>
 __device__ __forceinline__ void tile_products_xwin(
-    double * prod, double * xw, uint16_t * tab, const uint16_t * __restrict__ jt,
-    const uint16_t * __restrict__ first_row, const double * __restrict__ at,
-    const double * __restrict__ xt, unsigned limit, int last, int lane, int chunks, bool shifted,
+    double * prod, double * xw, uint32_t * tab, const uint16_t * __restrict__ jt,
+    const int32_t * __restrict__ first_row, const double * __restrict__ at,
+    const double * __restrict__ xt, int cbase, unsigned limit, int last, int lane, int chunks, bool shifted,
     int len, int lead)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -462,7 +464,7 @@ __device__ __forceinline__ void tile_products_xwin(
     v2d va[QUADS], vb[QUADS];
     if (shifted) {
         for (int i = lane; i < len; i += kWave)
-            tab[i] = first_row[i];
+            tab[i] = (uint32_t) (first_row[i] - cbase);
     }
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -493,7 +495,7 @@ __device__ __forceinline__ void tile_products_xwin(
                     const int ti = o + i - lead;
                     const unsigned t = ti > 0 ? (unsigned) ti : 0u;
                     const unsigned r = (t * magic) >> 22;
-                    cc[i] = min((unsigned) tab[t - r * (unsigned) len] + r, wlimit);
+                    cc[i] = min(tab[t - r * (unsigned) len] + r, wlimit);
                 }
             } else {
                 cc[0] = min(c[q].x & 0xFFFFu, wlimit);
@@ -513,21 +515,22 @@ __device__ __forceinline__ void tile_products_xwin(
 }
 
 // x window of a shifted tile whose columns are too far apart for one contiguous window (any
-// stencil in 2 or 3 dimensions): entry (row r, position pos) reads x[base + first_row[pos] + r],
-// i.e. the tile needs `len` runs of `rows` consecutive x entries; runs that touch or overlap are
-// merged by the plan, which stores where each position's run starts in the window (xoff, after
-// the first row in the tile's 16-bit slots) and which x entry each window slot holds (src, after
-// xoff).  Round trip 1: xoff, src, values; round trip 2: the window, one load per 64 slots
-// (27-point stencil: 180 slots in 9 runs instead of 486 gathered entries touching ~50 lines per
-// instruction); then the products read x from LDS.
+// stencil in 2 or 3 dimensions): entry (row r, position pos) reads x[first_row[pos] + r], i.e. the
+// tile needs `len` runs of `rows` consecutive x entries; runs that touch or overlap are merged by
+// the plan, which stores -- in the tile's slots of the 16-bit column stream, which a shifted tile
+// does not read -- where each position's run starts in the window (xoff, 16 bits) and which x
+// entry each window slot holds (src, 32 bits: the columns may be far apart; a per-slot "owning
+// position" from which the kernel derives src needs less room but measured 224 vs 203 us).
+// Round trip 1: xoff, src, values; round trip 2:
+// the window, one load per 64 slots (27-point stencil: 180 slots in 9 runs instead of 486 gathered
+// entries touching ~50 lines per instruction); then the products read x from LDS.
 template <int QUADS, int XW>
 __device__ __forceinline__ void tile_products_xseg(
     double * prod, double * xw, uint16_t * tab, const uint16_t * __restrict__ xoff,
-    const double * __restrict__ at, const double * __restrict__ xt, unsigned limit, int last, int lane,
-    int chunks, int len, int lead)
+    const uint32_t * __restrict__ src, const double * __restrict__ at, const double * __restrict__ x,
+    unsigned limit, int last, int lane, int chunks, int len, int lead)
 {
     static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
-    const uint16_t * __restrict__ src = xoff + len;
     unsigned so[XW / 64];
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
@@ -546,7 +549,7 @@ __device__ __forceinline__ void tile_products_xseg(
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
         if (ch < chunks)
-            xs[ch] = xt[min(so[ch], limit)];
+            xs[ch] = x[min(so[ch], limit)];
     tab[lane] = (uint16_t) xo;
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
-    __shared__ uint16_t first_row_all[C16 ? 4 : 1][C16 ? TILE / 2 : 1]; // shifted tiles: the first row's offsets
+    __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -655,18 +658,22 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         const int last = (k1 - 1 - kb) & ~3;
-        if (XW > 0 && C16 && (meta & kTileMetaXSeg))
-            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + k0 + maxlen,
-                                      a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
-                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
-        else if (XW > 0 && C16 && (meta & kTileMetaXWin))
-            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j16 + k0,
-                                      a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
+        if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
+            const int len = maxlen > 0 ? maxlen : 1;
+            const uint16_t * xoff = j16 + k0 + len;
+            const uint32_t * src = reinterpret_cast<const uint32_t *>(j16 + ((k0 + 2 * len + 1) & ~1));
+            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0],
+                                      reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]), xoff, src,
+                                      a + kb, x, (unsigned) (cols - 1), last, lane,
+                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, len, k0 - kb);
+        } else if (XW > 0 && C16 && (meta & kTileMetaXWin))
+            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j + k0,
+                                      a + kb, x + cbase, cbase, (unsigned) (cols - 1 - cbase), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
                                       maxlen > 0 ? maxlen : 1, k0 - kb);
         else if (C16 && (meta & kTileMetaShifted))
-            tile_products_shifted<QUADS>(prod, first_row_all[C16 ? wave : 0], j16 + k0, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane,
-                                         maxlen, k0 - kb);
+            tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0], j + k0, a + kb, x, (unsigned) (cols - 1), last, lane,
+                                              maxlen, k0 - kb);
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
         else
@@ -759,15 +766,22 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     }
 }
 
-// Plan-time pass (one wave per tile): find the tile's column range; if it fits 16 bits, store
-// the offsets from the smallest column in j16 and mark the tile narrow.  `narrow_count`
-// receives the number of narrow tiles.  A narrow tile of at least two equally long rows
-// whose rows all repeat the first row's columns, shifted by the row distance, is marked
-// "shifted" as well (counts[1]); its 16-bit offsets are still written, the kernel just does not
-// read them beyond the first row.
+// Plan-time pass (one wave per tile) that classifies the stream tiles and writes the second index
+// stream; counts[0..2] receive the number of narrow / shifted / windowed tiles.
+//  narrow:  the columns span < 65536: their offsets from the smallest one go to j16 (10 instead of
+//           12 bytes per entry), desc.w = that column;
+//  shifted: at least two equally long rows (<= kShiftedMaxLen entries) that all repeat the first
+//           row's columns moved right by the row distance -- whatever range they span: the kernel
+//           reads the first row's 32-bit columns and no others (8 bytes per entry);
+//  window:  x staged through LDS by the XW kernel variant, for a narrow tile whose columns span
+//           < 256 (kTileMetaXWin) or a shifted tile whose merged runs of x fit 256 slots
+//           (kTileMetaXSeg; the run tables go to the tile's j16 slots, which a shifted tile does not
+//           read), in both cases only if every slot is used at least twice (measured: 81/row band
+//           5.6 uses per slot 284 -> 257 us, 27-point stencil 2.7 uses 216 -> 199 us, 5-point
+//           stencil 1.65 uses 44.9 -> 51.3 us on a cache-resident 2048^2 grid).
 __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ j16, int * __restrict__ narrow_count, int detect_shifted)
+    uint16_t * __restrict__ j16, int * __restrict__ counts, int detect_shifted)
 {
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
@@ -790,14 +804,15 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         cmin = omin < cmin ? omin : cmin;
         cmax = omax > cmax ? omax : cmax;
     }
-    if (cmin < 0 || cmax - cmin >= 65536)
+    if (cmin < 0)
         return;
-    for (int k = k0 + lane; k < k1; k += kWave)
-        j16[k] = (uint16_t) (j[k] - cmin);
+    const bool narrow = cmax - cmin < 65536;
+    if (narrow)
+        for (int k = k0 + lane; k < k1; k += kWave)
+            j16[k] = (uint16_t) (j[k] - cmin);
     const int len = d0.z & 0xFFFF;
-    // at least two rows, or there is nothing to save; the first row must fit the kernel's table
     int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
-                  && 2 * len <= tile && k1 - k0 >= 2 * len && tile <= 1024;
+                  && len <= kShiftedMaxLen && k1 - k0 >= 2 * len && tile <= 1024;
     if (shifted) {
         int ok = 1;
         for (int k = k0 + lane; k < k1; k += kWave) {
@@ -806,19 +821,16 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         }
         shifted = __all(ok);
     }
-    // A window pays when each of its slots is used at least twice (measured: 81/row band 5.6 uses
-    // per slot 284 -> 257 us, 27-point stencil 2.7 uses 216 -> 199 us, 5-point stencil 1.65 uses
-    // 44.9 -> 51.3 us on a cache-resident 2048^2 grid); it costs LDS, hence occupancy.
     int xwin = 0;
-    if (cmax - cmin < 256) {
+    if (narrow && cmax - cmin < 256) {
         if (k1 - k0 >= 2 * (cmax - cmin + 1))
             xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
     } else if (shifted && len <= kWave) {
-        // x window by runs (kTileMetaXSeg): lane = position in the row
+        // window of runs: lane = position in the row
         const int nrows = (k1 - k0) / len;
-        const int col = lane < len ? j[k0 + lane] - cmin : 0;
+        const int col = lane < len ? j[k0 + lane] : 0;
         const int d = col - __shfl_up(col, 1);
-        const int fresh = lane == 0 || d < 0 || d > nrows;       // this position starts a new run
+        const int fresh = lane == 0 || d < 0 || d > nrows; // this position starts a new run
         int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
 #pragma unroll
         for (int s = 1; s < kWave; s <<= 1) {
@@ -827,31 +839,36 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
                 xo += up;
         }
         const int total = __shfl(xo, len - 1) + nrows;
-        if (total <= 256 && 2 * total <= k1 - k0 && 2 * len + 64 * ((total + 63) / 64) <= k1 - k0) {
-            __threadfence(); // the offsets written above land before these slots are reused
+        const int slots = 64 * ((total + 63) / 64);
+        const int src_at = (k0 + 2 * len + 1) & ~1; // 4-byte aligned slot index for the 32-bit src
+        if (total <= 256 && 2 * total <= k1 - k0 && src_at + 2 * slots <= k1) {
+            __threadfence(); // offsets written above land before their slots are reused
             const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
             uint16_t * xoff = j16 + k0 + len;
-            uint16_t * src = xoff + len;
-            const int slots = 64 * ((total + 63) / 64);
+            uint32_t * src = reinterpret_cast<uint32_t *>(j16 + src_at);
             for (int i = total + lane; i < slots; i += kWave)
-                src[i] = 0; // padding of the last chunk: any valid x entry
+                src[i] = (uint32_t) cmin; // padding of the last chunk: any valid column
             if (lane < len) {
                 xoff[lane] = (uint16_t) xo;
                 const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
                 for (int i = 0; i < cnt; ++i)
-                    src[xo + i] = (uint16_t) (col + i);
+                    src[xo + i] = (uint32_t) (col + i);
             }
             xwin = kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift);
         }
     }
+    if (!narrow && !shifted)
+        return;
     if (lane == 0) {
-        desc[w].z = d0.z | kTileMetaNarrow | (shifted ? kTileMetaShifted : 0) | xwin;
-        desc[w].w = cmin;
-        atomicAdd(narrow_count, 1);
+        desc[w].z = d0.z | (narrow ? kTileMetaNarrow : 0) | (shifted ? kTileMetaShifted : 0) | xwin;
+        if (narrow) {
+            desc[w].w = cmin;
+            atomicAdd(counts, 1);
+        }
         if (shifted)
-            atomicAdd(narrow_count + 1, 1);
+            atomicAdd(counts + 1, 1);
         if (xwin)
-            atomicAdd(narrow_count + 2, 1);
+            atomicAdd(counts + 2, 1);
     }
 }
 

@@ -669,7 +669,7 @@ def test_large_stencil27_properties(oracle):
     plan.close()
 
 
-@pytest.mark.parametrize("name", ["poisson2d", "banded", "banded81", "banded200", "stencil27", "random", "powerlaw"])
+@pytest.mark.parametrize("name", ["poisson2d", "banded", "banded81", "banded120", "banded200", "stencil27", "wide_stencil", "random", "powerlaw"])
 def test_shifted_tiles_bit_identical(name):
     """Tiles that read only their first row's column offsets (stencil interiors, bands) must give
     the very bits of the plan that reads every offset; detection must not fire on random columns."""
@@ -678,7 +678,10 @@ def test_shifted_tiles_bit_identical(name):
         "poisson2d": lambda: synth.poisson2d(300),
         "banded": lambda: synth.banded(40000, range(-15, 16), seed=3),
         "banded81": lambda: synth.banded(20000, range(-40, 41), seed=3),  # rows longer than a wave
-        "banded200": lambda: synth.banded(9000, range(-100, 100), seed=3),  # two rows per tile
+        "banded120": lambda: synth.banded(9000, range(-60, 60), seed=3),  # four rows per tile
+        "banded200": lambda: synth.banded(9000, range(-100, 100), seed=3),  # longer than the first-row table: not shifted
+        # columns of a row 140 000 apart: beyond 16-bit offsets, the first row is read as 32-bit columns
+        "wide_stencil": lambda: synth.banded(300000, [-70000, -300, -1, 0, 1, 300, 70000], seed=5),
         "stencil27": lambda: synth.stencil27_like(40, 40, 40, seed=2),
         "random": lambda: synth.random_uniform(50000, 50000, 9, seed=1),
         # rows stay below the split threshold: chunks of longer rows meet in atomics, whose order
@@ -700,7 +703,11 @@ def test_shifted_tiles_bit_identical(name):
         infos.append(plan.info())
         plan.close()
     assert infos[1]["shifted_tiles"] == 0 and infos[3]["shifted_tiles"] == 0
-    if name in ("poisson2d", "banded", "banded81", "banded200", "stencil27"):
+    if name == "banded200":
+        assert infos[0]["shifted_tiles"] == 0
+    if name == "wide_stencil":
+        assert infos[0]["narrow_tiles"] < 0.1 * infos[0]["row_blocks"]
+    if name in ("poisson2d", "banded", "banded81", "banded120", "stencil27", "wide_stencil"):
         assert infos[0]["shifted_tiles"] > 0.5 * infos[0]["row_blocks"], infos[0]
         assert infos[2]["shifted_tiles"] > 0.5 * infos[2]["row_blocks"], infos[2]
     if name == "random":
@@ -878,7 +885,7 @@ def test_x_window_variant_bit_identical(name):
             "poisson2d": lambda: synth.poisson2d(300),
             # stencils in three dimensions: the window is a handful of merged runs, not one range
             "stencil27": lambda: synth.stencil27_like(40, 40, 40, seed=2),
-            "stencil7": lambda: synth.banded(64000, [-1600, -40, -3, -2, -1, 0, 1, 2, 3, 40, 1600], seed=4),
+            "stencil7": lambda: synth.banded(64000, [-1600, -41, -40, -39, -3, -2, -1, 0, 1, 2, 3, 39, 40, 41, 1600], seed=4),
         }[name]()
     x = synth.x_vector(cols, seed=5)
     dev = torch.device("cuda:0")
