@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -268,9 +269,24 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
             const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
                 : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 768e6 ? 128 : 64);
+            // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
+            // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
+            // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
+            auto lanes_for = [](int len) {
+                int l = 0;
+                while (l < 6 && (16 << l) < len)
+                    ++l;
+                return l;
+            };
             while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
-                maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
-                minlen = std::min(minlen, p[r1 + 1] - p[r1]);
+                const int len = p[r1 + 1] - p[r1];
+                if (!exact && r1 > r) {
+                    const int l = lanes_for(std::max(maxlen, len));
+                    if (l > 0 && ((r1 - r + 1) << l) > 64)
+                        break;
+                }
+                maxlen = std::max(maxlen, len);
+                minlen = std::min(minlen, len);
                 ++r1;
             }
             if (r1 == r) { // one row longer than a tile
@@ -284,15 +300,8 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 }
                 r1 = r + 1;
             } else {
-                // lanes per row: as many as fit in the wave, never more than the rows are
-                // long; one lane per row keeps the reference's summation order
-                const int nrows = r1 - r;
-                const int avg = (p[r1] - p[r]) / nrows;
-                const int cap = 64 / nrows;
-                int lanes_log2 = 0;
-                if (!exact)
-                    while ((2 << lanes_log2) <= cap && (8 << lanes_log2) <= avg)
-                        ++lanes_log2;
+                // one lane per row (rows of <= 16 entries) keeps the reference's summation order
+                const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
                 // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
                 const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
                 const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
