@@ -349,7 +349,8 @@ def main():
                        "algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
                        "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
                        "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
-                       "uniform_tiles": info["uniform_tiles"],
+                       "uniform_tiles": info["uniform_tiles"], "shifted_tiles": info["shifted_tiles"],
+                       "tiles_with_x_window": info["xwin_tiles"],
                        "partition": ("rows/%d static chunks, x replicated, 1 all-gather(y)/step%s" % (
                            world, ", gather k overlaps multiply k+1" if op.overlap else ""))
                        if use_dist else "single GPU", "backend": args.backend if use_dist else None,

@@ -151,7 +151,8 @@ int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
 /* Descriptive numbers for JSON output / tests.  out[] receives up to n of:
  * [0] format (0 none, 1 csr, 2 coo, 3 ell, 4 hybrid)  [1] rows  [2] cols  [3] stored entries
  * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
- * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns */
+ * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns
+ * [11] shifted tiles  [12] tiles with an x window (see spmv_hip_plan_info) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================
@@ -167,10 +168,13 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
                       const int32_t *host_row_ptr, int algorithm, int lanes_per_row,
                       unsigned flags);
 /* Optional second planning step for the wave-tile algorithm (done automatically by
- * spmv_hip_upload_csr): wherever all columns of a tile lie within 65536 of its smallest column,
- * keep them as 16-bit offsets in a plan-owned index stream (2 extra bytes per entry of device
- * memory), so that those tiles read 10 instead of 12 bytes per entry.  Results are unchanged bit
- * for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
+ * spmv_hip_upload_csr): one pass over the device column indices that classifies every tile.
+ *  - all columns within 65536 of the smallest one: kept as 16-bit offsets in a plan-owned index
+ *    stream (2 extra bytes per entry of device memory); the tile reads 10 instead of 12 bytes/entry;
+ *  - equally long rows that repeat the first row's columns shifted by the row distance (stencil
+ *    interiors, bands; any column range): only the first row's columns are read, 8 bytes/entry;
+ *  - tiles whose x entries fit 256 LDS slots and are each used at least twice: x staged through LDS.
+ * Results are unchanged bit for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
  * pointer silently falls back to the 32-bit indices).  Synchronises `stream`. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);

@@ -968,7 +968,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
 {
     if (!c || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
-    int64_t v[11] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0};
+    int64_t v[13] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0};
     if (c->plan) {
         v[4] = c->plan->algorithm;
         v[5] = c->plan->lanes_per_row;
@@ -977,8 +977,10 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         v[8] = c->plan->long_blocks;
         v[9] += (int64_t) c->plan->meta_bytes;
         v[10] = c->plan->narrow_tiles;
+        v[11] = c->plan->shifted_tiles;
+        v[12] = c->plan->xwin_tiles;
     }
-    for (int i = 0; i < n && i < 11; ++i)
+    for (int i = 0; i < n && i < 13; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
