@@ -228,20 +228,21 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // ---------------------------------------------------------------------------------
 // CSR, wave tiles ("wavetile"): per-wavefront row ownership, no workgroup barrier.
 //
-// The host cuts the rows into tiles owned by ONE wave: up to 128 consecutive rows
-// (two per lane when rows are short) holding at most TILE stored entries (counted from the 4-aligned start).  A tile is
-// described by an int4 {first row | flags, first entry, meta, column base} with
-// meta = longest row | log2(lanes per row) << 16 | narrow << 24 | fast << 25 | uniform << 26;
-// tile w ends where tile w+1 starts.  In a uniform tile (all rows equally long, e.g. the interior
-// of a stencil) the row bounds follow from the descriptor and row_ptr is not read.  A wave reads its descriptor pair with scalar
-// loads and then has everything it needs to issue ALL its independent loads back to
-// back -- the row_ptr pair and old y of the lane's row, then the column/value quads
-// (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs three
-// dependent memory round trips (descriptor -> streams -> x gather) instead of the six
-// of a row_ptr-driven kernel.  The rounded products are parked in the wave's private
-// LDS slice (same-wave LDS operations execute in order: no barrier, no wait beyond the
-// data dependence), then each row is added up by L lanes; L = 1 (rows shorter than 16
-// entries on average) walks the row left to right exactly like the reference loop.
+// The host cuts the rows into tiles owned by ONE wave: up to 128 consecutive rows (two per lane
+// when rows are short) holding at most TILE stored entries (counted from the 4-aligned start).
+// A tile is described by an int4 {first row | flags, first entry, meta, column base} with
+//   meta = longest row | log2(lanes per row) << 16 | narrow << 24 | fast << 25 | uniform << 26
+//          | shifted << 27 | x window << 28 | (window chunks - 1) << 29 | window of runs << 31;
+// tile w ends where tile w+1 starts.  In a uniform tile (all rows equally long, e.g. the
+// interior of a stencil) the row bounds follow from the descriptor and row_ptr is not read.
+// A wave reads its descriptor pair and then has everything it needs to issue ALL its
+// independent loads back to back -- the row_ptr pair and old y of the lane's row, then the
+// column/value quads (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs
+// three dependent memory round trips (descriptor -> streams -> x) instead of the six of a
+// row_ptr-driven kernel.  The rounded products are parked in the wave's private LDS slice
+// (same-wave LDS operations execute in order: no barrier, no wait beyond the data dependence),
+// then each row is added up by L lanes, L chosen by the host from the tile's longest row
+// (<= 16 entries per lane); L = 1 walks the row left to right exactly like the reference loop.
 //
 // The kernel is also kept lean in issued instructions, which at 5 entries per row is
 // what bounds it next to HBM: no per-entry predicates (entries of neighbouring tiles
@@ -266,8 +267,8 @@ constexpr int kTileMetaLanesShift = 16;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
-// narrow + uniform + every row has the columns of the tile's first row shifted by its distance
-// from it (the interior of a stencil, a band matrix): only the first row's offsets are read
+// uniform + every row has the columns of the tile's first row shifted by its distance from it
+// (the interior of a stencil, a band matrix): only the first row's columns are read
 constexpr int kTileMetaShifted = 1 << 27;
 // narrow, and the tile's whole column range fits the x window of the XW kernel variant:
 // bits 29-30 hold the number of 64-entry chunks of x to stage, minus one
