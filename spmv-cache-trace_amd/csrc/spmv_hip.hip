@@ -14,6 +14,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "spmv_kernels.hpp"
@@ -87,7 +89,9 @@ struct spmv_hip_plan {
     const int32_t * compressed_from = nullptr; // the column array d_col16 was derived from
     int narrow_tiles = 0;
     int shifted_tiles = 0;
-    int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x
+    int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x, or with a window of runs
+    int32_t * d_patterns = nullptr; // shared window-of-runs layouts (kernels: kPatStride words each)
+    int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     size_t meta_bytes = 0;
 };
@@ -378,6 +382,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_tiles);
     if (pl->d_col16)
         (void) hipFree(pl->d_col16);
+    if (pl->d_patterns)
+        (void) hipFree(pl->d_patterns);
     delete pl;
 }
 
@@ -393,17 +399,81 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
         return fail(SPMV_HIP_ERR_STATE, "plan is already compressed");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
+    const bool want_patterns = !(pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES);
     int * d_count = nullptr;
+    unsigned long long * d_fp = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
     int counts[3] = {0, 0, 0};
     hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
+    if (e == hipSuccess && want_patterns) {
+        e = hipMalloc((void **) &d_fp, (size_t) pl->ntiles * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d_fp, 0, (size_t) pl->ntiles * sizeof(unsigned long long), s);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
                            pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
-                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1);
+                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp);
         e = hipGetLastError();
+    }
+    // patterns: the shifted tiles' shape fingerprints come back to the host, the most frequent
+    // shapes become patterns, and the tiles that really have one of those shapes are marked
+    // (first-row columns from the pattern; a window of runs where it pays)
+    if (e == hipSuccess && d_fp) {
+        std::vector<unsigned long long> fp((size_t) pl->ntiles);
+        e = hipMemcpyAsync(fp.data(), d_fp, fp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        std::vector<std::pair<unsigned long long, std::pair<int, int>>> shapes; // fingerprint, (count, first tile)
+        if (e == hipSuccess) {
+            std::unordered_map<unsigned long long, size_t> index;
+            for (int w = 0; w < pl->ntiles; ++w) {
+                if (!fp[(size_t) w])
+                    continue;
+                auto it = index.find(fp[(size_t) w]);
+                if (it == index.end()) {
+                    index.emplace(fp[(size_t) w], shapes.size());
+                    shapes.push_back({fp[(size_t) w], {1, w}});
+                } else {
+                    shapes[it->second].second.first++;
+                }
+            }
+            std::sort(shapes.begin(), shapes.end(),
+                      [](auto const & a, auto const & b) { return a.second.first > b.second.first; });
+            if (shapes.size() > (size_t) spmv::kMaxPatterns)
+                shapes.resize((size_t) spmv::kMaxPatterns);
+        }
+        if (e == hipSuccess && !shapes.empty()) {
+            const int np = (int) shapes.size();
+            std::vector<int> rep((size_t) np);
+            std::vector<unsigned long long> pfp((size_t) np);
+            for (int i = 0; i < np; ++i) {
+                rep[(size_t) i] = shapes[(size_t) i].second.second;
+                pfp[(size_t) i] = shapes[(size_t) i].first;
+            }
+            int * d_rep = nullptr;
+            unsigned long long * d_pfp = nullptr;
+            const size_t pat_bytes = (size_t) np * spmv::kPatStride * sizeof(int32_t);
+            e = hipMalloc((void **) &pl->d_patterns, pat_bytes);
+            if (e == hipSuccess) e = hipMalloc((void **) &d_rep, (size_t) np * sizeof(int));
+            if (e == hipSuccess) e = hipMalloc((void **) &d_pfp, (size_t) np * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_rep, rep.data(), (size_t) np * sizeof(int), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_pfp, pfp.data(), (size_t) np * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::csr_pattern_build_kernel, dim3(np), dim3(64), 0, s, d_rep, pl->d_tiles,
+                                   d_column_index, pl->d_patterns);
+                hipLaunchKernelGGL(spmv::csr_pattern_assign_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
+                                   pl->ntiles, pl->d_tiles, d_column_index, d_fp, d_pfp, np, pl->d_patterns, d_count);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (d_rep) (void) hipFree(d_rep);
+            if (d_pfp) (void) hipFree(d_pfp);
+            if (e == hipSuccess) {
+                pl->npatterns = np;
+                pl->meta_bytes += pat_bytes;
+            }
+        }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -412,9 +482,15 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->xwin_tiles = counts[2];
     if (d_count)
         (void) hipFree(d_count);
+    if (d_fp)
+        (void) hipFree(d_fp);
     if (e != hipSuccess) {
         (void) hipFree(pl->d_col16);
         pl->d_col16 = nullptr;
+        if (pl->d_patterns) {
+            (void) hipFree(pl->d_patterns);
+            pl->d_patterns = nullptr;
+        }
         return fail_hip(e, "index compression");
     }
     pl->meta_bytes += bytes;
@@ -471,7 +547,7 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             const bool x32 = pl->cols < (1 << 29);
 #define SPMV_WT_LAUNCH(T, C, X, R)                                                                    \
     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X, R>), dim3(pl->workgroups), dim3(256), 0, s, \
-                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact)
+                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns)
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
@@ -481,11 +557,11 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && !exact && c16 && x32 && pl->tile == 512 && !xcd
                 && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
-                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
             } else if (abl && c16 && x32 && pl->tile == 512) {
-                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
-                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
-                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact);
+                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
+                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
+                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
             } else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
             } else {

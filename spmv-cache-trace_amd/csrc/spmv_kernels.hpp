@@ -264,6 +264,7 @@ __global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int kTileFlagPartial = (int) 0x80000000u;
 constexpr int kTileMetaLanesShift = 16;
+constexpr int kTileMetaPattern = 1 << 19; // shifted tile: desc.w is a pattern number (first-row columns = first row + pattern)
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
@@ -278,6 +279,15 @@ constexpr int kTileMetaXChunksShift = 29;
 // overlap merged -- fit the window: the plan keeps, in the tile's unused 16-bit column slots,
 // the window position of every first-row column and the x offset of every window slot
 constexpr int kTileMetaXSeg = (int) 0x80000000u;
+// A window-of-runs tile refers (desc.w) to a pattern shared by all tiles with the same row count
+// and the same first-row columns relative to the first row index -- the whole interior of a
+// stencil is one pattern -- so the window tables cost no HBM traffic and no per-tile round trip.
+// Record, in 32-bit words: [0] row length, [1] rows, [2] window slots used;
+// [16..80) first-row columns - first row index; [80..112) window position of each row position
+// (16 bits each); [112..368) x index - first row index of every window slot.
+constexpr int kPatStride = 368;
+constexpr int kPatRel = 16, kPatXoff = 80, kPatSrc = 112;
+constexpr int kMaxPatterns = 64;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -399,14 +409,16 @@ constexpr int kShiftedMaxLen = 128;
 
 template <int QUADS, bool X32>
 __device__ __forceinline__ void tile_products_shifted(
-    double * prod, uint32_t * tab, const int32_t * __restrict__ first_row,
+    double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
     const double * __restrict__ at, const double * __restrict__ x, unsigned limit, int last, int lane,
     int len, int lead)
 {
     static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
     v2d va[QUADS], vb[QUADS];
+    // first_row: the tile's own first row in the column array (base 0), or its pattern's columns
+    // relative to the first row index (base = that index; cache-resident, no per-tile read)
     for (int i = lane; i < len; i += kWave)
-        tab[i] = (uint32_t) first_row[i];
+        tab[i] = (uint32_t) (first_row[i] + first_row_base);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         int o = 256 * q + 4 * lane;
@@ -517,27 +529,27 @@ __device__ __forceinline__ void tile_products_xwin(
 
 // x window of a shifted tile whose columns are too far apart for one contiguous window (any
 // stencil in 2 or 3 dimensions): entry (row r, position pos) reads x[first_row[pos] + r], i.e. the
-// tile needs `len` runs of `rows` consecutive x entries; runs that touch or overlap are merged by
-// the plan, which stores -- in the tile's slots of the 16-bit column stream, which a shifted tile
-// does not read -- where each position's run starts in the window (xoff, 16 bits) and which x
-// entry each window slot holds (src, 32 bits: the columns may be far apart; a per-slot "owning
-// position" from which the kernel derives src needs less room but measured 224 vs 203 us).
-// Round trip 1: xoff, src, values; round trip 2:
-// the window, one load per 64 slots (27-point stencil: 180 slots in 9 runs instead of 486 gathered
-// entries touching ~50 lines per instruction); then the products read x from LDS.
+// tile needs `len` runs of `rows` consecutive x entries.  Runs that touch or overlap are merged,
+// and the layout -- where each position's run starts in the window (xoff), which x entry each
+// window slot holds relative to the tile's first row (src) -- comes from the tile's pattern
+// record, which is shared by all tiles of the same shape and therefore cache-resident: the
+// window loads can be issued as soon as the descriptor is there (27-point stencil: 180 slots in
+// 9 runs instead of 486 gathered entries touching ~50 lines per instruction); the products then
+// read x from LDS.  Per-tile tables instead of patterns measured 201 vs 176 us (768 B per tile
+// and one more dependent round trip).
 template <int QUADS, int XW>
 __device__ __forceinline__ void tile_products_xseg(
-    double * prod, double * xw, uint16_t * tab, const uint16_t * __restrict__ xoff,
-    const uint32_t * __restrict__ src, const double * __restrict__ at, const double * __restrict__ x,
-    unsigned limit, int last, int lane, int chunks, int len, int lead)
+    double * prod, double * xw, uint16_t * tab, const int32_t * __restrict__ pat, int r0,
+    const double * __restrict__ at, const double * __restrict__ x,
+    int limit, int last, int lane, int chunks, int len, int lead)
 {
     static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
-    unsigned so[XW / 64];
+    int so[XW / 64];
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
         if (ch < chunks)
-            so[ch] = src[64 * ch + lane];
-    const unsigned xo = xoff[lane < len ? lane : len - 1]; // len <= 64 for these tiles
+            so[ch] = pat[kPatSrc + 64 * ch + lane];
+    const unsigned xo = reinterpret_cast<const uint16_t *>(pat + kPatXoff)[lane < len ? lane : len - 1]; // len <= 64
     v2d va[QUADS], vb[QUADS];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -549,8 +561,11 @@ __device__ __forceinline__ void tile_products_xseg(
     double xs[XW / 64];
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks)
-            xs[ch] = x[min(so[ch], limit)];
+        if (ch < chunks) {
+            int c = r0 + so[ch];
+            c = c < 0 ? 0 : (c > limit ? limit : c); // padding slots of the last chunk
+            xs[ch] = x[c];
+        }
     tab[lane] = (uint16_t) xo;
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
@@ -591,7 +606,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
-    int nnz_total, int cols, int exact_order)
+    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns)
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
     const int meta = __builtin_amdgcn_readfirstlane(d0.z);
     const int maxlen = meta & 0xFFFF;
-    const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0xFF;
+    const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
     const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
     const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
     const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
@@ -660,21 +675,22 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         // read back
         const int last = (k1 - 1 - kb) & ~3;
         if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
-            const int len = maxlen > 0 ? maxlen : 1;
-            const uint16_t * xoff = j16 + k0 + len;
-            const uint32_t * src = reinterpret_cast<const uint32_t *>(j16 + ((k0 + 2 * len + 1) & ~1));
             tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0],
-                                      reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]), xoff, src,
-                                      a + kb, x, (unsigned) (cols - 1), last, lane,
-                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, len, k0 - kb);
+                                      reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]),
+                                      patterns + (size_t) cbase * kPatStride, r0,
+                                      a + kb, x, cols - 1, last, lane,
+                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
         } else if (XW > 0 && C16 && (meta & kTileMetaXWin))
             tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j + k0,
                                       a + kb, x + cbase, cbase, (unsigned) (cols - 1 - cbase), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
                                       maxlen > 0 ? maxlen : 1, k0 - kb);
-        else if (C16 && (meta & kTileMetaShifted))
-            tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0], j + k0, a + kb, x, (unsigned) (cols - 1), last, lane,
-                                              maxlen, k0 - kb);
+        else if (C16 && (meta & kTileMetaShifted)) {
+            const bool pattern = (meta & kTileMetaPattern) != 0;
+            tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0],
+                                              pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
+                                              a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb);
+        }
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
         else
@@ -782,7 +798,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 //           stencil 1.65 uses 44.9 -> 51.3 us on a cache-resident 2048^2 grid).
 __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ j16, int * __restrict__ counts, int detect_shifted)
+    uint16_t * __restrict__ j16, int * __restrict__ counts, int detect_shifted,
+    unsigned long long * __restrict__ fingerprint)
 {
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
@@ -840,22 +857,23 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
                 xo += up;
         }
         const int total = __shfl(xo, len - 1) + nrows;
-        const int slots = 64 * ((total + 63) / 64);
-        const int src_at = (k0 + 2 * len + 1) & ~1; // 4-byte aligned slot index for the 32-bit src
-        if (total <= 256 && 2 * total <= k1 - k0 && src_at + 2 * slots <= k1) {
-            __threadfence(); // offsets written above land before their slots are reused
-            const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
-            uint16_t * xoff = j16 + k0 + len;
-            uint32_t * src = reinterpret_cast<uint32_t *>(j16 + src_at);
-            for (int i = total + lane; i < slots; i += kWave)
-                src[i] = (uint32_t) cmin; // padding of the last chunk: any valid column
-            if (lane < len) {
-                xoff[lane] = (uint16_t) xo;
-                const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
-                for (int i = 0; i < cnt; ++i)
-                    src[xo + i] = (uint32_t) (col + i);
-            }
-            xwin = kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift);
+        if (fingerprint) {
+            // the tile's shape: (row length, rows, first-row columns relative to the first row);
+            // csr_pattern_assign_kernel gives it its pattern later (and a window if it pays)
+            (void) total;
+            const int r0 = d0.x & ~kTileFlagPartial;
+            unsigned long long h = lane < len ? ((unsigned long long) (unsigned) (col - r0) + 0x9E3779B97F4A7C15ull * (lane + 1)) : 0ull;
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            if (lane >= len)
+                h = 0;
+#pragma unroll
+            for (int s = 1; s < kWave; s <<= 1)
+                h += __shfl_xor(h, s);
+            h += 0x94D049BB133111EBull * (unsigned long long) len + 0xD6E8FEB86659FD93ull * (unsigned long long) nrows;
+            if (lane == 0)
+                fingerprint[w] = h | 1ull; // 0 = not a candidate
         }
     }
     if (!narrow && !shifted)
@@ -869,6 +887,92 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         if (shifted)
             atomicAdd(counts + 1, 1);
         if (xwin)
+            atomicAdd(counts + 2, 1);
+    }
+}
+
+// One wave per pattern: write the record of pattern p from its representative tile (the run
+// analysis of csr_tile_compress_kernel once more, this time keeping the tables).
+__global__ __launch_bounds__(64) void csr_pattern_build_kernel(
+    const int * __restrict__ rep_tile, const int4 * __restrict__ desc, const int32_t * __restrict__ j,
+    int32_t * __restrict__ patterns)
+{
+    const int lane = (int) __lane_id();
+    const int w = rep_tile[blockIdx.x];
+    int32_t * pat = patterns + (size_t) blockIdx.x * kPatStride;
+    const int4 d0 = desc[w];
+    const int r0 = d0.x & ~kTileFlagPartial;
+    const int k0 = d0.y, k1 = desc[w + 1].y;
+    const int len = d0.z & 0xFFFF;
+    const int nrows = (k1 - k0) / len;
+    const int col = lane < len ? j[k0 + lane] : 0;
+    const int d = col - __shfl_up(col, 1);
+    const int fresh = lane == 0 || d < 0 || d > nrows;
+    int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) {
+        const int up = __shfl_up(xo, s);
+        if (lane >= s)
+            xo += up;
+    }
+    const int total = __shfl(xo, len - 1) + nrows;
+    const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
+    uint16_t * xoff = reinterpret_cast<uint16_t *>(pat + kPatXoff);
+    const int col0 = __shfl(col, 0);
+    for (int i = total + lane; i < 256; i += kWave)
+        pat[kPatSrc + i] = col0 - r0; // unused slots: any valid entry
+    if (lane < len) {
+        pat[kPatRel + lane] = col - r0;
+        xoff[lane] = (uint16_t) xo;
+        const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
+        for (int i = 0; i < cnt && xo + i < 256; ++i)
+            pat[kPatSrc + xo + i] = col - r0 + i;
+    }
+    if (lane == 0) {
+        pat[0] = len;
+        pat[1] = nrows;
+        pat[2] = total;
+    }
+}
+
+// One wave per tile: a candidate (fingerprint != 0) whose fingerprint is among the patterns' and
+// whose shape really equals that pattern's gets the pattern number in desc.w and is marked
+// kTileMetaXSeg; counts[2] += 1.
+__global__ __launch_bounds__(256) void csr_pattern_assign_kernel(
+    int ntiles, int4 * __restrict__ desc, const int32_t * __restrict__ j,
+    const unsigned long long * __restrict__ fingerprint, const unsigned long long * __restrict__ pattern_fp,
+    int npatterns, const int32_t * __restrict__ patterns, int * __restrict__ counts)
+{
+    const int wave = (int) threadIdx.x >> 6;
+    const int lane = (int) __lane_id();
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= ntiles)
+        return;
+    const unsigned long long fp = fingerprint[w];
+    if (fp == 0)
+        return;
+    const unsigned long long hit = __ballot(lane < npatterns && pattern_fp[lane < npatterns ? lane : 0] == fp);
+    if (hit == 0)
+        return;
+    const int p = __builtin_ctzll(hit);
+    const int32_t * pat = patterns + (size_t) p * kPatStride;
+    const int4 d0 = desc[w];
+    const int r0 = d0.x & ~kTileFlagPartial;
+    const int k0 = d0.y, k1 = desc[w + 1].y;
+    const int len = d0.z & 0xFFFF;
+    int same = len == pat[0] && len <= kWave && (k1 - k0) == pat[1] * len;
+    if (same && lane < len)
+        same = (j[k0 + lane] - r0) == pat[kPatRel + lane];
+    if (!__all(same))
+        return;
+    if (lane == 0) {
+        // a window only where every slot is used at least twice (see csr_tile_compress_kernel)
+        const int total = pat[2];
+        const bool window = total <= 256 && 2 * total <= k1 - k0;
+        desc[w].z = d0.z | kTileMetaPattern
+                    | (window ? (kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift)) : 0);
+        desc[w].w = p;
+        if (window)
             atomicAdd(counts + 2, 1);
     }
 }
