@@ -282,11 +282,12 @@ constexpr int kTileMetaXSeg = (int) 0x80000000u;
 // A window-of-runs tile refers (desc.w) to a pattern shared by all tiles with the same row count
 // and the same first-row columns relative to the first row index -- the whole interior of a
 // stencil is one pattern -- so the window tables cost no HBM traffic and no per-tile round trip.
-// Record, in 32-bit words: [0] row length, [1] rows, [2] window slots used;
-// [16..80) first-row columns - first row index; [80..112) window position of each row position
-// (16 bits each); [112..368) x index - first row index of every window slot.
-constexpr int kPatStride = 368;
-constexpr int kPatRel = 16, kPatXoff = 80, kPatSrc = 112;
+// Record, in 32-bit words: [0] row length, [1] rows, [2] window slots a window of runs would use
+// (2^20 = none worked out), [3] smallest first-row column - first row index;
+// [16..144) first-row columns - first row index; [144..176) window position of each row position
+// (16 bits each); [176..432) x index - first row index of every window slot.
+constexpr int kPatStride = 432;
+constexpr int kPatRel = 16, kPatXoff = 144, kPatSrc = 176;
 constexpr int kMaxPatterns = 64;
 
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
@@ -462,7 +463,7 @@ __device__ __forceinline__ void tile_products_shifted(
 template <int QUADS, int XW>
 __device__ __forceinline__ void tile_products_xwin(
     double * prod, double * xw, uint32_t * tab, const uint16_t * __restrict__ jt,
-    const int32_t * __restrict__ first_row, const double * __restrict__ at,
+    const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
     const double * __restrict__ xt, int cbase, unsigned limit, int last, int lane, int chunks, bool shifted,
     int len, int lead)
 {
@@ -477,7 +478,7 @@ __device__ __forceinline__ void tile_products_xwin(
     v2d va[QUADS], vb[QUADS];
     if (shifted) {
         for (int i = lane; i < len; i += kWave)
-            tab[i] = (uint32_t) (first_row[i] - cbase);
+            tab[i] = (uint32_t) (first_row[i] + first_row_base - cbase);
     }
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -680,11 +681,17 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                                       patterns + (size_t) cbase * kPatStride, r0,
                                       a + kb, x, cols - 1, last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
-        } else if (XW > 0 && C16 && (meta & kTileMetaXWin))
-            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb, j + k0,
-                                      a + kb, x + cbase, cbase, (unsigned) (cols - 1 - cbase), last, lane,
+        } else if (XW > 0 && C16 && (meta & kTileMetaXWin)) {
+            // with a pattern, desc.w is its number and the smallest column follows from it
+            const bool pattern = (meta & kTileMetaPattern) != 0;
+            const int32_t * pat = patterns + (size_t) (pattern ? cbase : 0) * kPatStride;
+            const int cb = pattern ? r0 + __builtin_amdgcn_readfirstlane(pat[3]) : cbase;
+            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb,
+                                      pattern ? pat + kPatRel : j + k0, pattern ? r0 : 0,
+                                      a + kb, x + cb, cb, (unsigned) (cols - 1 - cb), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
                                       maxlen > 0 ? maxlen : 1, k0 - kb);
+        }
         else if (C16 && (meta & kTileMetaShifted)) {
             const bool pattern = (meta & kTileMetaPattern) != 0;
             tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0],
@@ -840,41 +847,26 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         shifted = __all(ok);
     }
     int xwin = 0;
-    if (narrow && cmax - cmin < 256) {
-        if (k1 - k0 >= 2 * (cmax - cmin + 1))
-            xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
-    } else if (shifted && len <= kWave) {
-        // window of runs: lane = position in the row
-        const int nrows = (k1 - k0) / len;
-        const int col = lane < len ? j[k0 + lane] : 0;
-        const int d = col - __shfl_up(col, 1);
-        const int fresh = lane == 0 || d < 0 || d > nrows; // this position starts a new run
-        int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1) {
-            const int up = __shfl_up(xo, s);
-            if (lane >= s)
-                xo += up;
+    if (narrow && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
+        xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
+    if (shifted && fingerprint) {
+        // the tile's shape: (row length, rows, first-row columns relative to the first row);
+        // csr_pattern_assign_kernel gives it its pattern later (and a window of runs if it pays)
+        const int r0 = d0.x & ~kTileFlagPartial;
+        unsigned long long h = 0;
+        for (int pos = lane; pos < len; pos += kWave) {
+            unsigned long long t = (unsigned long long) (unsigned) (j[k0 + pos] - r0) + 0x9E3779B97F4A7C15ull * (unsigned long long) (pos + 1);
+            t ^= t >> 29;
+            t *= 0xBF58476D1CE4E5B9ull;
+            t ^= t >> 32;
+            h += t;
         }
-        const int total = __shfl(xo, len - 1) + nrows;
-        if (fingerprint) {
-            // the tile's shape: (row length, rows, first-row columns relative to the first row);
-            // csr_pattern_assign_kernel gives it its pattern later (and a window if it pays)
-            (void) total;
-            const int r0 = d0.x & ~kTileFlagPartial;
-            unsigned long long h = lane < len ? ((unsigned long long) (unsigned) (col - r0) + 0x9E3779B97F4A7C15ull * (lane + 1)) : 0ull;
-            h ^= h >> 29;
-            h *= 0xBF58476D1CE4E5B9ull;
-            h ^= h >> 32;
-            if (lane >= len)
-                h = 0;
 #pragma unroll
-            for (int s = 1; s < kWave; s <<= 1)
-                h += __shfl_xor(h, s);
-            h += 0x94D049BB133111EBull * (unsigned long long) len + 0xD6E8FEB86659FD93ull * (unsigned long long) nrows;
-            if (lane == 0)
-                fingerprint[w] = h | 1ull; // 0 = not a candidate
-        }
+        for (int s = 1; s < kWave; s <<= 1)
+            h += __shfl_xor(h, s);
+        h += 0x94D049BB133111EBull * (unsigned long long) len + 0xD6E8FEB86659FD93ull * (unsigned long long) ((k1 - k0) / len);
+        if (lane == 0)
+            fingerprint[w] = h | 1ull; // 0 = no shape
     }
     if (!narrow && !shifted)
         return;
@@ -891,8 +883,10 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     }
 }
 
-// One wave per pattern: write the record of pattern p from its representative tile (the run
-// analysis of csr_tile_compress_kernel once more, this time keeping the tables).
+// One wave per pattern: write the record of pattern p from its representative tile.  Rows of up
+// to 64 entries also get the layout of a window of runs: lane = position in the row; a position
+// whose column is within `rows` of the previous one continues its run, so the runs' x ranges
+// [column, column + rows) are merged where they touch or overlap.
 __global__ __launch_bounds__(64) void csr_pattern_build_kernel(
     const int * __restrict__ rep_tile, const int4 * __restrict__ desc, const int32_t * __restrict__ j,
     int32_t * __restrict__ patterns)
@@ -905,33 +899,47 @@ __global__ __launch_bounds__(64) void csr_pattern_build_kernel(
     const int k0 = d0.y, k1 = desc[w + 1].y;
     const int len = d0.z & 0xFFFF;
     const int nrows = (k1 - k0) / len;
-    const int col = lane < len ? j[k0 + lane] : 0;
-    const int d = col - __shfl_up(col, 1);
-    const int fresh = lane == 0 || d < 0 || d > nrows;
-    int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
+    int relmin = 0x7FFFFFFF;
+    for (int pos = lane; pos < len; pos += kWave) {
+        const int rel = j[k0 + pos] - r0;
+        pat[kPatRel + pos] = rel;
+        relmin = rel < relmin ? rel : relmin;
+    }
 #pragma unroll
     for (int s = 1; s < kWave; s <<= 1) {
-        const int up = __shfl_up(xo, s);
-        if (lane >= s)
-            xo += up;
+        const int o = __shfl_xor(relmin, s);
+        relmin = o < relmin ? o : relmin;
     }
-    const int total = __shfl(xo, len - 1) + nrows;
-    const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
-    uint16_t * xoff = reinterpret_cast<uint16_t *>(pat + kPatXoff);
-    const int col0 = __shfl(col, 0);
-    for (int i = total + lane; i < 256; i += kWave)
-        pat[kPatSrc + i] = col0 - r0; // unused slots: any valid entry
-    if (lane < len) {
-        pat[kPatRel + lane] = col - r0;
-        xoff[lane] = (uint16_t) xo;
-        const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
-        for (int i = 0; i < cnt && xo + i < 256; ++i)
-            pat[kPatSrc + xo + i] = col - r0 + i;
+    int total = 1 << 20;
+    if (len <= kWave) {
+        const int col = lane < len ? j[k0 + lane] : 0;
+        const int d = col - __shfl_up(col, 1);
+        const int fresh = lane == 0 || d < 0 || d > nrows;
+        int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
+#pragma unroll
+        for (int s = 1; s < kWave; s <<= 1) {
+            const int up = __shfl_up(xo, s);
+            if (lane >= s)
+                xo += up;
+        }
+        total = __shfl(xo, len - 1) + nrows;
+        const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
+        uint16_t * xoff = reinterpret_cast<uint16_t *>(pat + kPatXoff);
+        const int col0 = __shfl(col, 0);
+        for (int i = (total < 256 ? total : 256) + lane; i < 256; i += kWave)
+            pat[kPatSrc + i] = col0 - r0; // unused slots: any valid entry
+        if (lane < len) {
+            xoff[lane] = (uint16_t) (xo < 65535 ? xo : 65535);
+            const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
+            for (int i = 0; i < cnt && xo + i < 256; ++i)
+                pat[kPatSrc + xo + i] = col - r0 + i;
+        }
     }
     if (lane == 0) {
         pat[0] = len;
         pat[1] = nrows;
         pat[2] = total;
+        pat[3] = relmin;
     }
 }
 
@@ -960,15 +968,17 @@ __global__ __launch_bounds__(256) void csr_pattern_assign_kernel(
     const int r0 = d0.x & ~kTileFlagPartial;
     const int k0 = d0.y, k1 = desc[w + 1].y;
     const int len = d0.z & 0xFFFF;
-    int same = len == pat[0] && len <= kWave && (k1 - k0) == pat[1] * len;
-    if (same && lane < len)
-        same = (j[k0 + lane] - r0) == pat[kPatRel + lane];
+    int same = len == pat[0] && (k1 - k0) == pat[1] * len;
+    if (same)
+        for (int pos = lane; pos < len; pos += kWave)
+            same &= (j[k0 + pos] - r0) == pat[kPatRel + pos];
     if (!__all(same))
         return;
     if (lane == 0) {
-        // a window only where every slot is used at least twice (see csr_tile_compress_kernel)
+        // a window of runs only where every slot is used at least twice (see above), and a
+        // contiguous window (already marked) is the better one where both apply
         const int total = pat[2];
-        const bool window = total <= 256 && 2 * total <= k1 - k0;
+        const bool window = !(d0.z & kTileMetaXWin) && total <= 256 && 2 * total <= k1 - k0;
         desc[w].z = d0.z | kTileMetaPattern
                     | (window ? (kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift)) : 0);
         desc[w].w = p;
