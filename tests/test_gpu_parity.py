@@ -936,3 +936,41 @@ def test_x_window_kernel_with_minority_of_other_tiles(oracle):
         torch.cuda.synchronize()
         assert_close(ty.cpu().numpy(), want, scale, what="mixed flags %x" % flags)
         plan.close()
+
+
+def test_more_tile_shapes_than_patterns(oracle):
+    """150 blocks of rows, each with its own 7-column stencil: more distinct tile shapes than the
+    64 pattern records.  Tiles without a pattern read their own first row; y is bit-exact either way
+    (rows of 7 entries are summed by one lane, in the reference's order)."""
+    import torch
+    rng = np.random.default_rng(42)
+    cols = 400000
+    rows_per_block, blocks = 300, 150
+    rows = rows_per_block * blocks
+    col_parts = []
+    for b in range(blocks):
+        offs = np.sort(rng.choice(np.arange(-90000, 90000), size=7, replace=False))
+        base = 100000 + b * rows_per_block
+        r = np.arange(rows_per_block)[:, None] + base
+        col_parts.append((r + offs[None, :]).reshape(-1))
+    c = np.concatenate(col_parts).astype(np.int32)
+    assert c.min() >= 0 and c.max() < cols
+    p = (np.arange(rows + 1, dtype=np.int64) * 7).astype(np.int32)
+    v = rng.uniform(-1, 1, size=len(c))
+    x = synth.x_vector(cols, seed=9)
+    y0 = synth.x_vector(rows, seed=10)
+    want = y0 + oracle.csr_spmv(rows, p, c, v, x, num_threads=1)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    for flags in (0, capi.FLAG_NO_SHIFTED_TILES, capi.FLAG_ROWS128):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        info = plan.info()
+        ty = torch.from_numpy(y0).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_bitexact(ty.cpu().numpy(), want, "many shapes, flags %x" % flags)
+        if not (flags & capi.FLAG_NO_SHIFTED_TILES):
+            assert info["shifted_tiles"] > 0.5 * info["row_blocks"]
+        plan.close()
