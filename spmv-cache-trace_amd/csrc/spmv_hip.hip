@@ -90,6 +90,7 @@ struct spmv_hip_plan {
     int narrow_tiles = 0;
     int shifted_tiles = 0;
     int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x, or with a window of runs
+    int longest_tile_row = 0; // longest row inside a stream tile
     int32_t * d_patterns = nullptr; // shared window-of-runs layouts (kernels: kPatStride words each)
     int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
@@ -306,6 +307,7 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             } else {
                 // one lane per row (rows of <= 16 entries) keeps the reference's summation order
                 const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
+                pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
                 // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
                 const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
                 const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
@@ -551,11 +553,11 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
-            // x staged through LDS when most tiles' columns fit the window (narrow bands); with one lane
-            // per row (EXACT_ORDER, the in-place ELLPACK path) the long row sums want the occupancy more
-            // than the gather wants the window (L = 81: 347 vs 338 us), so not there
-            if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && !exact && c16 && x32 && pl->tile == 512 && !xcd
-                && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
+            // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
+            // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants
+            // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row
+            if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
+                && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
                                    pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
             } else if (abl && c16 && x32 && pl->tile == 512) {
