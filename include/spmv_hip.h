@@ -66,7 +66,7 @@ extern "C" {
                                             (by default their row bounds come from the tile descriptor) */
 #define SPMV_HIP_FLAG_ROWS64 0x80u       /* wavetile: at most 64 rows per tile ... */
 #define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
-                                            exceeds ~768 MB (streams from HBM), 64 while it is cache-resident */
+                                            exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
                                                 kernel (default only for row_length > 256; shorter rows run in place
                                                 as uniform wave tiles, one lane per row) */

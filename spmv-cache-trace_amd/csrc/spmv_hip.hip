@@ -269,11 +269,11 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             int32_t r1 = r;
             int32_t maxlen = 0, minlen = INT32_MAX;
             // rows per tile: 128 (two short rows per lane, fuller quads) pays once the matrix streams from
-            // HBM; while it still fits the 256 MiB Infinity Cache more, smaller tiles win (measured:
-            // Poisson 4096^2 223 vs 238 us, Poisson 2048^2 57 vs 50 us)
+            // HBM (twice the 256 MiB Infinity Cache); below that more, smaller tiles win (measured:
+            // Poisson 4096^2 223 vs 238 us, half of it 103 vs 107 us, a quarter 48 vs 43 us, 2048^2 57 vs 50 us)
             const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
             const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
-                : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 768e6 ? 128 : 64);
+                : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 512e6 ? 128 : 64);
             // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
             // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
             // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
