@@ -2,7 +2,7 @@
 """Time Matrix Market ingest: this repo's loader + CSR converter against the
 reference library's (oracle/_ref, when present) on a generated 5-point stencil file.
 
-    python tools/ingest_bench.py [--grid 1024] [--keep]
+    python tests/ingest_bench.py [--grid 1024] [--keep]
 """
 import argparse
 import os
