@@ -78,7 +78,7 @@ Matrix from_matrix_market_row_aligned(matrix_market::Matrix const & m, index_typ
 
     index_array_type column_index((std::size_t) k);
     value_array_type value((std::size_t) k);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((std::size_t) k > (1u << 16))
     for (long long r = 0; r < (long long) rows; ++r) {
         std::size_t dst = (std::size_t) row_ptr[(std::size_t) r];
         for (std::size_t q = e.start[(std::size_t) r]; q < e.start[(std::size_t) r + 1]; ++q, ++dst) {

@@ -58,7 +58,7 @@ Matrix from_matrix_market(matrix_market::Matrix const & m, bool skip_padding)
     for (index_type r = 0; r < rows; ++r)
         last_before[(std::size_t) r + 1] = e.start[(std::size_t) r + 1] > e.start[(std::size_t) r]
             ? e.col[e.start[(std::size_t) r + 1] - 1] : last_before[(std::size_t) r];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((std::size_t) rows * (std::size_t) row_length > (1u << 16))
     for (long long r = 0; r < (long long) rows; ++r) {
         std::size_t dst = (std::size_t) r * (std::size_t) row_length;
         std::size_t const b = e.start[(std::size_t) r], n = e.start[(std::size_t) r + 1] - b;

@@ -26,6 +26,12 @@ using matrix::matrix_error;
 
 namespace matrix_market {
 
+// Below this many entries the converters run on the calling thread: waking an OpenMP team costs
+// tens of milliseconds on a busy host, the work itself microseconds (BASELINE configs[0] is a
+// 1138-row matrix).
+static constexpr std::size_t kSerialBelow = 1u << 16;
+
+
 Matrix::Matrix(Header header, std::vector<std::string> comments, Size size,
                std::vector<index_type> i, std::vector<index_type> j, std::vector<real_type> a,
                std::vector<real_type> imag)
@@ -212,8 +218,9 @@ Matrix fromBuffer(char const * d, std::size_t n)
             b = e;
         }
     }
-    // pass 1: tokens per chunk
-#pragma omp parallel for schedule(dynamic, 1)
+    // pass 1: tokens per chunk (a file below 64 KiB per chunk is one chunk and is parsed by the
+    // calling thread alone: waking a team costs more than the parse)
+#pragma omp parallel for schedule(dynamic, 1) if (nchunks > 1)
     for (std::size_t c = 0; c < nchunks; ++c) {
         long long t = 0;
         std::size_t k = chunks[c].begin, e = chunks[c].end;
@@ -242,7 +249,7 @@ Matrix fromBuffer(char const * d, std::size_t n)
     // which entry each token is
     bool bad = false;
     long long bad_token = -1;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (nchunks > 1)
     for (std::size_t c = 0; c < nchunks; ++c) {
         long long t = chunks[c].first_token;
         std::size_t k = chunks[c].begin, e = chunks[c].end;
@@ -575,7 +582,7 @@ std::vector<size_type> two_key_order(std::vector<index_type> const & major,
         for (std::size_t k = 0; k < N; ++k)
             order[fill[(std::size_t) major[k] - 1]++] = (size_type) k;
     }
-#pragma omp parallel for schedule(dynamic, 1024)
+#pragma omp parallel for schedule(dynamic, 1024) if (N > kSerialBelow)
     for (long long r = 0; r < (long long) start.size() - 1; ++r) {
         auto b = order.begin() + (std::ptrdiff_t) start[(std::size_t) r];
         auto e = order.begin() + (std::ptrdiff_t) start[(std::size_t) r + 1];
@@ -621,7 +628,7 @@ RowMajorEntries row_major_entries(Matrix const & m)
     std::vector<std::size_t> cursor(out.start.begin(), out.start.end() - 1);
 
 #ifdef _OPENMP
-    int const threads = std::max(1, omp_get_max_threads());
+    int const threads = N > kSerialBelow ? std::max(1, omp_get_max_threads()) : 1;
 #else
     int const threads = 1;
 #endif
@@ -634,7 +641,7 @@ RowMajorEntries row_major_entries(Matrix const & m)
         bound[(std::size_t) t] = (index_type) (std::lower_bound(out.start.begin(), out.start.end(), target) - out.start.begin());
         bound[(std::size_t) t] = std::min(bound[(std::size_t) t], rows);
     }
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
+#pragma omp parallel for schedule(static, 1) num_threads(threads) if (threads > 1)
     for (int t = 0; t < threads; ++t) {
         index_type const lo = bound[(std::size_t) t], hi = bound[(std::size_t) t + 1];
         if (lo >= hi)
@@ -649,7 +656,7 @@ RowMajorEntries row_major_entries(Matrix const & m)
         }
     }
     // order each row by column; rows arrive in file order, so already-sorted rows are common
-#pragma omp parallel for schedule(dynamic, 2048)
+#pragma omp parallel for schedule(dynamic, 2048) if (N > kSerialBelow)
     for (long long r = 0; r < (long long) rows; ++r) {
         std::size_t const b = out.start[(std::size_t) r], e = out.start[(std::size_t) r + 1];
         bool sorted = true;
