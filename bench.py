@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--events", choices=["launch", "region"], default="region",
                     help="one HIP event pair around the K timed launches (default; mean launch duration = span / K, "
                          "launch gaps included), or a pair around every launch (adds ~5 us of gap per step)")
+    ap.add_argument("--partition", choices=["rows", "nnz"], default="rows",
+                    help="N > 1: the reference's static row chunks (default), or a split on row boundaries with "
+                         "equal stored entries per rank (uneven rows; only for workloads generated whole)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each all-gather before the next multiply (default: gather k overlaps multiply k+1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -218,6 +221,7 @@ def main():
 
     # ---- workload: this rank's rows, global x ------------------------------------------
     t_setup = time.perf_counter()
+    ranges = None
     if args.workload == "poisson2d":
         rows = args.grid * args.grid
     else:
@@ -227,7 +231,11 @@ def main():
         rows, cols, nnz, p, c, v, wname = make_rows(args, begin, end)
     elif world > 1:
         rows_g, cols, nnz, p, c, v, wname = make_rows(args, 0, None)
-        begin, end = partition.row_range(rows_g, rank, world)
+        if args.partition == "nnz":
+            ranges = partition.nnz_balanced_ranges(p, world)
+            begin, end = ranges[rank]
+        else:
+            begin, end = partition.row_range(rows_g, rank, world)
         p, c, v = partition.csr_slice(p, c, v, begin, end)
         rows = rows_g
     else:
@@ -238,7 +246,7 @@ def main():
             "adaptive": capi.CSR_ADAPTIVE, "wavetile": capi.CSR_WAVETILE}[args.algorithm]
     flags = (capi.FLAG_XCD_REMAP if args.xcd_remap else 0) | args.flags
     op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
-                                   overlap=not args.no_overlap)
+                                   overlap=not args.no_overlap, ranges=ranges)
     local_rows, local_nnz = end - begin, int(p[-1])
     local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
     torch.cuda.synchronize()
@@ -351,8 +359,8 @@ def main():
                        "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
                        "uniform_tiles": info["uniform_tiles"], "shifted_tiles": info["shifted_tiles"],
                        "tiles_with_x_window": info["xwin_tiles"],
-                       "partition": ("rows/%d static chunks, x replicated, 1 all-gather(y)/step%s" % (
-                           world, ", gather k overlaps multiply k+1" if op.overlap else ""))
+                       "partition": ("%s, x replicated, 1 all-gather(y)/step%s" % (
+                           ("rows/%d static chunks" % world) if ranges is None else ("%d row ranges of equal stored entries" % world), ", gather k overlaps multiply k+1" if op.overlap else ""))
                        if use_dist else "single GPU", "backend": args.backend if use_dist else None,
                        "rehearsal_shared_gpu": bool(args.share_gpu)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

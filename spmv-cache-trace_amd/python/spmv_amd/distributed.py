@@ -4,10 +4,12 @@ y segments per multiply (RCCL over xGMI when the process group is "nccl").
     rank g:   y_g += A[rows_g, :] @ x            (HIP kernel, local rows only)
     all:      y = all_gather(y_0, ..., y_{G-1})  (the only collective on the path)
 
-The partition rule is the reference's static row chunking (partition.row_range).
+The default partition is the reference's static row chunking (partition.row_range).
 Segments are padded to the common chunk length so the collective is a plain
 equal-count all-gather; because chunks are contiguous and only the last one is
-short, the first `rows` entries of the gathered buffer are y itself.
+short, the first `rows` entries of the gathered buffer are y itself.  Any other
+contiguous split (``ranges``, e.g. partition.nnz_balanced_ranges for matrices with
+uneven rows) pads every segment to the longest one; y() then drops the padding.
 
 With ``overlap=True`` the gather of multiply k runs on the collective's stream while
 multiply k+1 runs on the compute stream: the segment is snapshotted into a send buffer
@@ -26,11 +28,23 @@ from . import capi, partition
 
 
 class DistributedCsrSpmv:
-    def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None, overlap=False):
+    def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None, overlap=False,
+                 ranges=None):
         self.rows, self.cols = rows, cols
         self.rank, self.world = rank, world
-        self.chunk = partition.row_chunk(rows, world)
-        self.begin, self.end = partition.row_range(rows, rank, world)
+        if ranges is None:
+            ranges = [partition.row_range(rows, g, world) for g in range(world)]
+            self.chunk = partition.row_chunk(rows, world)
+        else:
+            ranges = [(int(b), int(e)) for b, e in ranges]
+            assert len(ranges) == world and ranges[0][0] == 0 and ranges[-1][1] == rows
+            assert all(ranges[g][1] == ranges[g + 1][0] for g in range(world - 1))
+            self.chunk = max(1, max(e - b for b, e in ranges))
+        self.ranges = ranges
+        # the gathered buffer is y itself when every segment but the last fills its chunk
+        self.packed = all(e - b == self.chunk for b, e in ranges[:-1] if e > b) and \
+            all(b == g * self.chunk or e == b for g, (b, e) in enumerate(ranges))
+        self.begin, self.end = ranges[rank]
         assert local_rows == self.end - self.begin
         self.device = device
         self.group = group
@@ -44,7 +58,7 @@ class DistributedCsrSpmv:
 
     @classmethod
     def on_gpu(cls, rows, cols, rank, world, device, p_local, c_local, v_local, x_host,
-               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False):
+               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False, ranges=None):
         """Product path: local slice uploaded to `device`, multiplied by the HIP kernel
         on torch's current stream.  Raises if the HIP library or the GPU is missing."""
         local_rows = len(p_local) - 1
@@ -60,7 +74,7 @@ class DistributedCsrSpmv:
             plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_local.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
 
-        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group, overlap)
+        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group, overlap, ranges)
         self.plan = plan
         self._keep = (tp, tc, tv, tx)
         return self
@@ -98,6 +112,9 @@ class DistributedCsrSpmv:
             self.gather()
 
     def y(self):
-        """The assembled y (first `rows` entries of the gathered buffer)."""
+        """The assembled y: the first `rows` entries of the gathered buffer, or, for a split with
+        uneven segments, the segments without their padding."""
         self.finish()
-        return self.y_full[:self.rows]
+        if self.packed:
+            return self.y_full[:self.rows]
+        return torch.cat([self.y_full[g * self.chunk: g * self.chunk + (e - b)] for g, (b, e) in enumerate(self.ranges)])

@@ -46,7 +46,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, out_dir, overlap=False):
+def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -61,31 +61,42 @@ def _worker(rank, world, port, steps, out_dir, overlap=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     O = oracle_py.Oracle()
-    rows, cols, p, c, v = synth.stencil27_like(11, 9, 7, seed=5)  # 693 rows: not divisible by 2 or 3... evenly
+    if balanced:  # uneven rows: split by stored entries, segments of different lengths
+        rows, cols, p, c, v = synth.powerlaw(700, 700, seed=4, max_len=300)
+        ranges = partition.nnz_balanced_ranges(p, world)
+    else:
+        rows, cols, p, c, v = synth.stencil27_like(11, 9, 7, seed=5)  # 693 rows: not divisible by 2 or 3... evenly
+        ranges = None
     x = synth.x_vector(cols, seed=9)
-    b, e = partition.row_range(rows, rank, world)
+    b, e = ranges[rank] if balanced else partition.row_range(rows, rank, world)
     pl, cl, vl = partition.csr_slice(p, c, v, b, e)
 
     def local_spmv(y_local):  # test double for the HIP kernel: the oracle on this rank's rows
         y = y_local.numpy()
         y[:e - b] = O.csr_spmv(e - b, pl, cl, vl, x, y=y[:e - b])
 
-    op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, overlap=overlap)
+    op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, overlap=overlap,
+                            ranges=ranges)
     for _ in range(steps):
         op.step()
     want = O.csr_spmv(rows, p, c, v, x, runs=steps)
     got = op.y().numpy()  # y() waits for the outstanding gather
-    ok = np.array_equal(got, want) and op.y_full.numel() == partition.row_chunk(rows, world) * world
+    ok = np.array_equal(got, want) and (balanced or op.y_full.numel() == partition.row_chunk(rows, world) * world)
+    if balanced:
+        ok = ok and len({e2 - b2 for b2, e2 in ranges}) > 1  # really uneven
+        if world == 3:
+            ok = ok and not op.packed  # a short segment in front of a longer one: y() has to drop padding
     # every rank must hold the whole y after the gather
     open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
-def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,balanced", [(2, False, False), (3, False, False), (2, True, False),
+                                                    (3, False, True), (2, True, True)])
+def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 3, str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 3, str(tmp_path), overlap, balanced), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
