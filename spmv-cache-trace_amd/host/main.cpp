@@ -72,6 +72,7 @@ enum Key
     key_csr_algorithm,
     key_lanes,
     key_expand_symmetric,
+    key_matrix_cache,
     key_exact_order,
     key_threads,
     key_check,
@@ -149,6 +150,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
         a.spmv.csr_lanes_per_row = (int) n;
         break;
     case key_expand_symmetric: a.spmv.expand_symmetric = true; break;
+    case key_matrix_cache: setenv("SPMV_MATRIX_CACHE", arg, 1); break;
     case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
     case key_threads:
         if (!parse_count(arg, n) || n < 1 || n > 4096)
@@ -208,6 +210,9 @@ int main(int argc, char ** argv)
         {"ell", key_ell, "PATH", 0, "same as --spmv-format ell --matrix PATH", 2},
         {"expand-symmetric", key_expand_symmetric, nullptr, 0,
          "EXTENSION: mirror the entries of symmetric files (the reference multiplies the stored triangle only)", 2},
+        {"matrix-cache", key_matrix_cache, "DIR", 0,
+         "EXTENSION: keep the parsed entries of every matrix file in DIR and read them back next time "
+         "(keyed by path, size and modification time; also: environment SPMV_MATRIX_CACHE)", 2},
 
         {nullptr, 0, nullptr, 0, "GPU:", 3},
         {"device", key_device, "cpu|hip", 0, "Where the kernel runs (default cpu; hip = MI355X, no fallback)", 3},

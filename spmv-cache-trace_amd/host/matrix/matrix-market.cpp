@@ -2,6 +2,7 @@
 
 #include "matrix-error.hpp"
 #include "matrix-reorder.hpp"
+#include "matrix-cache.hpp"
 
 #include <zlib.h>
 
@@ -548,7 +549,17 @@ Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
         if (gp)
             o << "The input matrix will be reordered using graph partitioning\n";
     }
-    Matrix m = load_file(file, o, verbose);
+    // optional binary cache of the parsed entries (matrix-cache.hpp); reordering comes after it
+    Matrix m;
+    std::string const cache = cache_directory();
+    if (!cache.empty() && load_cached(file, cache, m)) {
+        if (verbose)
+            o << "Read the parsed entries from " << cache_file_for(file, cache) << '\n';
+    } else {
+        m = load_file(file, o, verbose);
+        if (!cache.empty())
+            store_cached(file, cache, m);
+    }
     if (rcm)
         m = permute(m, find_new_order_RCM(m, o, verbose));
     if (gp)

@@ -514,3 +514,66 @@ def test_cli_hybrid_object():
                               "x_size", "y_size", "ell_row_length", "num_ell_entries", "num_coo_entries"]
     assert k["matrix_format"] == "hybrid" and k["ell_row_length"] == 7 and k["num_ell_entries"] == 367 * 7
     assert k["num_coo_entries"] == 83 and k["matrix_size"] == 31824
+
+
+def _mm_snapshot(host, h):
+    info = host.mm_info(h)
+    i, j, a = host.mm_entries(h)
+    comments = [host.mm_comment(h, k) for k in range(info["comments"])]
+    return info, i.copy(), j.copy(), a.copy(), comments
+
+
+@pytest.mark.parametrize("name", ["poisson2D.mtx", "bus1138_like.mtx", "test_mtx.gz"])
+def test_matrix_cache_round_trip(host, tmp_path, monkeypatch, name):
+    """SPMV_MATRIX_CACHE: the second load of a file comes from the binary cache and is the same
+    Matrix (header, sizes, comments, entries in file order); a changed source is parsed again."""
+    import shutil
+    src = str(tmp_path / name)
+    shutil.copy(os.path.join(GOLDEN, name), src)
+    h = host.mm_load(src)
+    plain = _mm_snapshot(host, h)
+    host.mm_free(h)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("SPMV_MATRIX_CACHE", str(cache))
+    h = host.mm_load(src)  # parses and stores
+    first = _mm_snapshot(host, h)
+    host.mm_free(h)
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].startswith(name + ".") and files[0].endswith(".mmbin")
+    stamp = os.stat(cache / files[0]).st_mtime_ns
+    # make the source unreadable as text: a load that still succeeds must have come from the cache
+    data = open(src, "rb").read()
+    st = os.stat(src)
+    open(src, "wb").write(b"x" * len(data))
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    h = host.mm_load(src)
+    second = _mm_snapshot(host, h)
+    host.mm_free(h)
+    assert os.stat(cache / files[0]).st_mtime_ns == stamp
+    for snap in (first, second):
+        assert snap[0] == plain[0] and snap[4] == plain[4]
+        assert np.array_equal(snap[1], plain[1]) and np.array_equal(snap[2], plain[2])
+        assert np.array_equal(snap[3].view(np.uint64), plain[3].view(np.uint64))
+    # a different modification time is a different file: the garbage is parsed, and rejected
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000_000))
+    with pytest.raises(Exception):
+        host.mm_load(src)
+    # a truncated cache entry is ignored, not trusted
+    open(src, "wb").write(data)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    blob = open(cache / files[0], "rb").read()
+    open(cache / files[0], "wb").write(blob[:len(blob) // 2])
+    h = host.mm_load(src)
+    again = _mm_snapshot(host, h)
+    host.mm_free(h)
+    assert again[0] == plain[0] and np.array_equal(again[3].view(np.uint64), plain[3].view(np.uint64))
+
+
+def test_cli_matrix_cache_option(tmp_path):
+    cache = tmp_path / "c"
+    cache.mkdir()
+    for _ in range(2):
+        rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS, "--profile=2", "--matrix-cache", str(cache), "--check")
+        assert rc == 0, err
+    assert len(os.listdir(cache)) == 1
