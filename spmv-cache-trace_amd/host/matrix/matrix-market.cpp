@@ -129,8 +129,11 @@ Header parse_header(std::string const & line)
 
 bool parse_i32(char const * b, char const * e, int32_t & out)
 {
-    if (b < e && *b == '+')
+    if (b < e && *b == '+') {
         ++b;
+        if (b < e && (*b == '+' || *b == '-'))
+            return false; // "+-1": one sign at most
+    }
     auto r = std::from_chars(b, e, out);
     return r.ec == std::errc() && r.ptr == e;
 }
@@ -156,8 +159,11 @@ Size parse_size(std::string const & line, Format format)
 
 bool parse_f64(char const * b, char const * e, double & out)
 {
-    if (b < e && *b == '+')
+    if (b < e && *b == '+') {
         ++b;
+        if (b < e && (*b == '+' || *b == '-'))
+            return false; // "+-0.5": one sign at most
+    }
     auto r = std::from_chars(b, e, out);
     if (r.ec == std::errc() && r.ptr == e)
         return true;

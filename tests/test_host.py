@@ -577,3 +577,16 @@ def test_cli_matrix_cache_option(tmp_path):
         rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS, "--profile=2", "--matrix-cache", str(cache), "--check")
         assert rc == 0, err
     assert len(os.listdir(cache)) == 1
+
+
+def test_loader_rejects_doubled_signs(host):
+    for bad in ("+-0.5", "++1.0", "+-1"):
+        field = "integer" if bad == "+-1" else "real"
+        with pytest.raises(Exception):
+            host.mm_from_text("%%MatrixMarket matrix coordinate " + field + " general\n2 2 1\n1 1 " + bad + "\n")
+    with pytest.raises(Exception):
+        host.mm_from_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n+-1 1 0.5\n")
+    h = host.mm_from_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n+1 +2 +0.5\n")
+    i, j, a = host.mm_entries(h)
+    assert (i[0], j[0], a[0]) == (1, 2, 0.5)
+    host.mm_free(h)

@@ -38,7 +38,8 @@ def _text(rows, cols, entries, field, symmetry, seed):
     for (i, j, a) in entries:
         toks += [("+" if rng.integers(4) == 0 else "") + str(i), str(j)]
         if field == "real":
-            toks.append(("+" if a >= 0 and rng.integers(4) == 0 else "") + repr(float(a)))
+            # (-0.0 >= 0 is true, and "+-0.0" is not a number)
+            toks.append(("+" if np.copysign(1.0, a) > 0 and rng.integers(4) == 0 else "") + repr(float(a)))
         elif field == "integer":
             toks.append(str(int(a) % 1000))
         elif field == "complex":
