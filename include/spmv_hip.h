@@ -183,7 +183,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [8] tiles with 16-bit column offsets (after spmv_hip_plan_csr_compress)
  *        [9] uniform tiles (all rows equally long: row_ptr not read)
  *        [10] shifted tiles (column offsets read for the first row only)
- *        [11] tiles whose column range fits a 256-entry window of x (x staged through LDS when most tiles qualify) */
+ *        [11] tiles whose column range fits a 256-entry window of x (x staged through LDS when most tiles qualify)
+ *        [12] tiles multiplied by the block-window kernel (x staged through LDS per 16 tiles) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

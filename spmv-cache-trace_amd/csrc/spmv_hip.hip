@@ -91,6 +91,9 @@ struct spmv_hip_plan {
     int shifted_tiles = 0;
     int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x, or with a window of runs
     int longest_tile_row = 0; // longest row inside a stream tile
+    int2 * d_blocks = nullptr; // block windows: {first column, slots} per 16 tiles (csr_blockwin_kernel)
+    int nblocks16 = 0;
+    int blockwin_tiles = 0;
     int32_t * d_patterns = nullptr; // shared window-of-runs layouts (kernels: kPatStride words each)
     int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
@@ -386,6 +389,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_col16);
     if (pl->d_patterns)
         (void) hipFree(pl->d_patterns);
+    if (pl->d_blocks)
+        (void) hipFree(pl->d_blocks);
     delete pl;
 }
 
@@ -405,7 +410,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     int * d_count = nullptr;
     unsigned long long * d_fp = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
-    int counts[3] = {0, 0, 0};
+    int counts[4] = {0, 0, 0, 0};
     hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
     if (e == hipSuccess && want_patterns) {
         e = hipMalloc((void **) &d_fp, (size_t) pl->ntiles * sizeof(unsigned long long));
@@ -482,6 +487,31 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->narrow_tiles = counts[0];
     pl->shifted_tiles = counts[1];
     pl->xwin_tiles = counts[2];
+    // block windows (x staged through LDS per 16 tiles) for what has no cheaper path: first count
+    // the tiles that would qualify, and only if they are the majority mark them
+    if (e == hipSuccess && pl->tile == 512 && pl->ntiles >= 4 * spmv::kBlockWinTiles
+        && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
+        const int nb = (pl->ntiles + spmv::kBlockWinTiles - 1) / spmv::kBlockWinTiles;
+        hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile, pl->d_tiles,
+                           pl->d_col16, (int2 *) nullptr, d_count, 0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess && 2 * (long long) counts[3] > pl->ntiles) {
+            e = hipMalloc((void **) &pl->d_blocks, (size_t) nb * sizeof(int2));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile,
+                                   pl->d_tiles, pl->d_col16, pl->d_blocks, d_count, 1);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) {
+                pl->nblocks16 = nb;
+                pl->blockwin_tiles = counts[3];
+                pl->meta_bytes += (size_t) nb * sizeof(int2);
+            }
+        }
+    }
     if (d_count)
         (void) hipFree(d_count);
     if (d_fp)
@@ -492,6 +522,11 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
         if (pl->d_patterns) {
             (void) hipFree(pl->d_patterns);
             pl->d_patterns = nullptr;
+        }
+        if (pl->d_blocks) {
+            (void) hipFree(pl->d_blocks);
+            pl->d_blocks = nullptr;
+            pl->nblocks16 = 0;
         }
         return fail_hip(e, "index compression");
     }
@@ -504,10 +539,10 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[12] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[13] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
-                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles};
-    for (int i = 0; i < n && i < 12; ++i)
+                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles};
+    for (int i = 0; i < n && i < 13; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -572,6 +607,11 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
 #undef SPMV_WT_C
 #undef SPMV_WT_X
 #undef SPMV_WT_LAUNCH
+            // the tiles marked for a block window were skipped above (only when the 16-bit column
+            // stream is valid for this column array, like the marks themselves)
+            if (c16 && pl->d_blocks)
+                hipLaunchKernelGGL((spmv::csr_blockwin_kernel<512>), dim3(pl->nblocks16), dim3(1024), 0, s, pl->ntiles,
+                                   pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
         }
         break;
     default:

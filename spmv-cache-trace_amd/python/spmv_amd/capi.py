@@ -256,10 +256,10 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(12, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 12))
+        out = np.zeros(13, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 13))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles"]
+                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

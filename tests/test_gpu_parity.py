@@ -974,3 +974,70 @@ def test_more_tile_shapes_than_patterns(oracle):
         if not (flags & capi.FLAG_NO_SHIFTED_TILES):
             assert info["shifted_tiles"] > 0.5 * info["row_blocks"]
         plan.close()
+
+
+def fem_like_matrix(rows, cols_spread, nblocks, seed, block=3):
+    """`nblocks` blocks of `block` consecutive columns per row, placed at random within
+    +-cols_spread of the diagonal: an unstructured band (finite-element-like)."""
+    rng = np.random.default_rng(seed)
+    cols = rows
+    starts = rng.integers(-cols_spread, cols_spread, size=(rows, nblocks), dtype=np.int64) + np.arange(rows, dtype=np.int64)[:, None]
+    cm = (starts[:, :, None] + np.arange(block, dtype=np.int64)[None, None, :]).reshape(rows, nblocks * block)
+    cm = np.clip(cm, 0, cols - 1)
+    cm.sort(axis=1)
+    p = (np.arange(rows + 1, dtype=np.int64) * (nblocks * block)).astype(np.int32)
+    return rows, cols, p, cm.reshape(-1).astype(np.int32), rng.uniform(-1.0, 1.0, size=cm.size)
+
+
+@pytest.mark.parametrize("case", ["fem81", "fem30_ragged", "mixed"])
+def test_block_window_kernel(oracle, case):
+    """Unstructured bands go through csr_blockwin_kernel (x staged in LDS per 16 tiles) when most
+    16-tile blocks qualify; the other tiles of the same matrix stay with csr_wavetile_kernel.
+    y must not depend on which kernel took a tile."""
+    import torch
+    if case == "fem81":
+        rows, cols, p, c, v = fem_like_matrix(20000, 2500, 27, seed=1)
+    elif case == "fem30_ragged":  # rows of different lengths: row_ptr is read
+        rows, cols, p0, c0, v0 = fem_like_matrix(30000, 1500, 10, seed=2)
+        rng = np.random.default_rng(3)
+        keep = rng.uniform(size=c0.size) < 0.8
+        lens = np.add.reduceat(keep.astype(np.int64), p0[:-1].astype(np.int64))
+        p = np.zeros(rows + 1, dtype=np.int32)
+        np.cumsum(lens, out=p[1:])
+        c, v = c0[keep], v0[keep]
+    else:  # a band, then rows with columns all over the matrix, then the band again
+        r1, cols, p1, c1, v1 = fem_like_matrix(12000, 2000, 27, seed=4)
+        r2, _, p2, c2, v2 = synth.random_uniform(3000, cols, 30, seed=5)
+        rows = r1 + r2 + r1
+        p = np.concatenate([p1, p1[-1] + p2[1:], p1[-1] + p2[-1] + p1[1:]]).astype(np.int32)
+        c = np.concatenate([c1, c2, c1])
+        v = np.concatenate([v1, v2, v1])
+    x = synth.x_vector(cols, seed=7)
+    y0 = synth.x_vector(rows, seed=8)
+    want = y0 + oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    ys = {}
+    for flags in (0, capi.FLAG_NO_X_WINDOW):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        info = plan.info()
+        if flags == 0:
+            assert info["blockwin_tiles"] > 0.5 * info["row_blocks"], info
+            if case == "mixed":
+                assert info["blockwin_tiles"] < info["row_blocks"]
+        else:
+            assert info["blockwin_tiles"] == 0
+        ty = torch.from_numpy(y0).to(dev)
+        for _ in range(2):  # accumulate twice: both launches of a multiply must have finished in order
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ys[flags] = ty.cpu().numpy()
+        plan.close()
+    want2 = want + (want - y0)
+    for flags, got in ys.items():
+        assert_close(got, want2, 2 * scale, what="%s flags %x" % (case, flags))
+    # the two kernels add a row's products in the same order with the same number of lanes
+    assert np.array_equal(ys[0].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))
