@@ -588,6 +588,10 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
+            // every tile belongs to the block-window kernel below: nothing for this launch to do
+            const bool all_blockwin = c16 && pl->d_blocks && pl->blockwin_tiles == pl->ntiles;
+            if (all_blockwin) {
+            } else
             // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants
             // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row
@@ -609,9 +613,18 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
 #undef SPMV_WT_LAUNCH
             // the tiles marked for a block window were skipped above (only when the 16-bit column
             // stream is valid for this column array, like the marks themselves)
-            if (c16 && pl->d_blocks)
-                hipLaunchKernelGGL((spmv::csr_blockwin_kernel<512>), dim3(pl->nblocks16), dim3(1024), 0, s, pl->ntiles,
-                                   pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
+            if (c16 && pl->d_blocks) {
+                if (pl->flags & 0x2000u) { // undocumented (tools/kernel_sweep.py): one workgroup per block, no sliding window
+                    hipLaunchKernelGGL((spmv::csr_blockwin_kernel<512>), dim3(pl->nblocks16), dim3(1024), 0, s, pl->ntiles,
+                                       pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
+                } else {
+                    // persistent workgroups, one per CU, each walking through consecutive blocks
+                    const int groups = std::min(pl->nblocks16, kCUs);
+                    const int per_group = (pl->nblocks16 + groups - 1) / groups;
+                    hipLaunchKernelGGL((spmv::csr_blockwin_stream_kernel<512>), dim3(groups), dim3(1024), 0, s, pl->ntiles,
+                                       pl->nblocks16, per_group, pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
+                }
+            }
         }
         break;
     default:

@@ -935,6 +935,219 @@ __global__ __launch_bounds__(1024) void csr_blockwin_kernel(
     }
 }
 
+// The same with persistent workgroups and a sliding window.  Consecutive blocks of a band need
+// almost the same columns (the window moves on by the block's rows), so a workgroup that walks
+// through consecutive blocks keeps x in a ring of 8192 LDS slots (slot = column mod 8192) and only
+// loads what is new; and because the next block's streams -- and that window increment -- are
+// requested before the current block is multiplied, something is always in flight although only
+// one workgroup fits a CU.  Two barriers per block: before the ring is written (the previous
+// block's gathers are done) and after.
+constexpr int kBlockRing = 8192;
+
+template <int QUADS>
+struct BwTile {
+    int r0, k0, kb, last, nrows, maxlen, lanes_log2, cbase;
+    int ps, pe, psB, peB;
+    double yv, yvB;
+    unsigned cx[QUADS], cy[QUADS];
+    v2d va[QUADS], vb[QUADS];
+    bool valid, second;
+};
+
+template <int TILE>
+__device__ __forceinline__ void bw_load_tile(
+    BwTile<TILE / 256> & t, int w, int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
+    const uint16_t * __restrict__ j16, const double * __restrict__ a, const double * __restrict__ y, int lane)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    constexpr int QUADS = TILE / 256;
+    t.valid = w < ntiles;
+    if (!t.valid)
+        return;
+    const int4 d0 = desc[w];
+    const int4 d1 = desc[w + 1];
+    const int meta = __builtin_amdgcn_readfirstlane(d0.z);
+    t.valid = (meta & kTileMetaBlockWin) != 0;
+    if (!t.valid)
+        return;
+    t.r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
+    t.k0 = __builtin_amdgcn_readfirstlane(d0.y);
+    t.cbase = __builtin_amdgcn_readfirstlane(d0.w);
+    const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
+    const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
+    t.maxlen = meta & 0xFFFF;
+    t.lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
+    t.nrows = r1 - t.r0;
+    t.kb = t.k0 & ~3;
+    t.last = (k1 - 1 - t.kb) & ~3;
+    const int sub = lane >> t.lanes_log2;
+    const int rowi = sub < t.nrows ? sub : t.nrows - 1;
+    const bool uniform = (meta & kTileMetaUniform) != 0;
+    if (uniform) {
+        t.ps = t.k0 + rowi * t.maxlen;
+        t.pe = t.ps + t.maxlen;
+    } else {
+        t.ps = p[t.r0 + rowi];
+        t.pe = p[t.r0 + rowi + 1];
+    }
+    t.yv = y[t.r0 + rowi];
+    t.second = t.nrows > kWave;
+    t.psB = t.peB = 0;
+    t.yvB = 0.0;
+    if (t.second) {
+        const int rowB = lane + kWave < t.nrows ? lane + kWave : t.nrows - 1;
+        if (uniform) {
+            t.psB = t.k0 + rowB * t.maxlen;
+            t.peB = t.psB + t.maxlen;
+        } else {
+            t.psB = p[t.r0 + rowB];
+            t.peB = p[t.r0 + rowB + 1];
+        }
+        t.yvB = y[t.r0 + rowB];
+    }
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < t.last ? o : t.last;
+        const v2u c = *reinterpret_cast<const v2u *>(j16 + t.kb + o);
+        t.cx[q] = c.x;
+        t.cy[q] = c.y;
+        t.va[q] = *reinterpret_cast<const v2d *>(a + t.kb + o);
+        t.vb[q] = *reinterpret_cast<const v2d *>(a + t.kb + o + 2);
+    }
+}
+
+template <int TILE>
+__device__ __forceinline__ void bw_compute_tile(
+    const BwTile<TILE / 256> & t, double * prod, const double * xring, double * __restrict__ y, int lane)
+{
+    constexpr int QUADS = TILE / 256;
+    const unsigned base = (unsigned) t.cbase;
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= t.last) {
+            // columns of the tile proper lie inside the ring's window; entries of neighbouring tiles
+            // that share a quad read some slot or other and are never summed
+            const unsigned c0 = (base + (t.cx[q] & 0xFFFFu)) & (kBlockRing - 1), c1 = (base + (t.cx[q] >> 16)) & (kBlockRing - 1);
+            const unsigned c2 = (base + (t.cy[q] & 0xFFFFu)) & (kBlockRing - 1), c3 = (base + (t.cy[q] >> 16)) & (kBlockRing - 1);
+            const double q0 = t.va[q].x * xring[c0];
+            const double q1 = t.va[q].y * xring[c1];
+            const double q2 = t.vb[q].x * xring[c2];
+            const double q3 = t.vb[q].y * xring[c3];
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = v2d{q0, q1};
+            dst[1] = v2d{q2, q3};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int sub = lane >> t.lanes_log2;
+    const int part = lane & ((1 << t.lanes_log2) - 1);
+    const int s = t.ps - t.kb, e_row = t.pe - t.kb;
+    double z;
+    if (t.lanes_log2 == 0) {
+        z = tile_row_sum<1>(prod, s, e_row, 0, t.maxlen);
+    } else {
+        const int trips = (t.maxlen + (1 << t.lanes_log2) - 1) >> t.lanes_log2;
+        switch (t.lanes_log2) {
+        case 1: z = tile_row_sum<2>(prod, s, e_row, part, trips); break;
+        case 2: z = tile_row_sum<4>(prod, s, e_row, part, trips); break;
+        case 3: z = tile_row_sum<8>(prod, s, e_row, part, trips); break;
+        case 4: z = tile_row_sum<16>(prod, s, e_row, part, trips); break;
+        case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
+        default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
+        }
+    }
+    if (sub < t.nrows && part == 0)
+        y[t.r0 + sub] = t.yv + z;
+    if (t.second) {
+        const double zB = tile_row_sum<1>(prod, t.psB - t.kb, t.peB - t.kb, 0, t.maxlen);
+        if (lane + kWave < t.nrows)
+            y[t.r0 + lane + kWave] = t.yvB + zB;
+    }
+    // the product slice is reused by this wave's next tile: its reads above come first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TILE>
+__global__ __launch_bounds__(1024) void csr_blockwin_stream_kernel(
+    int ntiles, int nblocks, int blocks_per_group, const int4 * __restrict__ desc, const int2 * __restrict__ blocks,
+    const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
+    const double * __restrict__ x, double * __restrict__ y)
+{
+    constexpr int XS = kBlockWinSlots / 1024; // window increments a thread may have to carry
+    __shared__ double xring[kBlockRing];
+    __shared__ __attribute__((aligned(16))) double prod_all[kBlockWinTiles][TILE + 4];
+    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    const int lane = (int) __lane_id();
+    const int tid = (int) threadIdx.x;
+    double * prod = prod_all[wave];
+    const int b_begin = (int) blockIdx.x * blocks_per_group;
+    const int b_end = min(nblocks, b_begin + blocks_per_group);
+    if (b_begin >= b_end)
+        return;
+
+    int wlo = 0, whi = 0; // columns [wlo, whi) are in the ring (wave-uniform)
+    BwTile<TILE / 256> cur, nxt;
+    double xs[XS];
+    int xs_from = 0, xs_hi = 0, xs_lo = 0; // the increment carried in xs belongs to window [xs_lo, xs_hi)
+    // prologue: the first block's streams and its whole window
+    {
+        const int2 bd = blocks[b_begin];
+        const int span = __builtin_amdgcn_readfirstlane(bd.y);
+        xs_lo = xs_from = __builtin_amdgcn_readfirstlane(bd.x);
+        xs_hi = xs_lo + (span > 0 ? span : 0);
+        bw_load_tile<TILE>(nxt, b_begin * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y, lane);
+#pragma unroll
+        for (int k = 0; k < XS; ++k) {
+            const int i = xs_from + tid + 1024 * k;
+            xs[k] = i < xs_hi ? x[i] : 0.0;
+        }
+    }
+    for (int b = b_begin; b < b_end; ++b) {
+        cur = nxt;
+        const bool window = xs_hi > xs_lo; // this block has a window
+        __syncthreads(); // the previous block's gathers are done: ring slots may be overwritten
+        if (window) {
+#pragma unroll
+            for (int k = 0; k < XS; ++k) {
+                const int i = xs_from + tid + 1024 * k;
+                if (i < xs_hi)
+                    xring[i & (kBlockRing - 1)] = xs[k];
+            }
+            wlo = xs_lo;
+            whi = xs_hi;
+        } else {
+            wlo = whi = 0;
+        }
+        __syncthreads();
+        // requests for the next block: its tiles' streams and what its window adds to the ring
+        if (b + 1 < b_end) {
+            const int2 bd = blocks[b + 1];
+            const int span = __builtin_amdgcn_readfirstlane(bd.y);
+            xs_lo = __builtin_amdgcn_readfirstlane(bd.x);
+            xs_hi = xs_lo + (span > 0 ? span : 0);
+            // columns already in the ring stay valid if the new window starts inside the old one
+            xs_from = (whi > wlo && xs_lo >= wlo && xs_lo <= whi) ? max(whi, xs_lo) : xs_lo;
+            bw_load_tile<TILE>(nxt, (b + 1) * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y, lane);
+#pragma unroll
+            for (int k = 0; k < XS; ++k) {
+                const int i = xs_from + tid + 1024 * k;
+                xs[k] = i < xs_hi ? x[i] : 0.0;
+            }
+        } else {
+            nxt.valid = false;
+            xs_lo = xs_hi = xs_from = 0;
+        }
+        if (window && cur.valid)
+            bw_compute_tile<TILE>(cur, prod, xring, y, lane);
+    }
+}
+
 // Plan-time: one workgroup per 16 consecutive tiles.  The block gets a window if every tile is a
 // plain narrow fast tile (no shifted tile, no per-tile window: those are cheaper), the union of
 // their column ranges fits kBlockWinSlots and has at least as many entries as slots.  With

@@ -1020,11 +1020,11 @@ def test_block_window_kernel(oracle, case):
     tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
     stream = torch.cuda.current_stream().cuda_stream
     ys = {}
-    for flags in (0, capi.FLAG_NO_X_WINDOW):
+    for flags in (0, 0x2000, capi.FLAG_NO_X_WINDOW):  # 0x2000: the one-workgroup-per-block variant
         plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
         plan.compress(tc.data_ptr(), stream)
         info = plan.info()
-        if flags == 0:
+        if flags != capi.FLAG_NO_X_WINDOW:
             assert info["blockwin_tiles"] > 0.5 * info["row_blocks"], info
             if case == "mixed":
                 assert info["blockwin_tiles"] < info["row_blocks"]
@@ -1041,3 +1041,4 @@ def test_block_window_kernel(oracle, case):
         assert_close(got, want2, 2 * scale, what="%s flags %x" % (case, flags))
     # the two kernels add a row's products in the same order with the same number of lanes
     assert np.array_equal(ys[0].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))
+    assert np.array_equal(ys[0x2000].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))

@@ -88,6 +88,7 @@ def main():
         "wavetile_c16_noshift_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_ROWS128 | 0x100000),
         "wavetile_c16_noxwin": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | 0x100000),
         "wavetile_c16_noxwin_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | capi.FLAG_NO_SHIFTED_TILES | 0x100000),
+        "wavetile_c16_blockwin_simple": (capi.CSR_WAVETILE, 0, 0x2000 | 0x100000),
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
         "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
         "wavetile_c16_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP | 0x100000),
