@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 // whose tiles have no cheaper path are marked (csr_blockwin_mark_kernel), and the kernel is
 // only launched when they are the majority; csr_wavetile_kernel skips the marked tiles.
 // ---------------------------------------------------------------------------------
-constexpr int kBlockWinSlots = 6144; // doubles
+constexpr int kBlockWinSlots = 8192; // doubles (the ring of csr_blockwin_stream_kernel)
 constexpr int kBlockWinTiles = 16;
 
 template <int TILE>
