@@ -1042,3 +1042,52 @@ def test_block_window_kernel(oracle, case):
     # the two kernels add a row's products in the same order with the same number of lanes
     assert np.array_equal(ys[0].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))
     assert np.array_equal(ys[0x2000].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))
+
+
+def test_block_window_long_walks(oracle):
+    """Enough blocks that every persistent workgroup walks through many of them (sliding ring,
+    increments only, many wrap-arounds), with a few rows of scattered columns in between that break
+    the walk (blocks without a window: ring invalidated, reloaded afterwards)."""
+    import torch
+    r1, cols, p1, c1, v1 = fem_like_matrix(400000, 3500, 9, seed=11)
+    # every 40000th row block gets 200 rows with columns all over the matrix
+    parts_p, parts_c, parts_v, rows = [np.zeros(1, dtype=np.int64)], [], [], 0
+    rng = np.random.default_rng(12)
+    for b in range(10):
+        lo, hi = b * 40000, (b + 1) * 40000
+        k0, k1 = int(p1[lo]), int(p1[hi])
+        parts_p.append(p1[lo + 1:hi + 1].astype(np.int64) - k0 + parts_p[-1][-1])
+        parts_c.append(c1[k0:k1])
+        parts_v.append(v1[k0:k1])
+        rows += hi - lo
+        if b % 3 == 1:
+            rr, _, pr, cr, vr = synth.random_uniform(200, cols, 20, seed=100 + b)
+            parts_p.append(pr[1:].astype(np.int64) + parts_p[-1][-1])
+            parts_c.append(cr)
+            parts_v.append(vr)
+            rows += rr
+    p = np.concatenate(parts_p).astype(np.int32)
+    c = np.concatenate(parts_c).astype(np.int32)
+    v = np.concatenate(parts_v)
+    assert len(p) == rows + 1 and p[-1] == len(c)
+    x = synth.x_vector(cols, seed=13)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=8)
+    scale = abs_products(rows, p, c, v, x)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    ys = []
+    for flags in (0, capi.FLAG_NO_X_WINDOW):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        info = plan.info()
+        if flags == 0:
+            assert 0.9 * info["row_blocks"] < info["blockwin_tiles"] < info["row_blocks"], info
+            assert info["row_blocks"] > 16 * 256 * 4  # several blocks per workgroup
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ys.append(ty.cpu().numpy())
+        plan.close()
+        assert_close(ys[-1], want, scale, what="long walk flags %x" % flags)
+    assert np.array_equal(ys[0].view(np.uint64), ys[1].view(np.uint64))
