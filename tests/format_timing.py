@@ -1,0 +1,28 @@
+"""Ad-hoc timing of the context-level CSR / COO / hybrid paths on a power-law matrix (webbase-like,
+BASELINE configs[4]); builds the hybrid layout with the oracle, hence lives under tests/."""
+import sys, os, time
+import numpy as np
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_py
+from spmv_amd import capi, synth
+O = oracle_py.Oracle()
+rows, cols, p, c, v = synth.powerlaw(1000005, 1000005, seed=4)
+i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+H = O.hybrid_from_coordinate(rows, i, j, a)
+print("hybrid: L=%d ell entries %d coo entries %d" % (H["row_length"], rows * H["row_length"], len(H["coo_val"])))
+x = synth.x_vector(cols)
+ctx = capi.Context(0)
+def timeit(n=50):
+    ts = []
+    for _ in range(n):
+        ctx.run(); ts.append(ctx.last_run_ns())
+    return np.median(ts) / 1e3
+ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"]); ctx.set_x(x)
+print("hip-hybrid median %.1f us" % timeit())
+r = (i - 1).astype(np.int32)
+ctx.upload_coo(rows, cols, r, (j - 1).astype(np.int32), a); ctx.set_x(x)
+print("hip-coo    median %.1f us" % timeit())
+ctx.upload_csr(rows, cols, p, c, v); ctx.set_x(x)
+print("hip-csr    median %.1f us" % timeit())
+ctx.close()
