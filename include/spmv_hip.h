@@ -73,9 +73,10 @@ extern "C" {
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
-#define SPMV_HIP_FLAG_NO_X_WINDOW 0x800u /* wavetile: never stage x through LDS.  Default after plan_csr_compress: when most
-                                            tiles' columns span < 256 (narrow bands) each tile reads its window of x once,
-                                            coalesced, into LDS instead of gathering it */
+#define SPMV_HIP_FLAG_NO_X_WINDOW 0x800u /* wavetile: never stage x through LDS.  Default after plan_csr_compress: per-wave
+                                            windows where most tiles' x entries fit 256 slots and are used twice (narrow
+                                            bands, stencils), and a per-workgroup ring for unstructured bands whose 16-tile
+                                            blocks span <= 8192 columns (a second kernel launch per multiply) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -173,7 +174,8 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  *    stream (2 extra bytes per entry of device memory); the tile reads 10 instead of 12 bytes/entry;
  *  - equally long rows that repeat the first row's columns shifted by the row distance (stencil
  *    interiors, bands; any column range): only the first row's columns are read, 8 bytes/entry;
- *  - tiles whose x entries fit 256 LDS slots and are each used at least twice: x staged through LDS.
+ *  - tiles whose x entries fit 256 LDS slots and are each used at least twice: x staged through LDS;
+ *  - blocks of 16 plain narrow tiles whose columns span <= 8192: marked for the block-window kernel.
  * Results are unchanged bit for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
  * pointer silently falls back to the 32-bit indices).  Synchronises `stream`. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
