@@ -1091,3 +1091,28 @@ def test_block_window_long_walks(oracle):
         plan.close()
         assert_close(ys[-1], want, scale, what="long walk flags %x" % flags)
     assert np.array_equal(ys[0].view(np.uint64), ys[1].view(np.uint64))
+
+
+def test_block_window_plan_with_another_column_array(oracle):
+    """The tile marks belong to the column array the plan was compressed from; with any other array
+    the wave-tile kernel must take every tile itself (32-bit columns), marked or not."""
+    import torch
+    rows, cols, p, c, v = fem_like_matrix(20000, 2500, 27, seed=21)
+    x = synth.x_vector(cols, seed=22)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    tc2 = tc.clone()
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE)
+    plan.compress(tc.data_ptr(), stream)
+    assert plan.info()["blockwin_tiles"] > 0
+    outs = []
+    for cols_ptr in (tc.data_ptr(), tc2.data_ptr()):
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), cols_ptr, tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        outs.append(ty.cpu().numpy())
+        assert_close(outs[-1], want, abs_products(rows, p, c, v, x), what="column array %d" % len(outs))
+    assert np.array_equal(outs[0].view(np.uint64), outs[1].view(np.uint64))
+    plan.close()
