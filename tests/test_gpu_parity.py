@@ -1116,3 +1116,54 @@ def test_block_window_plan_with_another_column_array(oracle):
         assert_close(outs[-1], want, abs_products(rows, p, c, v, x), what="column array %d" % len(outs))
     assert np.array_equal(outs[0].view(np.uint64), outs[1].view(np.uint64))
     plan.close()
+
+
+def test_many_small_random_structures(ctx, oracle):
+    """300 small matrices with random shapes, row-length laws (empty rows, rows longer than a tile),
+    column laws (anywhere, banded, runs, duplicates) and UNSORTED columns inside rows, through the
+    context API: whatever the classifier makes of them, y must match the oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(300):
+        rows = int(rng.integers(1, 400))
+        cols = int(rng.integers(1, 70000)) if trial % 5 == 0 else int(rng.integers(1, 500))
+        law = trial % 6
+        if law == 0:
+            lens = rng.integers(0, 12, size=rows)
+        elif law == 1:
+            lens = np.full(rows, int(rng.integers(1, 40)))
+        elif law == 2:
+            lens = rng.integers(0, 3, size=rows)
+            lens[rng.integers(0, rows)] = int(rng.integers(513, 3000))
+        elif law == 3:
+            lens = rng.geometric(0.15, size=rows) - 1
+        elif law == 4:
+            lens = np.full(rows, int(rng.integers(1, 9)))
+        else:
+            lens = rng.integers(0, 200, size=rows)
+        p = np.zeros(rows + 1, dtype=np.int32)
+        np.cumsum(lens, out=p[1:])
+        n = int(p[-1])
+        r_of = np.repeat(np.arange(rows), lens)
+        mode = (trial // 6) % 4
+        if mode == 0:
+            c = rng.integers(0, cols, size=n)
+        elif mode == 1:  # banded around the diagonal
+            c = np.clip(r_of * cols // max(rows, 1) + rng.integers(-20, 21, size=n), 0, cols - 1)
+        elif mode == 2:  # shifted pattern where lengths allow, else random
+            k_in_row = np.arange(n) - np.repeat(p[:-1], lens)
+            c = np.clip(r_of + 3 * k_in_row, 0, cols - 1)
+        else:  # few distinct columns: many duplicates
+            c = rng.integers(0, min(cols, 4), size=n)
+        c = c.astype(np.int32)
+        if mode != 2 and trial % 2:  # sort inside rows half of the time
+            order = np.lexsort((c, r_of))
+            c = c[order]
+        v = rng.uniform(-1, 1, size=n)
+        x = rng.uniform(-1, 1, size=cols)
+        y0 = rng.uniform(-1, 1, size=rows)
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0)
+        got = gpu_csr(ctx, rows, cols, p, c, v, x, y0=y0, algo=capi.CSR_WAVETILE)
+        scale = np.zeros(rows)
+        np.add.at(scale, r_of, np.abs(v) * np.abs(x[c]))
+        assert_close(got, want, scale + np.abs(y0), what="trial %d (law %d mode %d rows %d cols %d nnz %d)" % (
+            trial, law, mode, rows, cols, n))
