@@ -1167,3 +1167,49 @@ def test_many_small_random_structures(ctx, oracle):
         np.add.at(scale, r_of, np.abs(v) * np.abs(x[c]))
         assert_close(got, want, scale + np.abs(y0), what="trial %d (law %d mode %d rows %d cols %d nnz %d)" % (
             trial, law, mode, rows, cols, n))
+
+
+def test_many_small_random_structures_other_formats(ctx, oracle):
+    """The same idea for COO (file order shuffled), ELLPACK and hybrid, 120 matrices."""
+    rng = np.random.default_rng(77)
+    for trial in range(120):
+        rows = int(rng.integers(1, 300))
+        cols = int(rng.integers(1, 400))
+        lens = rng.integers(0, 30, size=rows) if trial % 3 else rng.geometric(0.2, size=rows) - 1
+        lens = np.minimum(lens, cols)
+        lens[0] = max(1, lens[0])  # the reference's ELL converter needs a non-empty first row
+        if lens.sum() == 0:
+            lens[0] = 1
+        i = np.repeat(np.arange(1, rows + 1), lens).astype(np.int32)
+        j = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) + 1 for n in lens]).astype(np.int32)
+        a = rng.uniform(-1, 1, size=len(i))
+        x = rng.uniform(-1, 1, size=cols)
+        y0 = rng.uniform(-1, 1, size=rows)
+        scale = np.zeros(rows)
+        np.add.at(scale, i - 1, np.abs(a) * np.abs(x[j - 1]))
+        scale += np.abs(y0)
+        what = "trial %d rows %d cols %d nnz %d" % (trial, rows, cols, len(i))
+        # COO, shuffled
+        perm = rng.permutation(len(i))
+        r0, c0, v0 = (i[perm] - 1).astype(np.int32), (j[perm] - 1).astype(np.int32), a[perm]
+        ctx.upload_coo(rows, cols, r0, c0, v0)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), oracle.coo_spmv(rows, r0, c0, v0, x, y=y0), scale, what="coo " + what)
+        # ELLPACK: bit-exact
+        rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+        assert rc == 0
+        ctx.upload_ell(rows, cols, L, ec, ev)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_bitexact(ctx.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0), "ell " + what)
+        # hybrid
+        H = oracle.hybrid_from_coordinate(rows, i, j, a)
+        ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        want = oracle.hybrid_spmv(rows, H, x, y=y0)
+        assert_close(ctx.get_y(), want, scale, what="hybrid " + what)
