@@ -77,6 +77,7 @@ extern "C" {
                                             windows where most tiles' x entries fit 256 slots and are used twice (narrow
                                             bands, stencils), and a per-workgroup ring for unstructured bands whose 16-tile
                                             blocks span <= 8192 columns (a second kernel launch per multiply) */
+#define SPMV_HIP_FLAG_NO_COLUMN_PANELS 0x1000u /* plan_csr_repack / upload_csr: never form column panels */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -179,6 +180,18 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  * Results are unchanged bit for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
  * pointer silently falls back to the 32-bit indices).  Synchronises `stream`. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
+/* Optional third planning step (done automatically by spmv_hip_upload_csr), after
+ * spmv_hip_plan_csr_compress: for a matrix whose columns are scattered (most tiles neither narrow
+ * nor shifted), with at least 12 entries per row and an x larger than one XCD's L2, the plan makes its
+ * own copy of the matrix cut into 8 column panels -- one per group of workgroups that share an XCD --
+ * so that every XCD gathers from one eighth of x out of its private L2; a row's partial sums are
+ * added to y with fp64 atomics (order not reproducible; within the usual tolerance).  The copy is
+ * used by spmv_hip_csr_spmv when it is called with the same d_column_index and d_value; the VALUES
+ * ARE SNAPSHOTTED: after changing them call spmv_hip_plan_csr_repack on a fresh plan, or pass
+ * SPMV_HIP_FLAG_NO_COLUMN_PANELS.  Does nothing (returns 0) when the matrix does not qualify;
+ * plan_info[13] tells.  Costs 12 bytes per entry + 32 bytes per row of device memory.  Synchronises. */
+int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
+                             const double *d_value, void *stream);
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);
 /* out[]: [0] algorithm  [1] lanes per row  [2] workgroups  [3] row blocks
  *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device
@@ -186,7 +199,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [9] uniform tiles (all rows equally long: row_ptr not read)
  *        [10] shifted tiles (column offsets read for the first row only)
  *        [11] tiles whose column range fits a 256-entry window of x (x staged through LDS when most tiles qualify)
- *        [12] tiles multiplied by the block-window kernel (x staged through LDS per 16 tiles) */
+ *        [12] tiles multiplied by the block-window kernel (x staged through LDS per 16 tiles)
+ *        [13] tiles of the column-panel copy (0 = no panels; see spmv_hip_plan_csr_repack) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

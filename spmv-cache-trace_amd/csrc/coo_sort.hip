@@ -89,3 +89,20 @@ extern "C" int spmv_hip_coo_sort_by_row(int32_t rows, int32_t nnz, int32_t * d_r
             (void) hipFree(p);
     return e == hipSuccess ? SPMV_HIP_OK : spmv_hip_internal_fail_hip(e, "COO sort by row");
 }
+
+
+// Exclusive prefix sum of n int32 values (column panels: counts -> virtual row pointers).
+extern "C" int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s)
+{
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    void * temp = nullptr;
+    size_t temp_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_in, d_out, (int) n, s);
+    if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, d_in, d_out, (int) n, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (temp)
+        (void) hipFree(temp);
+    return e == hipSuccess ? SPMV_HIP_OK : SPMV_HIP_ERR_HIP;
+}

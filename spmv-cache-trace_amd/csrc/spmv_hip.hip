@@ -91,6 +91,15 @@ struct spmv_hip_plan {
     int shifted_tiles = 0;
     int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x, or with a window of runs
     int longest_tile_row = 0; // longest row inside a stream tile
+    // column panels: the plan's own panel-major copy of the matrix, multiplied through `inner`
+    spmv_hip_plan * inner = nullptr;     // plan of the 8 * rows virtual rows
+    int32_t * d_vrow_ptr = nullptr;      // [8 * rows + 1]
+    int32_t * d_pcol = nullptr;          // [nnz]
+    double * d_pval = nullptr;           // [nnz]
+    const int32_t * panels_from_col = nullptr; // the arrays the copy was made from
+    const double * panels_from_val = nullptr;
+    spmv::PanelInfo pinfo{};
+    int panel_blocks = 0;                // workgroups per panel (grid = 8 * panel_blocks)
     int2 * d_blocks = nullptr; // block windows: {first column, slots} per 16 tiles (csr_blockwin_kernel)
     int nblocks16 = 0;
     int blockwin_tiles = 0;
@@ -218,8 +227,19 @@ int spmv_hip_device_count(int * count)
 
 /* ================================ Level 2 ======================================= */
 
+static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
+                             int algorithm, int lanes_per_row, unsigned flags, int32_t break_rows);
+
 int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
                       int algorithm, int lanes_per_row, unsigned flags)
+{
+    return plan_csr_internal(out, rows, cols, p, algorithm, lanes_per_row, flags, 0);
+}
+
+// break_rows > 0: no tile may contain a row index that is a multiple of break_rows except as its
+// first row (column panels: tiles stay inside one panel)
+static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
+                             int algorithm, int lanes_per_row, unsigned flags, int32_t break_rows)
 {
     if (!out)
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
@@ -267,7 +287,11 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
         std::vector<int4> desc;
         desc.reserve((size_t) rows / 48 + 16);
         int32_t r = 0;
+        int next_panel = 0;
         while (r < rows) {
+            if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
+                while (next_panel <= 8 && next_panel <= r / break_rows)
+                    pl->pinfo.first[next_panel++] = (int) desc.size();
             const int32_t kb = p[r] & ~3;
             int32_t r1 = r;
             int32_t maxlen = 0, minlen = INT32_MAX;
@@ -287,6 +311,8 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 return l;
             };
             while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
+                if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
+                    break;
                 const int len = p[r1 + 1] - p[r1];
                 if (!exact && r1 > r) {
                     const int l = lanes_for(std::max(maxlen, len));
@@ -322,6 +348,11 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             r = r1;
         }
         pl->ntiles = (int) desc.size();
+        if (break_rows > 0) {
+            while (next_panel <= 8)
+                pl->pinfo.first[next_panel++] = pl->ntiles;
+            pl->pinfo.rows = break_rows;
+        }
         desc.push_back(make_int4(rows, p[rows], 0, 0));
         pl->nblk = pl->ntiles;
         pl->workgroups = (pl->ntiles + 3) / 4;
@@ -391,6 +422,14 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_patterns);
     if (pl->d_blocks)
         (void) hipFree(pl->d_blocks);
+    if (pl->inner)
+        spmv_hip_plan_destroy(pl->inner);
+    if (pl->d_vrow_ptr)
+        (void) hipFree(pl->d_vrow_ptr);
+    if (pl->d_pcol)
+        (void) hipFree(pl->d_pcol);
+    if (pl->d_pval)
+        (void) hipFree(pl->d_pval);
     delete pl;
 }
 
@@ -535,14 +574,95 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     return SPMV_HIP_OK;
 }
 
+// defined in coo_sort.hip (hipCUB): out[i] = sum of in[0..i), n elements
+int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
+
+int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                             const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->inner)
+        return fail(SPMV_HIP_ERR_STATE, "plan is already repacked");
+    // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
+    // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
+    const bool scattered = 2 * (long long) pl->narrow_tiles < pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->rows < 1024
+        || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
+        || !pl->d_col16 /* not compressed: the tile classes are unknown */ || !scattered
+        || (long long) pl->cols * 8 < 3 * 1024 * 1024 || (long long) pl->nnz < 12LL * pl->rows
+        || (long long) pl->rows * 8 + 1 > 0x7FFFFFF0LL)
+        return SPMV_HIP_OK;
+    if (!d_row_ptr || !d_column_index || !d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int32_t rows = pl->rows;
+    const long long vrows = 8LL * rows;
+    const int width = (pl->cols + 7) / 8;
+    int32_t * d_count = nullptr;
+    hipError_t e = hipMalloc((void **) &d_count, (size_t) (vrows + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vrow_ptr, (size_t) (vrows + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_pcol, (size_t) pl->nnz * sizeof(int32_t) + 64);
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_pval, (size_t) pl->nnz * sizeof(double) + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count + vrows, 0, sizeof(int32_t), s);
+    std::vector<int32_t> vrow_ptr;
+    int rc = SPMV_HIP_OK;
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned) ((rows + 255) / 256);
+        hipLaunchKernelGGL(spmv::csr_panel_count_kernel, dim3(grid), dim3(256), 0, s, rows, width, d_row_ptr, d_column_index, d_count);
+        e = hipGetLastError();
+        if (e == hipSuccess && spmv_hip_internal_exclusive_scan_i32(d_count, pl->d_vrow_ptr, vrows + 1, s) != 0)
+            e = hipErrorUnknown;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::csr_panel_scatter_kernel, dim3(grid), dim3(256), 0, s, rows, width, d_row_ptr, d_column_index,
+                               d_value, pl->d_vrow_ptr, pl->d_pcol, pl->d_pval);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            vrow_ptr.resize((size_t) vrows + 1);
+            e = hipMemcpyAsync(vrow_ptr.data(), pl->d_vrow_ptr, vrow_ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (d_count)
+        (void) hipFree(d_count);
+    if (e == hipSuccess && vrow_ptr.back() != pl->nnz)
+        rc = fail(SPMV_HIP_ERR_INVALID, "column index out of range while forming column panels");
+    if (e == hipSuccess && rc == SPMV_HIP_OK) {
+        // the panel-major matrix is a CSR matrix of 8 * rows virtual rows: plan and classify it like any other
+        // (no x windows: its kernel variant has none)
+        rc = plan_csr_internal(&pl->inner, (int32_t) vrows, pl->cols, vrow_ptr.data(), SPMV_HIP_CSR_WAVETILE, 0,
+                               (pl->flags | SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_NO_COLUMN_PANELS) & ~SPMV_HIP_FLAG_ROWS128, rows);
+        if (rc == SPMV_HIP_OK)
+            rc = spmv_hip_plan_csr_compress(pl->inner, pl->d_pcol, stream);
+    }
+    if (e != hipSuccess || rc != SPMV_HIP_OK) {
+        if (pl->inner) { spmv_hip_plan_destroy(pl->inner); pl->inner = nullptr; }
+        if (pl->d_vrow_ptr) { (void) hipFree(pl->d_vrow_ptr); pl->d_vrow_ptr = nullptr; }
+        if (pl->d_pcol) { (void) hipFree(pl->d_pcol); pl->d_pcol = nullptr; }
+        if (pl->d_pval) { (void) hipFree(pl->d_pval); pl->d_pval = nullptr; }
+        return e != hipSuccess ? fail_hip(e, "column panels") : rc;
+    }
+    pl->pinfo = pl->inner->pinfo;
+    int most = 0;
+    for (int k = 0; k < 8; ++k)
+        most = std::max(most, pl->pinfo.first[k + 1] - pl->pinfo.first[k]);
+    pl->panel_blocks = (most + 3) / 4;
+    pl->panels_from_col = d_column_index;
+    pl->panels_from_val = d_value;
+    pl->meta_bytes += (size_t) (vrows + 1) * sizeof(int32_t) + (size_t) pl->nnz * 12 + pl->inner->meta_bytes;
+    return SPMV_HIP_OK;
+}
+
 int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[13] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[14] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
-                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles};
-    for (int i = 0; i < n && i < 13; ++i)
+                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
+                           pl->inner ? pl->inner->ntiles : 0};
+    for (int i = 0; i < n && i < 14; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -575,7 +695,20 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         }
         break;
     case SPMV_HIP_CSR_WAVETILE:
-        if (pl->ntiles > 0) {
+        if (pl->inner && pl->panels_from_col == j && pl->panels_from_val == a && pl->panel_blocks > 0) {
+            // column panels: the plan's panel-major copy, one panel per XCD label, atomic partial sums
+            const spmv_hip_plan * in = pl->inner;
+            const bool x32 = pl->cols < (1 << 29);
+            const dim3 grid((unsigned) (8 * pl->panel_blocks));
+            if (x32)
+                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, true>), grid, dim3(256), 0, s, in->ntiles,
+                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, pl->nnz, pl->cols, 0,
+                                   in->d_patterns, pl->pinfo);
+            else
+                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, true>), grid, dim3(256), 0, s, in->ntiles,
+                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, pl->nnz, pl->cols, 0,
+                                   in->d_patterns, pl->pinfo);
+        } else if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
             // the 16-bit index stream is only valid for the column array it was derived from
@@ -584,7 +717,7 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             const bool x32 = pl->cols < (1 << 29);
 #define SPMV_WT_LAUNCH(T, C, X, R)                                                                    \
     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X, R>), dim3(pl->workgroups), dim3(256), 0, s, \
-                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns)
+                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{})
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
             const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
@@ -598,11 +731,11 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
                 && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
-                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
+                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
             } else if (abl && c16 && x32 && pl->tile == 512) {
-                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
-                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
-                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns);
+                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
             } else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
             } else {
@@ -851,6 +984,9 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
         if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
+        // scattered columns and an x that does not fit one XCD's L2: column panels (the context owns
+        // the arrays, so the snapshot of the values cannot go stale)
+        if ((rc = spmv_hip_plan_csr_repack(c->plan, c->d_ptr, c->d_col, c->d_val, c->stream)) != 0) return rc;
     }
     c->format = 1;
     return SPMV_HIP_OK;

@@ -603,12 +603,24 @@ __device__ __forceinline__ void tile_products_xseg(
 
 // ABL: timing experiments that switch parts of the work off (results are wrong by design):
 // 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0>
+// Column panels (kernel variant PANELS): the matrix handed to the kernel is the plan's own copy, cut
+// into 8 column panels and stored panel by panel, "row" v = panel * rows + r holding row r's
+// entries of that panel.  Workgroups b, b + 8, b + 16, ... share an XCD (observed dispatch order,
+// used for speed only), so workgroup b works on panel b % 8: every XCD then gathers from one eighth
+// of x, which stays in its private 4 MB L2, instead of dragging all of x through it (2 M rows x 24
+// random columns: 694 us with x = 16 MB, 270 us with x = 2 MB).  A row's eight partial sums meet in
+// y through fp64 atomics.
+struct PanelInfo {
+    int first[9]; // tiles [first[k], first[k+1]) belong to panel k
+    int rows;     // rows of the matrix (= virtual rows per panel)
+};
+
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false>
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
-    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y,
-    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns)
+    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y_arg,
+    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo)
 {
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
@@ -617,9 +629,19 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
-    const int w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
-    if (w >= ntiles)
-        return; // whole wave leaves; no workgroup barrier anywhere in this kernel
+    int w;
+    double * __restrict__ y = y_arg;
+    if (PANELS) {
+        const int pk = (int) blockIdx.x & 7;
+        w = pinfo.first[pk] + ((int) blockIdx.x >> 3) * 4 + wave;
+        if (w >= pinfo.first[pk + 1])
+            return;
+        y = y_arg - (size_t) pk * (size_t) pinfo.rows; // virtual row v of panel pk is row v - pk * rows
+    } else {
+        w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
+        if (w >= ntiles)
+            return; // whole wave leaves; no workgroup barrier anywhere in this kernel
+    }
     double * prod = prod_all[wave];
 
     const int4 d0 = desc[w];
@@ -658,7 +680,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             ps = pt[rowi];
             pe = pt[rowi + 1];
         }
-        const double yv = yt[rowi];
+        const double yv = PANELS ? 0.0 : yt[rowi]; // panels: the partial sums are added atomically
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
         const bool second = nrows > kWave; // wave-uniform; implies one lane per row
         int psB = 0, peB = 0;
@@ -672,7 +694,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 psB = p[r0 + rowB];
                 peB = p[r0 + rowB + 1];
             }
-            yvB = yt[rowB];
+            if (!PANELS)
+                yvB = yt[rowB];
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
@@ -728,12 +751,20 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
             }
         }
-        if (sub < nrows && part == 0)
-            yt[sub] = yv + z;
+        if (sub < nrows && part == 0) {
+            if (PANELS)
+                unsafeAtomicAdd(yt + sub, z);
+            else
+                yt[sub] = yv + z;
+        }
         if (second) {
             const double zB = (ABL & 2) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
-            if (lane + kWave < nrows)
-                yt[lane + kWave] = yvB + zB;
+            if (lane + kWave < nrows) {
+                if (PANELS)
+                    unsafeAtomicAdd(yt + lane + kWave, zB);
+                else
+                    yt[lane + kWave] = yvB + zB;
+            }
         }
     } else if (!partial && k1 - kb <= TILE) {
         // ---- stream tile at the ragged end of the arrays, or a tile of empty rows: scalar
@@ -748,7 +779,10 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             double z = 0.0;
             for (int k = s; k < e_row; ++k)
                 z += prod[k];
-            y[r0 + r] += z;
+            if (PANELS)
+                unsafeAtomicAdd(y + r0 + r, z);
+            else
+                y[r0 + r] += z;
         }
     } else if (!exact_order) {
         // ---- one long row, or one chunk of a very long row: the wave strides it ----------
@@ -766,7 +800,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             z0 += a[k] * x[j[k]];
         double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
         if (lane == 0) {
-            if (partial)
+            if (partial || PANELS)
                 unsafeAtomicAdd(y + r0, z);
             else
                 y[r0] += z;
@@ -788,8 +822,58 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (lane == 0)
-            y[r0] += z;
+        if (lane == 0) {
+            if (PANELS)
+                unsafeAtomicAdd(y + r0, z);
+            else
+                y[r0] += z;
+        }
+    }
+}
+
+// Plan-time kernels of the column panels.  csr_panel_count_kernel: entries of row r in panel k
+// -> count[k * rows + r] (one thread per row); after an exclusive scan over the 8 * rows counts,
+// csr_panel_scatter_kernel copies every entry to its panel's place, rows in order, entries of a
+// row in their original order.
+__global__ __launch_bounds__(256) void csr_panel_count_kernel(
+    int rows, int width, const int32_t * __restrict__ p, const int32_t * __restrict__ j, int32_t * __restrict__ count)
+{
+    const long long r = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows)
+        return;
+    int n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = p[r]; k < p[r + 1]; ++k) {
+        const int pk = j[k] / width;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            n[q] += (pk == q);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        count[(size_t) q * rows + r] = n[q];
+}
+
+__global__ __launch_bounds__(256) void csr_panel_scatter_kernel(
+    int rows, int width, const int32_t * __restrict__ p, const int32_t * __restrict__ j, const double * __restrict__ a,
+    const int32_t * __restrict__ vrow_ptr, int32_t * __restrict__ pj, double * __restrict__ pa)
+{
+    const long long r = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows)
+        return;
+    int cur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        cur[q] = vrow_ptr[(size_t) q * rows + r];
+    for (int k = p[r]; k < p[r + 1]; ++k) {
+        const int c = j[k];
+        const int pk = c / width;
+        int dst = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (pk == q)
+                dst = cur[q]++;
+        pj[dst] = c;
+        pa[dst] = a[k];
     }
 }
 

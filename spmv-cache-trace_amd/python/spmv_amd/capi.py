@@ -19,6 +19,7 @@ CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
 FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER, FLAG_READ_ROW_PTR, FLAG_ROWS64, FLAG_ROWS128, FLAG_ELL_COLUMN_MAJOR = 0x1, 0x2, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 FLAG_NO_SHIFTED_TILES = 0x400
 FLAG_NO_X_WINDOW = 0x800
+FLAG_NO_COLUMN_PANELS = 0x1000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -48,6 +49,7 @@ SIGNATURES = {
     "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_plan_csr": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _i32p, C.c_int, C.c_int, C.c_uint]),
     "spmv_hip_plan_csr_compress": (C.c_int, [_vp, _vp, _vp]),
+    "spmv_hip_plan_csr_repack": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_plan_destroy": (None, [_vp]),
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -256,15 +258,20 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(13, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 13))
+        out = np.zeros(14, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 14))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles"]
+                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):
         """16-bit column offsets for the tiles that allow it (wave-tile algorithm only)."""
         check(self.lib.spmv_hip_plan_csr_compress(self.h, d_col, stream))
+
+    def repack(self, d_row_ptr, d_col, d_val, stream=0):
+        """Column panels for scattered matrices (after compress; a no-op when the matrix does not
+        qualify).  The plan then owns a snapshot of the values."""
+        check(self.lib.spmv_hip_plan_csr_repack(self.h, d_row_ptr, d_col, d_val, stream))
 
     def spmv(self, d_row_ptr, d_col, d_val, d_x, d_y, stream=0):
         """All arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""

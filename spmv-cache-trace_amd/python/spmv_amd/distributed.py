@@ -69,6 +69,7 @@ class DistributedCsrSpmv:
         tx = torch.from_numpy(np.ascontiguousarray(x_host, dtype=np.float64)).to(device)
         if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
             plan.compress(tc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
         def local_spmv(y_local):
             plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_local.data_ptr(),

@@ -1213,3 +1213,65 @@ def test_many_small_random_structures_other_formats(ctx, oracle):
         ctx.run()
         want = oracle.hybrid_spmv(rows, H, x, y=y0)
         assert_close(ctx.get_y(), want, scale, what="hybrid " + what)
+
+
+@pytest.mark.parametrize("case", ["random24", "random_unsorted", "with_long_rows"])
+def test_column_panels(oracle, case):
+    """Scattered columns with an x larger than one XCD's L2: the plan's panel-major copy (8 column
+    panels, atomic partial sums) against the oracle and against the plan without panels."""
+    import torch
+    rng = np.random.default_rng(31)
+    if case == "with_long_rows":
+        rows, cols = 40000, 600000
+        lens = rng.integers(8, 40, size=rows)
+        lens[rng.integers(0, rows, size=5)] = [600, 1500, 2100, 4000, 513]
+        lens[rng.integers(0, rows, size=50)] = 0
+    else:
+        rows, cols = 60000, 500000
+        lens = np.full(rows, 24)
+    p = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(lens, out=p[1:])
+    c = rng.integers(0, cols, size=int(p[-1])).astype(np.int32)
+    if case != "random_unsorted":
+        r_of = np.repeat(np.arange(rows), lens)
+        c = c[np.lexsort((c, r_of))]
+    v = rng.uniform(-1, 1, size=len(c))
+    x = synth.x_vector(cols, seed=32)
+    y0 = synth.x_vector(rows, seed=33)
+    want = y0 + oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    for flags in (0, capi.FLAG_NO_COLUMN_PANELS):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        info = plan.info()
+        assert (info["panel_tiles"] > 0) == (flags == 0), info
+        ty = torch.from_numpy(y0).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_close(ty.cpu().numpy(), want, scale, what="%s flags %x" % (case, flags))
+        # other value array: the snapshot does not apply, the plain path multiplies what it is given
+        tv2 = tv * 2.0
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv2.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_close(ty.cpu().numpy(), 2.0 * (want - y0), 2 * scale, what="%s other values, flags %x" % (case, flags))
+        plan.close()
+
+
+def test_column_panels_not_for_structured_or_small(oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for gen in (lambda: synth.poisson2d(700), lambda: synth.random_uniform(50000, 100000, 24, seed=3),
+                lambda: synth.powerlaw(600000, 600000, seed=4)):
+        rows, cols, p, c, v = gen()
+        tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        assert plan.info()["panel_tiles"] == 0  # structured / x fits an L2 / too few entries per row
+        plan.close()

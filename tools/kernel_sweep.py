@@ -89,6 +89,7 @@ def main():
         "wavetile_c16_noxwin": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | 0x100000),
         "wavetile_c16_noxwin_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_blockwin_simple": (capi.CSR_WAVETILE, 0, 0x2000 | 0x100000),
+        "wavetile_c16_panels": (capi.CSR_WAVETILE, 0, 0x100000 | 0x200000),
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
         "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
         "wavetile_c16_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP | 0x100000),
@@ -109,6 +110,8 @@ def main():
     for k, (a, l, f) in variants.items():
         if f & 0x100000:
             plans[k].compress(tc.data_ptr(), stream)
+        if f & 0x200000:  # sweep-local marker: column panels where the matrix qualifies
+            plans[k].repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
     times = {k: [] for k in plans}
     for rnd in range(args.rounds + 1):
         for k, plan in plans.items():
