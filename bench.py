@@ -378,7 +378,8 @@ def main():
                        "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
                        "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
                        "uniform_tiles": info["uniform_tiles"], "shifted_tiles": info["shifted_tiles"],
-                       "tiles_with_x_window": info["xwin_tiles"],
+                       "tiles_with_x_window": info["xwin_tiles"], "block_window_tiles": info["blockwin_tiles"],
+                       "column_panel_tiles": info["panel_tiles"],
                        "partition": ("%s, x replicated, 1 all-gather(y)/step%s" % (
                            ("rows/%d static chunks" % world) if ranges is None else ("%d row ranges of equal stored entries" % world), ", gather k overlaps multiply k+1" if op.overlap else ""))
                        if use_dist else "single GPU", "backend": args.backend if use_dist else None,
