@@ -91,6 +91,7 @@ struct spmv_hip_plan {
     int shifted_tiles = 0;
     int xwin_tiles = 0; // tiles whose whole column range fits a 256-entry window of x, or with a window of runs
     int longest_tile_row = 0; // longest row inside a stream tile
+    int spread_tiles = 0;     // tiles whose columns reach further than an eighth of the matrix
     // column panels: the plan's own panel-major copy of the matrix, multiplied through `inner`
     spmv_hip_plan * inner = nullptr;     // plan of the 8 * rows virtual rows
     int32_t * d_vrow_ptr = nullptr;      // [8 * rows + 1]
@@ -449,7 +450,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     int * d_count = nullptr;
     unsigned long long * d_fp = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
-    int counts[4] = {0, 0, 0, 0};
+    int counts[5] = {0, 0, 0, 0, 0};
     hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
     if (e == hipSuccess && want_patterns) {
         e = hipMalloc((void **) &d_fp, (size_t) pl->ntiles * sizeof(unsigned long long));
@@ -460,7 +461,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     if (e == hipSuccess) {
         hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
                            pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
-                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp);
+                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp, std::max(1, (pl->cols + 7) / 8));
         e = hipGetLastError();
     }
     // patterns: the shifted tiles' shape fingerprints come back to the host, the most frequent
@@ -526,6 +527,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->narrow_tiles = counts[0];
     pl->shifted_tiles = counts[1];
     pl->xwin_tiles = counts[2];
+    pl->spread_tiles = counts[4];
     // block windows (x staged through LDS per 16 tiles) for what has no cheaper path: first count
     // the tiles that would qualify, and only if they are the majority mark them
     if (e == hipSuccess && pl->tile == 512 && pl->ntiles >= 4 * spmv::kBlockWinTiles
@@ -586,7 +588,7 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         return fail(SPMV_HIP_ERR_STATE, "plan is already repacked");
     // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
     // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
-    const bool scattered = 2 * (long long) pl->narrow_tiles < pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
+    const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->rows < 1024
         || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
         || !pl->d_col16 /* not compressed: the tile classes are unknown */ || !scattered

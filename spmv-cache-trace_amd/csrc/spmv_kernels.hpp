@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(1024) void csr_blockwin_mark_kernel(
 __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
     uint16_t * __restrict__ j16, int * __restrict__ counts, int detect_shifted,
-    unsigned long long * __restrict__ fingerprint)
+    unsigned long long * __restrict__ fingerprint, int panel_width)
 {
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
@@ -1338,6 +1338,10 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     }
     if (cmin < 0)
         return;
+    // counts[4]: tiles whose columns reach further than one column panel (an eighth of the matrix):
+    // what "scattered" means for spmv_hip_plan_csr_repack
+    if (lane == 0 && cmax - cmin >= panel_width)
+        atomicAdd(counts + 4, 1);
     const bool narrow = cmax - cmin < 65536;
     if (narrow)
         for (int k = k0 + lane; k < k1; k += kWave)

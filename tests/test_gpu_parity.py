@@ -1266,8 +1266,11 @@ def test_column_panels_not_for_structured_or_small(oracle):
     import torch
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
+    def wide_band():  # columns within +-40000 of the diagonal: beyond 16-bit offsets, but local
+        rows, cols, p, c, v = fem_like_matrix(1000000, 40000, 8, seed=5)
+        return rows, cols, p, c, v
     for gen in (lambda: synth.poisson2d(700), lambda: synth.random_uniform(50000, 100000, 24, seed=3),
-                lambda: synth.powerlaw(600000, 600000, seed=4)):
+                lambda: synth.powerlaw(600000, 600000, seed=4), wide_band):
         rows, cols, p, c, v = gen()
         tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
         plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE)
