@@ -50,6 +50,18 @@ def main():
         p, c, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
     elif args.workload == "queen":  # ~80 entries/row, banded-ish
         rows, cols, p, c, v = synth.banded(2000000, list(range(-40, 41)), seed=5)
+    elif args.workload == "fem3d":
+        # like "fem" below but the 27 blocks of a row lie within +-40000 of the diagonal (a 3-D mesh's
+        # bandwidth): too wide for 16-bit offsets and for an LDS window, yet far from scattered
+        rng = np.random.default_rng(7)
+        rows = cols = 1500000
+        starts = rng.integers(-40000, 40000, size=(rows, 27), dtype=np.int64) + np.arange(rows, dtype=np.int64)[:, None]
+        cm = (starts[:, :, None] + np.arange(3, dtype=np.int64)[None, None, :]).reshape(rows, 81)
+        cm = np.clip(cm, 0, cols - 1)
+        cm.sort(axis=1)
+        p = (np.arange(rows + 1, dtype=np.int64) * 81).astype(np.int32)
+        c = cm.reshape(-1).astype(np.int32)
+        v = rng.uniform(-1.0, 1.0, size=c.shape[0])
     elif args.workload == "fem":
         # an unstructured band, closer to a finite-element matrix (Queen_4147) than the perfect band
         # above: 27 blocks of 3 consecutive columns per row, placed at random within +-3000 of the diagonal
