@@ -50,6 +50,26 @@ def main():
         p, c, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
     elif args.workload == "queen":  # ~80 entries/row, banded-ish
         rows, cols, p, c, v = synth.banded(2000000, list(range(-40, 41)), seed=5)
+    elif args.workload == "fem_mesh":
+        # a jittered 3-D mesh: 80 x 80 x 78 nodes, 3 unknowns per node, every node coupled to 27 nodes
+        # near its 27 grid neighbours (each moved by up to 2 nodes): rows of a node share their
+        # columns, neighbouring nodes share most of theirs -- the locality of a real finite-element
+        # matrix -- but no two rows are shifted copies of each other
+        rng = np.random.default_rng(8)
+        nx, ny, nz = 80, 80, 78
+        nodes = nx * ny * nz
+        offs = np.array([dz * nx * ny + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)], dtype=np.int64)
+        nb = np.arange(nodes, dtype=np.int64)[:, None] + offs[None, :] + rng.integers(-2, 3, size=(nodes, 27))
+        nb = np.clip(nb, 0, nodes - 1)
+        nb.sort(axis=1)
+        cm_node = (3 * nb[:, :, None] + np.arange(3, dtype=np.int64)[None, None, :]).reshape(nodes, 81)
+        rows = cols = 3 * nodes
+        cm = np.repeat(cm_node, 3, axis=0)
+        cm.sort(axis=1)
+        p = (np.arange(rows + 1, dtype=np.int64) * 81).astype(np.int32)
+        c = cm.reshape(-1).astype(np.int32)
+        v = rng.uniform(-1.0, 1.0, size=c.shape[0])
+        del cm, cm_node, nb
     elif args.workload == "fem3d":
         # like "fem" below but the 27 blocks of a row lie within +-40000 of the diagonal (a 3-D mesh's
         # bandwidth): too wide for 16-bit offsets and for an LDS window, yet far from scattered
