@@ -154,7 +154,8 @@ int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
  * [0] format (0 none, 1 csr, 2 coo, 3 ell, 4 hybrid)  [1] rows  [2] cols  [3] stored entries
  * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
  * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns
- * [11] shifted tiles  [12] tiles with an x window (see spmv_hip_plan_info) */
+ * [11] shifted tiles  [12] tiles with an x window  [13] block-window tiles  [14] tiles of the
+ * column-panel copy (see spmv_hip_plan_info) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================

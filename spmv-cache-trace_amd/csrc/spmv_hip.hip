@@ -1237,7 +1237,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
 {
     if (!c || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
-    int64_t v[13] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0};
+    int64_t v[15] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0};
     if (c->plan) {
         v[4] = c->plan->algorithm;
         v[5] = c->plan->lanes_per_row;
@@ -1248,8 +1248,10 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         v[10] = c->plan->narrow_tiles;
         v[11] = c->plan->shifted_tiles;
         v[12] = c->plan->xwin_tiles;
+        v[13] = c->plan->blockwin_tiles;
+        v[14] = c->plan->inner ? c->plan->inner->ntiles : 0;
     }
-    for (int i = 0; i < n && i < 13; ++i)
+    for (int i = 0; i < n && i < 15; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

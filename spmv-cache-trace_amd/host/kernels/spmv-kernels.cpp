@@ -349,15 +349,16 @@ protected:
 
     std::ostream & print_device(std::ostream & o) const
     {
-        std::int64_t info[13] = {0};
-        spmv_hip_ctx_info(ctx, info, 13);
+        std::int64_t info[15] = {0};
+        spmv_hip_ctx_info(ctx, info, 15);
         static char const * const algo[] = {"auto", "scalar", "vector", "adaptive", "wavetile"};
         o << ",\n\"device\": {\"backend\": \"hip\", \"index\": " << options.device;
         if (info[0] == 1)
             o << ", \"csr_algorithm\": \"" << algo[info[4] >= 0 && info[4] <= 4 ? info[4] : 0]
               << "\", \"lanes_per_row\": " << info[5] << ", \"tiles\": " << info[7] << ", \"long_rows\": " << info[8]
               << ", \"tiles_16bit_columns\": " << info[10] << ", \"tiles_shifted\": " << info[11]
-              << ", \"tiles_x_window\": " << info[12];
+              << ", \"tiles_x_window\": " << info[12] << ", \"tiles_block_window\": " << info[13]
+              << ", \"tiles_column_panels\": " << info[14];
         o << ", \"workgroups\": " << info[6] << ", \"device_bytes\": " << info[9]
           << ", \"last_run_device_ns\": " << device_ns << "}";
         return o;

@@ -229,10 +229,11 @@ class Context:
         return ns.value
 
     def info(self):
-        out = np.zeros(13, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 13))
+        out = np.zeros(15, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 15))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
-                "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles"]
+                "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles",
+                "blockwin_tiles", "panel_tiles"]
         return dict(zip(keys, out.tolist()))
 
 

@@ -1278,3 +1278,34 @@ def test_column_panels_not_for_structured_or_small(oracle):
         plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
         assert plan.info()["panel_tiles"] == 0  # structured / x fits an L2 / too few entries per row
         plan.close()
+
+
+def test_context_api_takes_the_special_paths(oracle):
+    """spmv_hip_upload_csr plans, classifies and repacks by itself: an unstructured band must end up
+    in the block-window kernel and a scattered matrix in column panels, with the right y."""
+    rng = np.random.default_rng(41)
+    c2 = capi.Context(0)
+    try:
+        rows, cols, p, c, v = fem_like_matrix(30000, 2500, 27, seed=42)
+        x = synth.x_vector(cols, seed=43)
+        c2.upload_csr(rows, cols, p, c, v)
+        c2.set_x(x)
+        c2.run(2)
+        info = c2.info()
+        assert info["blockwin_tiles"] > 0.5 * info["row_blocks"] and info["panel_tiles"] == 0, info
+        assert_close(c2.get_y(), oracle.csr_spmv(rows, p, c, v, x, runs=2, num_threads=4),
+                     2 * abs_products(rows, p, c, v, x), what="ctx block window")
+        rows, cols = 50000, 600000
+        p = (np.arange(rows + 1, dtype=np.int64) * 20).astype(np.int32)
+        c = rng.integers(0, cols, size=int(p[-1])).astype(np.int32)
+        v = rng.uniform(-1, 1, size=len(c))
+        x = synth.x_vector(cols, seed=44)
+        c2.upload_csr(rows, cols, p, c, v)
+        c2.set_x(x)
+        c2.run(3)
+        info = c2.info()
+        assert info["panel_tiles"] > 0, info
+        assert_close(c2.get_y(), oracle.csr_spmv(rows, p, c, v, x, runs=3, num_threads=4),
+                     3 * abs_products(rows, p, c, v, x), what="ctx column panels")
+    finally:
+        c2.close()
