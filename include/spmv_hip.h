@@ -183,7 +183,7 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
 /* Optional third planning step (done automatically by spmv_hip_upload_csr), after
  * spmv_hip_plan_csr_compress: for a matrix whose columns are scattered (in most tiles they reach
- * further than an eighth of the matrix, and the tiles are not shifted ones), with at least 12 entries per row and an x larger than one XCD's L2, the plan makes its
+ * further than an eighth of the matrix, and the tiles are not shifted ones), with at least 4 entries per row, at least 2^20 entries and an x larger than one XCD's L2, the plan makes its
  * own copy of the matrix cut into 8 column panels -- one per group of workgroups that share an XCD --
  * so that every XCD gathers from one eighth of x out of its private L2; a row's partial sums are
  * added to y with fp64 atomics (order not reproducible; within the usual tolerance).  The copy is

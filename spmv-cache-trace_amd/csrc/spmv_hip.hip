@@ -591,9 +591,12 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->rows < 1024
         || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
-        || !pl->d_col16 /* not compressed: the tile classes are unknown */ || !scattered
-        || (long long) pl->cols * 8 < 3 * 1024 * 1024 || (long long) pl->nnz < 12LL * pl->rows
+        || !pl->d_col16 /* not compressed: the tile classes are unknown */
         || (long long) pl->rows * 8 + 1 > 0x7FFFFFF0LL)
+        return SPMV_HIP_OK;
+    const bool force = (pl->flags & 0x4000u) != 0; // undocumented (tools/gather_locality.py): panels whatever the shape
+    if (!force && (!scattered || (long long) pl->cols * 8 < 3 * 1024 * 1024 || (long long) pl->nnz < 4LL * pl->rows
+                   || pl->nnz < (1 << 20) /* too small for the gather to matter; keeps small matrices bit-exact */))
         return SPMV_HIP_OK;
     if (!d_row_ptr || !d_column_index || !d_value)
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");

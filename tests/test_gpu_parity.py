@@ -1222,7 +1222,7 @@ def test_column_panels(oracle, case):
     import torch
     rng = np.random.default_rng(31)
     if case == "with_long_rows":
-        rows, cols = 40000, 600000
+        rows, cols = 60000, 600000
         lens = rng.integers(8, 40, size=rows)
         lens[rng.integers(0, rows, size=5)] = [600, 1500, 2100, 4000, 513]
         lens[rng.integers(0, rows, size=50)] = 0
@@ -1295,7 +1295,7 @@ def test_context_api_takes_the_special_paths(oracle):
         assert info["blockwin_tiles"] > 0.5 * info["row_blocks"] and info["panel_tiles"] == 0, info
         assert_close(c2.get_y(), oracle.csr_spmv(rows, p, c, v, x, runs=2, num_threads=4),
                      2 * abs_products(rows, p, c, v, x), what="ctx block window")
-        rows, cols = 50000, 600000
+        rows, cols = 60000, 600000
         p = (np.arange(rows + 1, dtype=np.int64) * 20).astype(np.int32)
         c = rng.integers(0, cols, size=int(p[-1])).astype(np.int32)
         v = rng.uniform(-1, 1, size=len(c))

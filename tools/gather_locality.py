@@ -17,12 +17,14 @@ def main():
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     rows = 2000000
-    for cols in (65536, 262144, 524288, 1048576, 2097152, 4194304):
-        _, _, p, c, v = synth.random_uniform(rows, cols, 24, seed=3)
+    per_row = int(sys.argv[sys.argv.index("--per-row") + 1]) if "--per-row" in sys.argv else 24
+    sizes = (2097152,) if "--per-row" in sys.argv else (65536, 262144, 524288, 1048576, 2097152, 4194304)
+    for cols in sizes:
+        _, _, p, c, v = synth.random_uniform(rows, cols, per_row, seed=3)
         tp, tc, tv = (torch.from_numpy(t).to(dev) for t in (p, c, v))
         tx = torch.from_numpy(synth.x_vector(cols)).to(dev)
         ty = torch.zeros(rows, dtype=torch.float64, device=dev)
-        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE)
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, 0x4000 if "--force" in sys.argv else 0)
         plan.compress(tc.data_ptr(), stream)
         if "--panels" in sys.argv:
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)

@@ -122,6 +122,7 @@ def main():
         "wavetile_c16_noxwin_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_blockwin_simple": (capi.CSR_WAVETILE, 0, 0x2000 | 0x100000),
         "wavetile_c16_panels": (capi.CSR_WAVETILE, 0, 0x100000 | 0x200000),
+        "wavetile_c16_panels_forced": (capi.CSR_WAVETILE, 0, 0x4000 | 0x100000 | 0x200000),
         "wavetile_c16_big": (capi.CSR_WAVETILE, 0, capi.FLAG_BIG_TILE | 0x100000),
         "wavetile_c16_rowptr": (capi.CSR_WAVETILE, 0, capi.FLAG_READ_ROW_PTR | 0x100000),
         "wavetile_c16_xcd": (capi.CSR_WAVETILE, 0, capi.FLAG_XCD_REMAP | 0x100000),
@@ -138,7 +139,7 @@ def main():
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
-    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0x3FFFF) for k, (a, l, f) in variants.items()}
+    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0x3FFFF) for k, (a, l, f) in variants.items()}  # sweep-local markers are above bit 17
     for k, (a, l, f) in variants.items():
         if f & 0x100000:
             plans[k].compress(tc.data_ptr(), stream)
