@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <string>
 
 namespace {
@@ -105,4 +106,128 @@ extern "C" int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_
     if (temp)
         (void) hipFree(temp);
     return e == hipSuccess ? SPMV_HIP_OK : SPMV_HIP_ERR_HIP;
+}
+
+
+namespace {
+
+__global__ __launch_bounds__(256) void panel_key_kernel(int n, int width, const int32_t * __restrict__ col,
+                                                        int32_t * __restrict__ key, int32_t * __restrict__ idx)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        key[i] = col[i] / width;
+        idx[i] = (int32_t) i;
+    }
+}
+
+// first[k] = position of the first sorted entry with key >= k is derived on the host from these
+__global__ __launch_bounds__(256) void panel_first_kernel(int n, const int32_t * __restrict__ key_sorted, int32_t * __restrict__ first)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        if (i == 0 || key_sorted[i] != key_sorted[i - 1])
+            first[key_sorted[i]] = (int32_t) i;
+}
+
+struct PanelPlace {
+    int ufirst[9];      // unpadded start of every panel in the sorted order
+    long long start[9]; // padded start in the output arrays
+};
+
+__global__ __launch_bounds__(256) void panel_place_kernel(int n, const int32_t * __restrict__ key_sorted,
+                                                          const int32_t * __restrict__ idx_sorted,
+                                                          const int32_t * __restrict__ row, const int32_t * __restrict__ col,
+                                                          const double * __restrict__ val, int32_t * __restrict__ prow,
+                                                          int32_t * __restrict__ pcol, double * __restrict__ pval, PanelPlace pp)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int k = key_sorted[i];
+        const long long dst = pp.start[k] + (i - pp.ufirst[k]);
+        const int32_t src = idx_sorted[i];
+        prow[dst] = row[src];
+        pcol[dst] = col[src];
+        pval[dst] = val[src];
+    }
+}
+
+} // namespace
+
+// Column panels for COO triplets (row-sorted on entry): a copy grouped by column panel, stable inside
+// a panel, every panel padded to a multiple of 1024 entries with (row -1, column 0, value 0).
+// start[0..8] receives the panel boundaries in the copy; the three output arrays are hipMalloc'ed here.
+extern "C" int spmv_hip_internal_coo_panels(int32_t cols, int32_t nnz, const int32_t * d_row, const int32_t * d_col,
+                                            const double * d_val, int32_t ** out_row, int32_t ** out_col,
+                                            double ** out_val, long long * start, hipStream_t s)
+{
+    *out_row = *out_col = nullptr;
+    *out_val = nullptr;
+    const int width = (cols + 7) / 8;
+    int32_t *key = nullptr, *key_sorted = nullptr, *idx = nullptr, *idx_sorted = nullptr, *d_first = nullptr;
+    void * temp = nullptr;
+    size_t temp_bytes = 0;
+    const size_t nb = (size_t) nnz * sizeof(int32_t);
+    hipError_t e = hipMalloc((void **) &key, nb);
+    if (e == hipSuccess) e = hipMalloc((void **) &key_sorted, nb);
+    if (e == hipSuccess) e = hipMalloc((void **) &idx, nb);
+    if (e == hipSuccess) e = hipMalloc((void **) &idx_sorted, nb);
+    if (e == hipSuccess) e = hipMalloc((void **) &d_first, 9 * sizeof(int32_t));
+    const int grid = (int) std::min<long long>(((long long) nnz + 255) / 256, 256 * 64);
+    int32_t first[9];
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(panel_key_kernel, dim3(grid), dim3(256), 0, s, nnz, width, d_col, key, idx);
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, key, key_sorted, idx, idx_sorted, nnz, 0, 3, s);
+    }
+    if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key, key_sorted, idx, idx_sorted, nnz, 0, 3, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_first, 0xFF, 9 * sizeof(int32_t), s); // -1 = panel without entries
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(panel_first_kernel, dim3(grid), dim3(256), 0, s, nnz, key_sorted, d_first);
+        e = hipMemcpyAsync(first, d_first, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    PanelPlace pp;
+    long long total = 0;
+    if (e == hipSuccess) {
+        first[8] = nnz;
+        for (int k = 7; k >= 0; --k)
+            if (first[k] < 0)
+                first[k] = first[k + 1];
+        for (int k = 0; k < 8; ++k) {
+            pp.ufirst[k] = first[k];
+            pp.start[k] = total;
+            const long long len = (long long) first[k + 1] - first[k];
+            total += (len + 1023) / 1024 * 1024;
+        }
+        pp.ufirst[8] = nnz;
+        pp.start[8] = total;
+        for (int k = 0; k <= 8; ++k)
+            start[k] = pp.start[k];
+        e = hipMalloc((void **) out_row, (size_t) total * sizeof(int32_t) + 64);
+        if (e == hipSuccess) e = hipMalloc((void **) out_col, (size_t) total * sizeof(int32_t) + 64);
+        if (e == hipSuccess) e = hipMalloc((void **) out_val, (size_t) total * sizeof(double) + 64);
+        if (e == hipSuccess) e = hipMemsetAsync(*out_row, 0xFF, (size_t) total * sizeof(int32_t) + 64, s);
+        if (e == hipSuccess) e = hipMemsetAsync(*out_col, 0, (size_t) total * sizeof(int32_t) + 64, s);
+        if (e == hipSuccess) e = hipMemsetAsync(*out_val, 0, (size_t) total * sizeof(double) + 64, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(panel_place_kernel, dim3(grid), dim3(256), 0, s, nnz, key_sorted, idx_sorted, d_row, d_col, d_val,
+                               *out_row, *out_col, *out_val, pp);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    void * frees[] = {key, key_sorted, idx, idx_sorted, d_first, temp};
+    for (void * q : frees)
+        if (q)
+            (void) hipFree(q);
+    if (e != hipSuccess) {
+        if (*out_row) (void) hipFree(*out_row);
+        if (*out_col) (void) hipFree(*out_col);
+        if (*out_val) (void) hipFree(*out_val);
+        *out_row = *out_col = nullptr;
+        *out_val = nullptr;
+        return SPMV_HIP_ERR_HIP;
+    }
+    return SPMV_HIP_OK;
 }

