@@ -51,10 +51,13 @@ extern "C" {
 #define SPMV_HIP_CSR_ADAPTIVE 3 /* row blocks: coalesced stream of col/val -> products in LDS ->
                                    per-row sums (reference order when a row gets one lane);
                                    rows longer than a tile get a whole workgroup */
-#define SPMV_HIP_CSR_WAVETILE 4 /* per-wavefront row ownership: tiles of <= 64 rows owned by one
+#define SPMV_HIP_CSR_WAVETILE 4 /* per-wavefront row ownership: tiles of <= 128 rows owned by one
                                    wave, descriptor-driven so all of a tile's loads issue at once,
                                    products in the wave's LDS slice, no workgroup barrier; very
-                                   long rows are split over several waves (fp64 atomics) */
+                                   long rows are split over several waves (fp64 atomics).  After
+                                   spmv_hip_plan_csr_compress / _repack the tiles are specialised by
+                                   structure: 16-bit columns, shifted tiles and patterns, x windows,
+                                   block windows, column panels */
 
 /* plan / ctx flags */
 #define SPMV_HIP_FLAG_XCD_REMAP 0x1u   /* give each XCD one contiguous run of tiles instead of the round-robin
@@ -77,7 +80,9 @@ extern "C" {
                                             windows where most tiles' x entries fit 256 slots and are used twice (narrow
                                             bands, stencils), and a per-workgroup ring for unstructured bands whose 16-tile
                                             blocks span <= 8192 columns (a second kernel launch per multiply) */
-#define SPMV_HIP_FLAG_NO_COLUMN_PANELS 0x1000u /* plan_csr_repack / upload_csr: never form column panels */
+#define SPMV_HIP_FLAG_NO_COLUMN_PANELS 0x1000u /* plan_csr_repack / upload_csr / upload_coo / upload_hybrid: never form
+                                                  column panels (a copy of a scattered matrix cut into 8 column ranges,
+                                                  one per group of workgroups that share an XCD's L2) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -92,7 +97,7 @@ int spmv_hip_device_count(int *count);
 
 /* =================================================================================
  * Level 1 -- context API: host arrays in, host arrays out.
- * Bound by the hip_{csr,coo,ell}_spmv_kernel adapters (host/hip-spmv-kernels.cpp),
+ * Bound by the hip_{csr,coo,ell,hybrid}_spmv_kernel adapters (host/kernels/spmv-kernels.cpp),
  * which stand where the reference's csr_spmv_kernel / coo_spmv_kernel /
  * ell_spmv_kernel stand (src/kernels/{csr,coo,ell}-spmv.cpp).
  * ============================================================================== */
