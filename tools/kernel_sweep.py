@@ -50,6 +50,27 @@ def main():
         p, c, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
     elif args.workload == "queen":  # ~80 entries/row, banded-ish
         rows, cols, p, c, v = synth.banded(2000000, list(range(-40, 41)), seed=5)
+    elif args.workload == "longrows_dense":
+        # the same shape with consecutive columns (a dense band): the long-row path without gather effects
+        rows = cols = 60000
+        L = 1500
+        cm = (np.arange(rows, dtype=np.int64)[:, None] + np.arange(L, dtype=np.int64)[None, :]) % cols
+        cm.sort(axis=1)
+        p = (np.arange(rows + 1, dtype=np.int64) * L).astype(np.int32)
+        c = cm.reshape(-1).astype(np.int32)
+        v = np.random.default_rng(9).uniform(-1.0, 1.0, size=c.shape[0])
+        del cm
+    elif args.workload == "longrows":
+        # 60000 rows of 1500 entries each (longer than a tile, shorter than the split threshold),
+        # columns within +-30000 of the diagonal
+        rng = np.random.default_rng(9)
+        rows = cols = 60000
+        L = 1500
+        cm = np.sort((np.arange(rows, dtype=np.int64)[:, None] + rng.integers(-30000, 30000, size=(rows, L))) % cols, axis=1)
+        p = (np.arange(rows + 1, dtype=np.int64) * L).astype(np.int32)
+        c = cm.reshape(-1).astype(np.int32)
+        v = rng.uniform(-1.0, 1.0, size=c.shape[0])
+        del cm
     elif args.workload == "fem_mesh":
         # a jittered 3-D mesh: 80 x 80 x 78 nodes, 3 unknowns per node, every node coupled to 27 nodes
         # near its 27 grid neighbours (each moved by up to 2 nodes): rows of a node share their
