@@ -46,9 +46,13 @@ public:
     // flops and algorithmic bytes of one run() (SURVEY 8d formulas), 0 if not defined
     virtual double flops_per_run() const { return 0.0; }
     virtual double bytes_per_run() const { return 0.0; }
-    virtual std::vector<double> result() const = 0;
+    // number of entries of x (0 if the kernel has no such vector)
+    virtual std::size_t columns() const { return 0; }
+    // Not pure: a Kernel written against the reference's header (src/kernels/kernel.hpp:18-45)
+    // compiles against this one unchanged; it simply cannot take part in --check.
+    virtual std::vector<double> result() const { throw kernel_error(name() + ": result() is not implemented"); }
     // Replace x (default: all ones, src/kernels/csr-spmv.cpp:35) before prepare().
-    virtual void set_x(std::vector<double> const & x) = 0;
+    virtual void set_x(std::vector<double> const &) { throw kernel_error(name() + ": set_x() is not implemented"); }
 };
 
 inline std::ostream & operator<<(std::ostream & o, Kernel const & kernel) { return kernel.print(o); }

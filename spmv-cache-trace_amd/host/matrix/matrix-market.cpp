@@ -1,4 +1,5 @@
 #include "matrix-market.hpp"
+#include "synthetic.hpp"
 
 #include "matrix-error.hpp"
 #include "matrix-reorder.hpp"
@@ -558,7 +559,10 @@ Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
     // optional binary cache of the parsed entries (matrix-cache.hpp); reordering comes after it
     Matrix m;
     std::string const cache = cache_directory();
-    if (!cache.empty() && load_cached(file, cache, m)) {
+    if (synthetic::is_spec(file)) {
+        // EXTENSION: "synthetic:<family>[:<parameters>]" is generated, not read (synthetic.hpp)
+        m = synthetic::generate(file);
+    } else if (!cache.empty() && load_cached(file, cache, m)) {
         if (verbose)
             o << "Read the parsed entries from " << cache_file_for(file, cache) << '\n';
     } else {

@@ -1,0 +1,478 @@
+#include "synthetic.hpp"
+
+#include "matrix-error.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace synthetic {
+
+namespace {
+
+using csr_matrix::index_type;
+using csr_matrix::size_type;
+
+// counter-based randomness: every number is a hash of what it belongs to (splitmix64 finaliser)
+inline std::uint64_t mix(std::uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline std::uint64_t h2(std::uint64_t a, std::uint64_t b) { return mix(mix(a) ^ (b * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull)); }
+inline double u01(std::uint64_t h) { return (double) (h >> 11) * (1.0 / 9007199254740992.0); }   // [0, 1)
+inline double u11(std::uint64_t h) { return (double) (h >> 11) * (2.0 / 9007199254740992.0) - 1.0; } // [-1, 1)
+
+std::vector<long long> numbers(std::string const & s)
+{
+    std::vector<long long> out;
+    std::size_t pos = 0;
+    while (pos < s.size()) {
+        std::size_t end = s.find(',', pos);
+        if (end == std::string::npos)
+            end = s.size();
+        std::string const tok = s.substr(pos, end - pos);
+        char * e = nullptr;
+        long long const v = std::strtoll(tok.c_str(), &e, 10);
+        if (tok.empty() || *e != '\0' || v < 0)
+            throw matrix::matrix_error("synthetic matrix: expected non-negative integers, got '" + s + "'");
+        out.push_back(v);
+        pos = end + 1;
+    }
+    return out;
+}
+
+// Two passes over the rows [rb, re): lengths -> row_ptr, then every row fills its own slice.
+template <class Len, class Fill>
+csr_matrix::Matrix build(long long rows_total, long long cols, long long rb, long long re, Len len, Fill fill)
+{
+    if (rows_total > INT32_MAX || cols > INT32_MAX)
+        throw matrix::matrix_error("synthetic matrix: more than 2^31-1 rows or columns");
+    long long const nr = re - rb;
+    csr_matrix::size_array_type row_ptr((std::size_t) nr + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < nr; ++r)
+        row_ptr[(std::size_t) r + 1] = (size_type) len(rb + r);
+    long long k = 0;
+    for (long long r = 0; r < nr; ++r) {
+        k += row_ptr[(std::size_t) r + 1];
+        if (k > INT32_MAX)
+            throw matrix::matrix_error("synthetic matrix: Integer overflow when computing number of non-zeros");
+        row_ptr[(std::size_t) r + 1] = (size_type) k;
+    }
+    csr_matrix::index_array_type col((std::size_t) k);
+    csr_matrix::value_array_type val((std::size_t) k);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (long long r = 0; r < nr; ++r)
+        fill(rb + r, col.data() + row_ptr[(std::size_t) r], val.data() + row_ptr[(std::size_t) r]);
+    return csr_matrix::Matrix((index_type) nr, (index_type) cols, (size_type) k, 1, std::move(row_ptr), std::move(col),
+                              std::move(val));
+}
+
+// ---- poisson2d: the arrays of python/spmv_amd/synth.py poisson2d(), value for value --------------
+csr_matrix::Matrix poisson2d(long long n, long long rb, long long re, long long * total)
+{
+    if (n < 1 || n > 46340)
+        throw matrix::matrix_error("synthetic:poisson2d: grid edge must be in 1..46340");
+    long long const N = n * n;
+    if (total) *total = N;
+    if (re < 0) re = N;
+    auto len = [n](long long r) {
+        long long const i = r / n, j = r % n;
+        return 1 + (i > 0) + (j > 0) + (j < n - 1) + (i < n - 1);
+    };
+    auto fill = [n](long long r, index_type * c, double * v) {
+        long long const i = r / n, j = r % n;
+        if (i > 0) { *c++ = (index_type) (r - n); *v++ = -1.0; }
+        if (j > 0) { *c++ = (index_type) (r - 1); *v++ = -1.0; }
+        *c++ = (index_type) r; *v++ = 4.0;
+        if (j < n - 1) { *c++ = (index_type) (r + 1); *v++ = -1.0; }
+        if (i < n - 1) { *c++ = (index_type) (r + n); *v++ = -1.0; }
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
+// ---- kkt: [H 0 A'; 0 R C'; A C 0], unknowns ordered states, controls, multipliers ----------------
+csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * total)
+{
+    if (n < 1 || n > 1000)
+        throw matrix::matrix_error("synthetic:kkt: grid edge must be in 1..1000");
+    long long const ny = n * n * n, nu = 6 * n * n, N = 2 * ny + nu;
+    if (total) *total = N;
+    if (re < 0) re = N;
+    long long const n2 = n * n;
+    std::uint64_t const seedA = 0xA11CE, seedH = 0xB0B, seedC = 0xC0DE;
+    auto ext = [n](long long a) { return 1 + (a > 0) + (a < n - 1); };
+    auto faces = [n](long long a, long long b, long long c) {
+        return (a == 0) + (a == n - 1) + (b == 0) + (b == n - 1) + (c == 0) + (c == n - 1);
+    };
+    auto len = [=](long long r) -> long long {
+        if (r < ny) { // state: diagonal of H, then A' (one entry per constraint whose stencil holds this state)
+            long long const a = r / n2, b = (r / n) % n, c = r % n;
+            return 1 + ext(a) * ext(b) * ext(c);
+        }
+        if (r < ny + nu)
+            return 2; // control: diagonal of R, its boundary cell's constraint
+        long long const s = r - ny - nu, a = s / n2, b = (s / n) % n, c = s % n;
+        return ext(a) * ext(b) * ext(c) + faces(a, b, c); // constraint: 27-point row of A, controls of its faces
+    };
+    auto cell_of_control = [=](long long k) {
+        long long const f = k / n2, u = (k % n2) / n, v = k % n;
+        switch (f) {
+        case 0: return (0 * n + u) * n + v;
+        case 1: return ((n - 1) * n + u) * n + v;
+        case 2: return (u * n + 0) * n + v;
+        case 3: return (u * n + (n - 1)) * n + v;
+        case 4: return (u * n + v) * n + 0;
+        default: return (u * n + v) * n + (n - 1);
+        }
+    };
+    auto fill = [=](long long r, index_type * col, double * val) {
+        if (r < ny) {
+            long long const a = r / n2, b = (r / n) % n, c = r % n;
+            *col++ = (index_type) r;
+            *val++ = 2.0 + u11(h2(seedH, (std::uint64_t) r));
+            for (int da = -1; da <= 1; ++da)
+                for (int db = -1; db <= 1; ++db)
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        long long const aa = a + da, bb = b + db, cc = c + dc;
+                        if (aa < 0 || aa >= n || bb < 0 || bb >= n || cc < 0 || cc >= n)
+                            continue;
+                        long long const s = (aa * n + bb) * n + cc;
+                        int const code = (da + 1) * 9 + (db + 1) * 3 + (dc + 1);
+                        *col++ = (index_type) (ny + nu + s);
+                        *val++ = u11(h2(seedA, (std::uint64_t) (s * 27 + (26 - code)))); // A[s][r]
+                    }
+        } else if (r < ny + nu) {
+            long long const k = r - ny;
+            *col++ = (index_type) r;
+            *val++ = 1.5 + 0.5 * u11(h2(seedH, (std::uint64_t) r));
+            *col++ = (index_type) (ny + nu + cell_of_control(k));
+            *val++ = u11(h2(seedC, (std::uint64_t) k));
+        } else {
+            long long const s = r - ny - nu, a = s / n2, b = (s / n) % n, c = s % n;
+            for (int da = -1; da <= 1; ++da)
+                for (int db = -1; db <= 1; ++db)
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        long long const aa = a + da, bb = b + db, cc = c + dc;
+                        if (aa < 0 || aa >= n || bb < 0 || bb >= n || cc < 0 || cc >= n)
+                            continue;
+                        int const code = (da + 1) * 9 + (db + 1) * 3 + (dc + 1);
+                        *col++ = (index_type) ((aa * n + bb) * n + cc);
+                        *val++ = u11(h2(seedA, (std::uint64_t) (s * 27 + code))); // A[s][j]
+                    }
+            long long const ks[6] = {a == 0 ? 0 * n2 + b * n + c : -1, a == n - 1 ? 1 * n2 + b * n + c : -1,
+                                     b == 0 ? 2 * n2 + a * n + c : -1, b == n - 1 ? 3 * n2 + a * n + c : -1,
+                                     c == 0 ? 4 * n2 + a * n + b : -1, c == n - 1 ? 5 * n2 + a * n + b : -1};
+            for (long long k : ks)
+                if (k >= 0) {
+                    *col++ = (index_type) (ny + k);
+                    *val++ = u11(h2(seedC, (std::uint64_t) k));
+                }
+        }
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
+// ---- queen: 3 unknowns per node of a jittered mesh, symmetric structure, dense 3x3 blocks ------------
+csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total)
+{
+    long long const nodes = gx * gy * gz;
+    if (gx < 1 || gy < 1 || gz < 1 || nodes > 700000000LL)
+        throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
+    long long const N = 3 * nodes;
+    if (total) *total = N;
+    if (re < 0) re = N;
+    constexpr int J = 3; // a jittered link's far end is moved by J nodes
+    std::uint64_t const seedJ = 0x51DE, seedQ = 0x0EE2;
+    // the 13 "forward" neighbour offsets (x fastest); the other 13 are their mirror images
+    int fd[13][3];
+    long long foff[13];
+    {
+        int k = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    long long const off = ((long long) dz * gy + dy) * gx + dx;
+                    if (off > 0) {
+                        fd[k][0] = dx; fd[k][1] = dy; fd[k][2] = dz;
+                        foff[k++] = off;
+                    }
+                }
+    }
+    auto inside = [=](long long m, int const * d) {
+        long long const x = m % gx + d[0], y = (m / gx) % gy + d[1], z = m / (gx * gy) + d[2];
+        return x >= 0 && x < gx && y >= 0 && y < gy && z >= 0 && z < gz;
+    };
+    // half of the links keep their grid neighbour, the others end J nodes to either side of it.  J = 3
+    // keeps the three links of an x-triple (offsets c-1, c, c+1) apart whatever their jitter, so an
+    // interior node has 26 distinct neighbours like a node of a hexahedral mesh
+    auto jit = [=](long long m, int k) {
+        std::uint64_t const h = h2(seedJ, (std::uint64_t) (m * 13 + k));
+        return (h & 1) ? 0 : ((h & 2) ? J : -J);
+    };
+    // neighbours of node n (itself included), ascending, no duplicates; returns their number (<= 13 + 13*5 + 1)
+    auto neighbours = [=](long long n, long long * out) {
+        int c = 0;
+        out[c++] = n;
+        for (int k = 0; k < 13; ++k) {
+            if (inside(n, fd[k])) { // the link n starts
+                long long const t = n + foff[k] + jit(n, k);
+                if (t >= 0 && t < nodes && t != n)
+                    out[c++] = t;
+            }
+            for (int j = -J; j <= J; j += J) { // links that end at n
+                long long const m = n - foff[k] - j;
+                if (m >= 0 && m < nodes && m != n && inside(m, fd[k]) && jit(m, k) == j)
+                    out[c++] = m;
+            }
+        }
+        std::sort(out, out + c);
+        return (int) (std::unique(out, out + c) - out);
+    };
+    // node graph first (150 MB at full size), then the rows asked for
+    std::vector<long long> node_ptr((std::size_t) nodes + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (long long n = 0; n < nodes; ++n) {
+        long long tmp[96];
+        node_ptr[(std::size_t) n + 1] = neighbours(n, tmp);
+    }
+    for (long long n = 0; n < nodes; ++n)
+        node_ptr[(std::size_t) n + 1] += node_ptr[(std::size_t) n];
+    std::vector<index_type> nbr((std::size_t) node_ptr[(std::size_t) nodes]);
+#pragma omp parallel for schedule(static)
+    for (long long n = 0; n < nodes; ++n) {
+        long long tmp[96];
+        int const c = neighbours(n, tmp);
+        for (int i = 0; i < c; ++i)
+            nbr[(std::size_t) node_ptr[(std::size_t) n] + i] = (index_type) tmp[i];
+    }
+    auto len = [&](long long r) { return 3 * (node_ptr[(std::size_t) (r / 3) + 1] - node_ptr[(std::size_t) (r / 3)]); };
+    auto fill = [&](long long r, index_type * col, double * val) {
+        long long const n = r / 3;
+        int const a = (int) (r % 3);
+        for (long long q = node_ptr[(std::size_t) n]; q < node_ptr[(std::size_t) n + 1]; ++q) {
+            long long const m = nbr[(std::size_t) q];
+            std::uint64_t const edge = h2(h2(seedQ, (std::uint64_t) std::min(n, m)), (std::uint64_t) std::max(n, m));
+            for (int b = 0; b < 3; ++b) {
+                // block(lo, hi)[a][b]; the mirrored block is its transpose, the diagonal block symmetric
+                int const ia = n < m ? a : b, ib = n < m ? b : a;
+                double v;
+                if (n == m) {
+                    v = u11(h2(edge, (std::uint64_t) (std::min(a, b) * 3 + std::max(a, b))));
+                    if (a == b)
+                        v += 30.0;
+                } else {
+                    v = u11(h2(edge, (std::uint64_t) (ia * 3 + ib)));
+                }
+                *col++ = (index_type) (3 * m + b);
+                *val++ = v;
+            }
+        }
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
+// ---- webbase / powerlaw ------------------------------------------------------------------------------
+long long gcd_ll(long long a, long long b) { return b == 0 ? a : gcd_ll(b, a % b); }
+
+csr_matrix::Matrix webbase(long long N, long long Z, long long maxrow, int locality_pct, int popularity_exp,
+                           long long rb, long long re, long long * total)
+{
+    if (N < 2 || N > INT32_MAX || Z < N || Z > INT32_MAX || maxrow < 1 || maxrow > N || maxrow > 1000000 ||
+        locality_pct < 0 || locality_pct > 100 || (double) Z > (double) N * (double) maxrow)
+        throw matrix::matrix_error("synthetic:webbase: need 2 <= N, N <= Z <= N*maxrow, 1 <= maxrow <= min(N, 10^6), locality 0..100");
+    if (total) *total = N;
+    if (re < 0) re = N;
+    std::uint64_t const seedL = 0x3EB, seedF = 0xF1C5, seedHost = 0x4057, seedC = 0xC01;
+    // row lengths: P(len = k) ~ k^-alpha on 1..maxrow with alpha solved for the mean Z/N
+    double const mean = (double) Z / (double) N;
+    auto mean_of = [maxrow](double alpha) {
+        double s0 = 0.0, s1 = 0.0;
+        for (long long k = maxrow; k >= 1; --k) {
+            double const w = std::pow((double) k, -alpha);
+            s0 += w;
+            s1 += w * (double) k;
+        }
+        return s1 / s0;
+    };
+    double lo = 0.0, hi = 12.0;
+    for (int it = 0; it < 80; ++it) {
+        double const mid = 0.5 * (lo + hi);
+        (mean_of(mid) > mean ? lo : hi) = mid;
+    }
+    double const alpha = 0.5 * (lo + hi);
+    std::vector<double> cdf((std::size_t) maxrow);
+    {
+        double s = 0.0;
+        for (long long k = 1; k <= maxrow; ++k)
+            cdf[(std::size_t) k - 1] = (s += std::pow((double) k, -alpha));
+        for (double & c : cdf)
+            c /= s;
+    }
+    std::vector<index_type> lens((std::size_t) N);
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < N; ++r) {
+        double const u = u01(h2(seedL, (std::uint64_t) r));
+        lens[(std::size_t) r] = (index_type) (std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin()) + 1;
+    }
+    long long const longest = (long long) (h2(seedL, 0xFFFFFFFFull) % (std::uint64_t) N);
+    lens[(std::size_t) longest] = (index_type) maxrow;
+    long long sum = 0;
+    for (index_type l : lens)
+        sum += l;
+    // exactly Z entries: move single entries in and out of hashed rows (never the longest row)
+    for (std::uint64_t it = 0; sum != Z; ++it) {
+        // hashed rows first; should they all be full (Z close to N * maxrow), walk the rows in order
+        long long const t = it < 64ull * (std::uint64_t) N ? (long long) (h2(seedF, it) % (std::uint64_t) N)
+                                                          : (long long) (it % (std::uint64_t) N);
+        if (t == longest)
+            continue;
+        if (sum < Z && lens[(std::size_t) t] < maxrow) {
+            ++lens[(std::size_t) t];
+            ++sum;
+        } else if (sum > Z && lens[(std::size_t) t] > 1) {
+            --lens[(std::size_t) t];
+            --sum;
+        }
+    }
+    // host blocks: many small, a few of thousands of pages
+    std::vector<index_type> hstart((std::size_t) N), hsize((std::size_t) N);
+    for (long long s = 0, hidx = 0; s < N; ++hidx) {
+        double const u = std::max(u01(h2(seedHost, (std::uint64_t) hidx)), 1e-12);
+        long long size = (long long) (8.0 * std::pow(u, -0.8));
+        size = std::max(1LL, std::min({size, 50000LL, N - s}));
+        for (long long r = s; r < s + size; ++r) {
+            hstart[(std::size_t) r] = (index_type) s;
+            hsize[(std::size_t) r] = (index_type) size;
+        }
+        s += size;
+    }
+    long long P = 611953 % N;
+    while (P < 2 || gcd_ll(P, N) != 1)
+        ++P;
+    auto len = [&](long long r) { return (long long) lens[(std::size_t) r]; };
+    auto fill = [&](long long r, index_type * col, double * val) {
+        long long const L = lens[(std::size_t) r], S = hsize[(std::size_t) r], s0 = hstart[(std::size_t) r];
+        std::uint64_t const hr = h2(seedC, (std::uint64_t) r);
+        long long nl = (long long) ((double) L * locality_pct / 100.0 + u01(h2(hr, 1)));
+        nl = std::min({nl, S, L});
+        if (nl > 0) { // distinct pages of the row's own host: an arithmetic progression modulo its size
+            long long const a = (long long) (h2(hr, 2) % (std::uint64_t) S);
+            long long g = 1 + (long long) (h2(hr, 3) % (std::uint64_t) S);
+            while (gcd_ll(g, S) != 1)
+                g = g % S + 1;
+            for (long long i = 0; i < nl; ++i)
+                col[i] = (index_type) (s0 + (a + i * g) % S);
+        }
+        for (long long i = nl; i < L; ++i) { // the rest: pages by popularity rank, ranks scattered over the index space
+            double u = u01(h2(hr, (std::uint64_t) (16 + i)));
+            double w = u;
+            for (int e = 1; e < popularity_exp; ++e)
+                w *= u;
+            long long const rank = std::min(N - 1, (long long) (w * (double) N));
+            col[i] = (index_type) (popularity_exp > 1 ? (rank * P + 12345) % N : rank);
+        }
+        std::sort(col, col + L);
+        for (long long i = 1; i < L; ++i) // duplicates move up ...
+            if (col[i] <= col[i - 1])
+                col[i] = col[i - 1] + 1;
+        if (col[L - 1] > (index_type) (N - 1)) { // ... and back down where they ran off the end
+            col[L - 1] = (index_type) (N - 1);
+            for (long long i = L - 2; i >= 0 && col[i] >= col[i + 1]; --i)
+                col[i] = col[i + 1] - 1;
+        }
+        for (long long i = 0; i < L; ++i)
+            val[i] = u11(h2(hr, (std::uint64_t) (1u << 20) + (std::uint64_t) i));
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
+} // namespace
+
+bool is_spec(std::string const & path) { return path.compare(0, 10, "synthetic:") == 0; }
+
+csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long long re, long long * total)
+{
+    if (!is_spec(spec))
+        throw matrix::matrix_error("not a synthetic matrix specification: " + spec);
+    std::string rest = spec.substr(10);
+    std::string family = rest, params;
+    std::size_t const colon = rest.find(':');
+    if (colon != std::string::npos) {
+        family = rest.substr(0, colon);
+        params = rest.substr(colon + 1);
+    }
+    std::vector<long long> const v = numbers(params);
+    long long tot = 0;
+    auto check_range = [&](long long N) {
+        if (rb < 0 || (re >= 0 && (re < rb || re > N)) || rb > N)
+            throw matrix::matrix_error("synthetic matrix: row range out of bounds");
+    };
+    csr_matrix::Matrix A;
+    if (family == "poisson2d") {
+        if (v.size() != 1)
+            throw matrix::matrix_error("synthetic:poisson2d:<n> takes one number");
+        check_range(v[0] * v[0]);
+        A = poisson2d(v[0], rb, re, &tot);
+    } else if (family == "kkt") {
+        if (v.size() > 1)
+            throw matrix::matrix_error("synthetic:kkt[:<n>] takes at most one number");
+        long long const n = v.empty() ? 200 : v[0];
+        check_range(2 * n * n * n + 6 * n * n);
+        A = kkt(n, rb, re, &tot);
+    } else if (family == "queen") {
+        if (!v.empty() && v.size() != 3)
+            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz] takes three numbers");
+        long long const gx = v.empty() ? 110 : v[0], gy = v.empty() ? 71 : v[1], gz = v.empty() ? 177 : v[2];
+        check_range(3 * gx * gy * gz);
+        A = queen(gx, gy, gz, rb, re, &tot);
+    } else if (family == "webbase" || family == "powerlaw") {
+        bool const web = family == "webbase";
+        if (v.size() > (web ? 4u : 3u))
+            throw matrix::matrix_error("synthetic:" + family + ": too many parameters");
+        long long const N = v.size() > 0 ? v[0] : 1000005, Z = v.size() > 1 ? v[1] : (v.empty() ? 3105536 : 3 * N);
+        long long const maxrow = v.size() > 2 ? v[2] : std::min(4700LL, N);
+        int const loc = web ? (v.size() > 3 ? (int) v[3] : 75) : 0;
+        check_range(N);
+        A = webbase(N, Z, maxrow, loc, web ? 4 : 1, rb, re, &tot);
+    } else {
+        throw matrix::matrix_error("unknown synthetic matrix family '" + family +
+                                   "' (poisson2d, queen, kkt, webbase, powerlaw)");
+    }
+    if (total)
+        *total = tot;
+    return A;
+}
+
+matrix_market::Matrix generate(std::string const & spec)
+{
+    csr_matrix::Matrix const A = generate_csr(spec);
+    std::size_t const Z = (std::size_t) A.row_ptr[(std::size_t) A.rows];
+    std::vector<matrix_market::index_type> i(Z), j(Z);
+    std::vector<matrix_market::real_type> a(Z);
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < (long long) A.rows; ++r)
+        for (size_type k = A.row_ptr[(std::size_t) r]; k < A.row_ptr[(std::size_t) r + 1]; ++k) {
+            i[(std::size_t) k] = (matrix_market::index_type) r + 1;
+            j[(std::size_t) k] = A.column_index[(std::size_t) k] + 1;
+            a[(std::size_t) k] = A.value[(std::size_t) k];
+        }
+    matrix_market::Header h;
+    matrix_market::Size s;
+    s.rows = A.rows;
+    s.columns = A.columns;
+    s.num_entries = (matrix_market::size_type) Z;
+    return matrix_market::Matrix(h, {"% generated: " + spec}, s, std::move(i), std::move(j), std::move(a));
+}
+
+} // namespace synthetic

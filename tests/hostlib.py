@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "spmv-cache-trace_amd")
-HOST_SO = os.path.join(PKG, "libspmv_host.so")
+HOST_SO = os.path.join(PKG, "libspmv_host_test.so")  # the test hooks; links libspmv_host.so
 CLI = os.path.join(PKG, "spmv-cache-trace-hip")
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
