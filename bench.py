@@ -2,26 +2,34 @@
 """bench.py -- headline benchmark of the MI355X SpMV path.
 
     python bench.py [--gpus N --steps K --warmup W]
+    python bench.py --workload queen|kkt|webbase|powerlaw [--format csr|coo|ell|hybrid]
+    python bench.py --matrix Queen_4147.tar.gz [--expand-symmetric] [--format ...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path, y += A*x, over the workload with all inputs
-already resident in HBM.  Workload (BASELINE.json configs[1]): Poisson 5-point stencil
-CSR on a 4096 x 4096 grid, N = 16 777 216 rows, Z = 83 869 696 stored entries, fp64
-values / int32 indices.  With N > 1 GPUs the SAME matrix is row-partitioned
-(ceil(rows/N) rows per rank, the reference's static chunk rule), x is replicated, and
-every step ends with ONE all-gather of the y segments (RCCL): total work is fixed, so
-scaling is "strong".
+A "step" is one pass of the hot path, y += A*x, over the workload with all inputs already
+resident in HBM.  Default workload (BASELINE.json configs[1]): Poisson 5-point stencil CSR on a
+4096 x 4096 grid, N = 16 777 216 rows, Z = 83 869 696 stored entries, fp64 values / int32
+indices.  The other BASELINE configurations run from their files (--matrix, through the repo's
+own loader, libspmv_host.so; symmetric files are multiplied as stored unless --expand-symmetric)
+or, where the files cannot be fetched, from structure-faithful generators of the same size
+(--workload queen | kkt | webbase, host/matrix/synthetic.hpp).
 
-Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).
-`roofline` prices the local SpMV kernel: algorithmic bytes of one launch
-(CSR: 12*Z + 4*(rows+1) + 16*rows + 8*cols, BASELINE.md section 3, for the rank's row
-slice) divided by its mean duration measured with HIP events on the launch stream.
-`cpu_baseline` (rank 0, N = 1 only) times the reference's own OpenMP CSR kernel
-(oracle/_ref, kind "reference") or the C oracle (kind "port") on the host cores.
+With N > 1 GPUs the SAME matrix is row-partitioned (ceil(rows/N) rows per rank, the reference's
+static chunk rule), x is replicated, and every step ends with ONE all-gather of the y segments
+(RCCL): total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).  `roofline` prices
+the local SpMV kernel: algorithmic bytes of one launch divided by its
+mean duration measured with HIP events on the launch stream; next to that fraction it carries
+`frac_streamed` (the bytes the chosen tile classes really stream) and `frac_of_triad` (against
+the STREAM triad measured in the same process).  `cpu_baseline` (rank 0, N = 1 only) times the
+reference's own OpenMP kernel (oracle/_ref, kind "reference") or the C oracle (kind "port") on
+the host cores; the same leg is the parity gate (whole vector, 1e-10 relative).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,9 @@ sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
 # the host driver only supports dmabuf IPC: without this RCCL cannot share buffers across ranks
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+XGMI_LINK_GBS = 64.0       # per direction and link, 7 links per GPU (the figure DESIGN.md section 6 uses)
+CLI = os.path.join(ROOT, "spmv-cache-trace_amd", "spmv-cache-trace-hip")
 
 
 def parse_args():
@@ -40,8 +50,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "stencil27", "random"])
+    ap.add_argument("--workload", default="poisson2d",
+                    choices=["poisson2d", "queen", "kkt", "webbase", "powerlaw", "stencil27", "random"],
+                    help="poisson2d = BASELINE configs[1]; queen / kkt / webbase = generated stand-ins of configs[2..4] "
+                         "at full size; powerlaw = webbase with uniformly scattered columns; stencil27 / random: round-1 stand-ins")
+    ap.add_argument("--matrix", default=None, help="Matrix Market file (.mtx, .gz, .tgz, .tar.gz) or synthetic:<spec>; overrides --workload")
+    ap.add_argument("--expand-symmetric", action="store_true",
+                    help="mirror the entries of a symmetric file (EXTENSION; the reference multiplies the stored triangle)")
+    ap.add_argument("--format", default="csr", choices=["csr", "coo", "ell", "hybrid"],
+                    help="storage format (coo / ell / hybrid: one GPU, through the context API)")
     ap.add_argument("--grid", type=int, default=4096, help="poisson2d grid edge (4096 = BASELINE configs[1])")
+    ap.add_argument("--kkt-grid", type=int, default=200, help="kkt grid edge (200 = nlpkkt200's size)")
     ap.add_argument("--algorithm", default="auto", choices=["auto", "scalar", "vector", "adaptive", "wavetile"])
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--xcd-remap", action="store_true")
@@ -50,14 +69,19 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores visible to this process")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-reference-protocol", action="store_true",
+                    help="skip the extra run of the C++ CLI that times the multiply the reference's way (sync per run)")
     ap.add_argument("--events", choices=["launch", "region"], default="region",
                     help="one HIP event pair around the K timed launches (default; mean launch duration = span / K, "
                          "launch gaps included), or a pair around every launch (adds ~5 us of gap per step)")
     ap.add_argument("--partition", choices=["rows", "nnz"], default="rows",
                     help="N > 1: the reference's static row chunks (default), or a split on row boundaries with "
-                         "equal stored entries per rank (uneven rows; only for workloads generated whole)")
+                         "equal stored entries per rank (uneven rows)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each all-gather before the next multiply (default: gather k overlaps multiply k+1)")
+    ap.add_argument("--snapshot", action="store_true",
+                    help="N > 1 with overlap: accumulate in place and copy the segment to a send buffer (round 1's way) "
+                         "instead of alternating two segment buffers")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N > 1 on a box with one GPU")
     ap.add_argument("--share-gpu", action="store_true",
@@ -67,25 +91,56 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_rows(args, begin, end):
-    """This rank's rows [begin, end) of the workload, plus global sizes."""
-    from spmv_amd import synth, partition
+def workload_spec(args):
+    """(spec for the host library or None, short name)."""
+    if args.matrix:
+        return args.matrix, os.path.basename(args.matrix)
     if args.workload == "poisson2d":
-        n = args.grid
-        rows = n * n
-        nr, cols, p, c, v = synth.poisson2d(n, begin, rows if end is None else end)
-        return rows, cols, 5 * rows - 4 * n, p, c, v, "poisson2d-5pt-%dx%d-csr" % (n, n)
-    if args.workload == "stencil27":
-        # nlpkkt200-like stand-in (configs[3]): 27-point stencil, ~16.2M rows, ~436M entries
-        rows, cols, p, c, v = synth.stencil27_like(253, 253, 253)
-        name = "stencil27-253^3-csr"
+        return "synthetic:poisson2d:%d" % args.grid, "poisson2d-5pt-%dx%d" % (args.grid, args.grid)
+    if args.workload == "kkt":
+        return "synthetic:kkt:%d" % args.kkt_grid, "kkt-27pt-%d^3 (nlpkkt%d-like)" % (args.kkt_grid, args.kkt_grid)
+    if args.workload == "queen":
+        return "synthetic:queen", "queen-like 110x71x177 mesh x 3 dof (Queen_4147-like)"
+    if args.workload == "webbase":
+        return "synthetic:webbase", "webbase-like power law, 75% host-local links (webbase-1M-like)"
+    if args.workload == "powerlaw":
+        return "synthetic:powerlaw", "power-law rows, uniformly scattered columns"
+    return None, {"stencil27": "stencil27-253^3", "random": "random-4M-24perrow"}[args.workload]
+
+
+def load_csr(args, rank, world):
+    """This rank's rows of the workload as CSR arrays: (rows_total, cols, nnz_total or None, p, c, v, begin, end,
+    ranges or None, keep-alive object)."""
+    from spmv_amd import hostapi, partition, synth
+    spec, _ = workload_spec(args)
+    ranges = None
+    if spec is None:  # numpy generators of round 1 (whole matrix, then cut)
+        if args.workload == "stencil27":
+            rows, cols, p, c, v = synth.stencil27_like(253, 253, 253)
+        else:
+            rows, cols, p, c, v = synth.random_uniform(4000000, 4000000, 24, seed=3)
+        keep = None
+    elif world > 1 and spec.startswith("synthetic:") and args.partition == "rows":
+        # a generated matrix: only this rank's rows are made (the row count comes from an empty range)
+        probe = hostapi.load_csr_rows(spec, 0, 0)
+        rows = probe.rows_total
+        probe.close()
+        begin, end = partition.row_range(rows, rank, world)
+        keep = hostapi.load_csr_rows(spec, begin, end)
+        return rows, keep.cols, None, keep.row_ptr, keep.column_index, keep.value, begin, end, None, keep
     else:
-        rows, cols, p, c, v = synth.random_uniform(4000000, 4000000, 24, seed=3)
-        name = "random-4M-24perrow-csr"
+        keep = hostapi.load(spec, "csr", expand_symmetric=args.expand_symmetric)
+        rows, cols, p, c, v = keep.rows, keep.cols, keep.row_ptr, keep.column_index, keep.value
     nnz = int(p[-1])
-    if end is not None:
+    begin, end = 0, rows
+    if world > 1:
+        if args.partition == "nnz":
+            ranges = partition.nnz_balanced_ranges(p, world)
+            begin, end = ranges[rank]
+        else:
+            begin, end = partition.row_range(rows, rank, world)
         p, c, v = partition.csr_slice(p, c, v, begin, end)
-    return rows, cols, nnz, p, c, v, name
+    return rows, cols, nnz, p, c, v, begin, end, ranges, keep
 
 
 def host_cores():
@@ -107,11 +162,12 @@ def host_cores():
     return n
 
 
-def pmc_traffic(kernel_name, algorithmic_bytes):
+def pmc_traffic(kernel_name, workload, algorithmic_bytes):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_summary.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 + WRITE_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
-    the figure is only reported when the summary was taken on the same kernel and workload."""
+    the figure is only reported when the summary was taken on the same kernel and workload, and
+    `traffic_source` names the file it comes from."""
     import glob
     best = None
     seq = -1
@@ -130,73 +186,167 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     return best
 
 
-def cpu_baseline(args, rows, cols, p, c, v, x, y_gpu=None):
-    """Reference OpenMP CSR kernel (or the C oracle) on the host cores, bounded sample.  Also the
+def format_bytes(fmt, rows, cols, nnz, stored=None, coo_entries=0):
+    """Algorithmic bytes of one y += A*x (SURVEY 8d / BASELINE.md section 3)."""
+    from spmv_amd import synth
+    if fmt == "csr":
+        return synth.csr_bytes(rows, cols, nnz)
+    if fmt == "coo":
+        return synth.coo_bytes(rows, cols, nnz)
+    if fmt == "ell":
+        return 12 * stored + 16 * rows + 8 * cols
+    return 12 * stored + 16 * coo_entries + 16 * rows + 8 * cols  # hybrid: ELL part + COO remainder
+
+
+def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None):
+    """The reference's OpenMP kernel (or the C oracle) on the host cores, bounded sample.  Also the
     parity gate: one CPU multiply from y = 0 is compared with the GPU's (y_gpu), whole vector,
-    tolerance 1e-10 relative (BASELINE.json).  Returns (cpu_baseline, parity)."""
+    tolerance 1e-10 relative (BASELINE.json).  A = dict of the format's arrays.  Returns (cpu_baseline, parity)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     threads = args.cpu_threads or host_cores()
-    nnz = int(p[-1])
     budget = args.cpu_seconds
-    if oracle_py.RefLib.available():
+    nnz = A["nnz"]
+    if fmt == "csr":
+        p, c, v = A["p"], A["c"], A["v"]
+    if fmt == "csr" and oracle_py.RefLib.available():
         R = oracle_py.RefLib()
-        A = R.csr_from_arrays(rows, cols, p, c, v)
+        M = R.csr_from_arrays(rows, cols, p, c, v)
         t = time.perf_counter()
         if not args.cpu_threads:
             # the box may expose more CPUs than it grants: probe a few team sizes briefly
             best = None
             for cand in sorted({min(threads, 16), min(threads, 32), min(threads, 64), threads}):
-                ns, _ = R.csr_spmv_timed(A, x, cand, 2)
+                ns, _ = R.csr_spmv_timed(M, x, cand, 2)
                 if best is None or np.median(ns) < best[0]:
                     best = (float(np.median(ns)), cand)
             threads = best[1]
-        ns, _ = R.csr_spmv_timed(A, x, threads, 2)  # 1 warm-up + 2 timed, to size the sample
+        ns, _ = R.csr_spmv_timed(M, x, threads, 2)  # 1 warm-up + 2 timed, to size the sample
         per = max(float(np.median(ns)) * 1e-9, 1e-4)
         runs = int(max(3, min(200, (budget - (time.perf_counter() - t)) / per)))
-        ns, _ = R.csr_spmv_timed(A, x, threads, runs)
-        ns1, _ = R.csr_spmv_timed(A, x, 1, 3)  # one thread, as BASELINE configs[0] is defined
-        y_cpu = R.csr_spmv(A, x, num_threads=threads) if y_gpu is not None else None
-        R.csr_free(A)
+        ns, _ = R.csr_spmv_timed(M, x, threads, runs)
+        ns1, _ = R.csr_spmv_timed(M, x, 1, 3)  # one thread, as BASELINE configs[0] is defined
+        y_cpu = R.csr_spmv(M, x, num_threads=threads) if y_gpu is not None else None
+        R.csr_free(M)
         kind = "reference"
     else:
         O = oracle_py.Oracle()
+        if fmt == "csr":
+            run = lambda y, T: O.csr_spmv_inplace(rows, p, c, v, x, y, T)
+            fresh = lambda T: O.csr_spmv(rows, p, c, v, x, num_threads=T)
+        elif fmt == "coo":
+            # the atomic form is what the GPU kernel implements (coo-matrix.cpp:287-309)
+            fresh = lambda T: O.coo_spmv_atomic(rows, A["r"], A["c"], A["v"], x, num_threads=T)
+            run = lambda y, T: fresh(T)
+        elif fmt == "ell":
+            fresh = lambda T: O.ell_spmv(rows, A["L"], A["c"], A["v"], x, num_threads=T)
+            run = lambda y, T: fresh(T)
+        else:
+            H = dict(row_length=A["L"], ell_col=A["c"], ell_val=A["v"], coo_row=A["cr"], coo_col=A["cc"], coo_val=A["cv"],
+                     skip_padding=False)
+            fresh = lambda T: O.hybrid_spmv(rows, H, x, num_threads=T)
+            run = lambda y, T: fresh(T)
         y = np.zeros(rows)
-        O.csr_spmv_inplace(rows, p, c, v, x, y, threads)  # warm-up
+        run(y, threads)  # warm-up
         ns = []
         t_end = time.perf_counter() + budget
         while len(ns) < 3 or (time.perf_counter() < t_end and len(ns) < 200):
             t0 = time.perf_counter_ns()
-            O.csr_spmv_inplace(rows, p, c, v, x, y, threads)
+            run(y, threads)
             ns.append(time.perf_counter_ns() - t0)
         ns = np.array(ns)
         ns1 = []
         for _ in range(3):
             t0 = time.perf_counter_ns()
-            O.csr_spmv_inplace(rows, p, c, v, x, y, 1)
+            run(y, 1)
             ns1.append(time.perf_counter_ns() - t0)
         ns1 = np.array(ns1)
-        y_cpu = O.csr_spmv(rows, p, c, v, x, num_threads=threads) if y_gpu is not None else None
+        y_cpu = fresh(threads if fmt in ("csr", "ell") else 1) if y_gpu is not None else None
         kind = "port"
     med = float(np.median(ns)) * 1e-9
     parity = None
     if y_gpu is not None:
-        err = float(np.max(np.abs(y_gpu - y_cpu)) / max(float(np.max(np.abs(y_cpu))), 1e-300))
+        diff = np.abs(y_gpu - y_cpu)
+        finite = bool(np.isfinite(y_gpu).all())
+        err = float(np.max(diff) / max(float(np.max(np.abs(y_cpu))), 1e-300)) if finite else float("nan")
         parity = {"against": "cpu_baseline kernel (%s), one multiply from y = 0" % kind, "rows_checked": int(rows),
-                  "max_rel_err": err, "tolerance": 1e-10, "pass": bool(err <= 1e-10),
+                  "max_rel_err": err if finite else "nan", "tolerance": 1e-10, "pass": bool(finite and err <= 1e-10),
                   "bitexact": bool(np.array_equal(y_gpu, y_cpu))}
     return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
-            "sample": "full workload, %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
-                      % (len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
-            "gbs": round((12.0 * nnz + 4 * (rows + 1) + 16.0 * rows + 8.0 * cols) / med / 1e9, 2),
+            "sample": "full workload (%s), %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
+                      % (fmt, len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
+            "gbs": round(A["bytes"] / med / 1e9, 2),
             "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3)}, parity
+
+
+def reference_protocol(args, fmt, runs):
+    """The same multiply timed the reference's way (src/profile-kernel.cpp:137-179): the C++ CLI
+    (host/main.cpp) loads or generates the matrix itself, uploads it through the C ABI, and times
+    `runs` runs each bracketed by barriers with the device idle at both ends; --check compares y
+    with the CPU CSR kernel after the same number of accumulating runs.  Returns a dict, or a
+    dict with "error"."""
+    spec, _ = workload_spec(args)
+    if spec is None or not os.path.exists(CLI):
+        return None
+    cmd = [CLI, "--matrix", spec, "--spmv-format", "hip-" + fmt, "--threads", "1", "--profile", str(runs),
+           "--x", "uniform", "--check"]
+    if args.expand_symmetric:
+        cmd.append("--expand-symmetric")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": str(e)}
+    if r.returncode != 0 and not r.stdout.strip():
+        return {"error": (r.stderr or "").strip()[-300:]}
+    try:
+        d = json.loads(r.stdout)
+    except ValueError:
+        return {"error": "unparsable output: " + r.stdout[-200:]}
+    et = d["execution_time"]
+    flops = d.get("throughput", {}).get("flops_per_run", 0.0)
+    out = {"command": " ".join(os.path.basename(c) if c == CLI else c for c in cmd),
+           "protocol": "1 warm-up + %d runs, each: barrier, t0, barrier, run + device sync, barrier, t1 (host steady_clock)" % runs,
+           "execution_time_ns": {k: et[k] for k in ("samples", "min", "median", "mean", "max")},
+           "gflops_median": round(flops / et["median"], 2) if et["median"] else None,
+           "device_ns_last_run": d.get("kernel", {}).get("device", {}).get("last_run_device_ns"),
+           "parity": d.get("parity"), "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
+
+
+class ContextOperator:
+    """COO / ELLPACK / hybrid through the Level-1 context API (what the C++ adapters bind), launched
+    on torch's current stream so that the events of the timed region see it."""
+
+    def __init__(self, fmt, M, x, device_index, flags, stream):
+        from spmv_amd import capi
+        self.ctx = capi.Context(device_index, flags)
+        self.ctx.set_stream(stream)
+        if fmt == "coo":
+            self.ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
+        elif fmt == "ell":
+            self.ctx.upload_ell(M.rows, M.cols, M.row_length, M.column_index, M.value)
+        else:
+            self.ctx.upload_hybrid(M.rows, M.cols, M.row_length, M.column_index, M.value,
+                                   M.coo_row_index, M.coo_column_index, M.coo_value)
+        self.ctx.set_x(x)
+        self.rows = M.rows
+
+    def step(self):
+        self.ctx.run(1, sync=False)
+
+    def zero_y(self):
+        self.ctx.set_y(np.zeros(self.rows))
+
+    def y(self):
+        return self.ctx.get_y()
 
 
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from spmv_amd import capi, partition, synth
+    from spmv_amd import capi, hostapi, partition, synth
     from spmv_amd.distributed import DistributedCsrSpmv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,6 +358,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; this benchmark has no CPU fallback")
+    fmt = args.format
+    if fmt != "csr" and (world > 1 or args.force_collective):
+        sys.exit("bench.py: --format %s runs on one GPU (the row partition of the N > 1 path is CSR)" % fmt)
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -221,51 +374,89 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    # ---- workload: this rank's rows, global x ------------------------------------------
+    def finish(code=0, message=None):
+        """Every rank leaves together: the verdict travels before the last barrier."""
+        if use_dist:
+            flag = torch.tensor([code], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            code = int(flag.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if code:
+            sys.exit(message or "bench.py: a check failed on another rank")
+        sys.exit(0)
+
+    # ---- workload ------------------------------------------------------------------------------
     t_setup = time.perf_counter()
-    ranges = None
-    if args.workload == "poisson2d":
-        rows = args.grid * args.grid
-    else:
-        rows = None
-    if rows is not None and world > 1:
-        begin, end = partition.row_range(rows, rank, world)
-        rows, cols, nnz, p, c, v, wname = make_rows(args, begin, end)
-    elif world > 1:
-        rows_g, cols, nnz, p, c, v, wname = make_rows(args, 0, None)
-        if args.partition == "nnz":
-            ranges = partition.nnz_balanced_ranges(p, world)
-            begin, end = ranges[rank]
-        else:
-            begin, end = partition.row_range(rows_g, rank, world)
-        p, c, v = partition.csr_slice(p, c, v, begin, end)
-        rows = rows_g
-    else:
-        rows, cols, nnz, p, c, v, wname = make_rows(args, 0, None)
-        begin, end = 0, rows
-    x = synth.x_vector(cols, "uniform", seed=12345)
+    spec, wname = workload_spec(args)
+    wname = "%s-%s" % (wname, fmt)
     algo = {"auto": capi.CSR_AUTO, "scalar": capi.CSR_SCALAR, "vector": capi.CSR_VECTOR,
             "adaptive": capi.CSR_ADAPTIVE, "wavetile": capi.CSR_WAVETILE}[args.algorithm]
     flags = (capi.FLAG_XCD_REMAP if args.xcd_remap else 0) | args.flags
-    op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
-                                   overlap=not args.no_overlap, ranges=ranges)
-    local_rows, local_nnz = end - begin, int(p[-1])
-    local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
+    stream = torch.cuda.current_stream().cuda_stream
+    host_arrays = None  # what the cpu_baseline leg multiplies
+    if fmt == "csr":
+        rows, cols, nnz, p, c, v, begin, end, ranges, keep = load_csr(args, rank, world)
+        if nnz is None:  # only this rank's rows were generated: the total is the sum over ranks
+            t = torch.tensor([float(p[-1])], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            nnz = int(t.item())
+        x = synth.x_vector(cols, "uniform", seed=12345)
+        op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
+                                       overlap=not args.no_overlap, ranges=ranges, pingpong=not args.snapshot)
+        local_rows, local_nnz = end - begin, int(p[-1])
+        local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
+        total_bytes = synth.csr_bytes(rows, cols, nnz)
+        info = op.plan.info()
+        streamed = info["streamed_bytes"]
+        if world == 1:
+            host_arrays = {"p": p, "c": c, "v": v, "nnz": nnz, "bytes": total_bytes}
+        step = op.step
+        kernel_name = "csr_%s" % capi.CSR_ALGORITHM_NAMES[info["algorithm"]]
+    else:
+        if spec is None:
+            sys.exit("bench.py: --format %s needs --matrix or a generated --workload" % fmt)
+        M = hostapi.load(spec, fmt, expand_symmetric=args.expand_symmetric)
+        keep = M
+        rows, cols, nnz = M.rows, M.cols, M.num_entries
+        begin, end, ranges = 0, rows, None
+        x = synth.x_vector(cols, "uniform", seed=12345)
+        op = ContextOperator(fmt, M, x, local_rank, flags, stream)
+        local_rows, local_nnz = rows, nnz
+        local_bytes = total_bytes = format_bytes(fmt, rows, cols, nnz, M.stored, M.num_coo_entries)
+        info = op.ctx.info()
+        streamed = info["streamed_bytes"]
+        step = op.step
+        kernel_name = {"coo": "coo_wide", "ell": "csr_wavetile" if info["row_blocks"] else "ell", "hybrid": "csr_wavetile+coo_wide"}[fmt]
+        if fmt == "coo":
+            host_arrays = {"r": M.row_index, "c": M.column_index, "v": M.value}
+        elif fmt == "ell":
+            host_arrays = {"L": M.row_length, "c": M.column_index, "v": M.value}
+        else:
+            host_arrays = {"L": M.row_length, "c": M.column_index, "v": M.value, "cr": M.coo_row_index,
+                           "cc": M.coo_column_index, "cv": M.coo_value}
+        host_arrays.update(nnz=nnz, bytes=total_bytes)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
-    # ---- one multiply into a zero y, kept on the device: the cpu_baseline leg (the only place the
-    # checker libraries under oracle/ are loaded) compares it with the CPU kernel's y -----------------
+    # ---- one multiply into a zero y, kept for the cpu_baseline leg (the only place the checker
+    # libraries under oracle/ are loaded), which compares it with the CPU kernel's y ------------
     y_check = None
-    if world == 1 and not args.no_cpu_baseline and not args.no_parity_check:
-        op.multiply_local()
-        torch.cuda.synchronize()
-        y_check = op.y_local[:local_rows].clone()
-        op.y_local.zero_()
+    if world == 1 and not use_dist and not args.no_cpu_baseline and not args.no_parity_check:
+        if fmt == "csr":
+            op.multiply_local()
+            torch.cuda.synchronize()
+            y_check = op.y_local[:local_rows].cpu().numpy()
+            op.zero()
+        else:
+            op.step()
+            torch.cuda.synchronize()
+            y_check = op.y()
+            op.zero_y()
 
     # ---- warm-up, then K timed steps -------------------------------------------------------
     for _ in range(args.warmup):
-        op.step()
+        step()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -273,15 +464,18 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # with a collective in the step the compute stream also carries the snapshot copy and the wait
-    # for the previous gather, so the span is no longer K launches: time every launch there
+    # with a collective in the step the compute stream also carries the waits for earlier gathers,
+    # so the span is no longer K launches: time every launch there
     per_launch = args.events == "launch" or use_dist
     if not per_launch:
         ev0[0].record()
     for k in range(args.steps):
         if per_launch:
             ev0[k].record()
-        op.multiply_local()
+        if fmt == "csr":
+            op.multiply_local()
+        else:
+            step()
         if per_launch:
             ev1[k].record()
         if use_dist:
@@ -291,7 +485,8 @@ def main():
                 op.gather()
     if not per_launch:
         ev1[0].record()
-    op.finish()
+    if fmt == "csr":
+        op.finish()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -307,6 +502,26 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = stats.tolist()
 
+    # ---- the empirical denominator: STREAM triad on 3 x 512 MiB in the same process -------------
+    triad_gbs = None
+    try:
+        nt = 64 * 1024 * 1024
+        ta = torch.zeros(nt, dtype=torch.float64, device=device)
+        tb = torch.ones(nt, dtype=torch.float64, device=device)
+        tc_ = torch.ones(nt, dtype=torch.float64, device=device)
+        for _ in range(3):
+            capi.triad(nt, ta.data_ptr(), tb.data_ptr(), tc_.data_ptr(), 3.1, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            capi.triad(nt, ta.data_ptr(), tb.data_ptr(), tc_.data_ptr(), 3.1, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        triad_gbs = 24.0 * nt * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del ta, tb, tc_
+    except (RuntimeError, capi.SpmvHipError):
+        triad_gbs = None
+
     # N > 1: the collective on its own (after the timed region, not part of `value`): a few
     # blocking all-gathers, max over ranks, so the line shows where a step's time goes.
     gather_us = None
@@ -316,7 +531,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
-            dist.all_gather_into_tensor(op.y_full, op.send_buf if op.overlap else op.y_local, group=op.group)
+            dist.all_gather_into_tensor(op.y_full, op.y_local, group=op.group)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - g0)
         gt = torch.tensor([float(np.median(times))], dtype=torch.float64, device=device)
@@ -327,21 +542,21 @@ def main():
     # the last rank's rows on its own GPU (product kernel, one multiply) and compares it with the
     # gathered segment, which has accumulated warm-up + K multiplies.
     gather_check = None
-    if use_dist and world > 1 and rank == 0 and args.workload == "poisson2d":
+    if use_dist and world > 1 and rank == 0 and spec is not None and spec.startswith("synthetic:") and ranges is None:
         ob, oe = partition.row_range(rows, world - 1, world)
         strip = min(4096, oe - ob)
-        _, _, ps, cs, vs = synth.poisson2d(args.grid, ob, ob + strip)
-        tps, tcs, tvs = (torch.from_numpy(t).to(device) for t in (ps, cs, vs))
+        S = hostapi.load_csr_rows(spec, ob, ob + strip)
+        tps, tcs, tvs = (torch.from_numpy(np.array(t)).to(device) for t in (S.row_ptr, S.column_index, S.value))
         ys = torch.zeros(strip, dtype=torch.float64, device=device)
-        plan_s = capi.CsrPlan(strip, cols, ps, algo, args.lanes, flags)
-        plan_s.spmv(tps.data_ptr(), tcs.data_ptr(), tvs.data_ptr(), op._keep[3].data_ptr(), ys.data_ptr(),
-                    torch.cuda.current_stream().cuda_stream)
+        plan_s = capi.CsrPlan(strip, cols, S.row_ptr, algo, args.lanes, flags)
+        plan_s.spmv(tps.data_ptr(), tcs.data_ptr(), tvs.data_ptr(), op._keep[3].data_ptr(), ys.data_ptr(), stream)
         torch.cuda.synchronize()
         want = ys * float(args.steps + args.warmup)
         got = op.y()[ob:ob + strip]
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-300))
         gather_check = {"rows_checked": strip, "of_rank": world - 1, "max_rel_err": err, "pass": bool(err <= 1e-10)}
         plan_s.close()
+        S.close()
 
     # N > 1, for information only (never `value`): the same K multiplies with ONE all-gather after the
     # last of them -- what a caller pays who, like the reference's timed loop, looks at y only after
@@ -361,69 +576,93 @@ def main():
         deferred = {"steps": args.steps, "all_gathers": 1, "ms_total": round(dt.item() * 1e3, 4),
                     "gflops": round(2.0 * nnz * args.steps / dt.item() / 1e9, 2)}
 
+    code, message = 0, None
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
         gflops = 2.0 * nnz * args.steps / elapsed_max / 1e9
         kern_s = kern_ms_max * 1e-3  # slowest rank's mean launch duration
         achieved = local_bytes / kern_s / 1e9
-        info = op.plan.info()
+        streamed_gbs = streamed / kern_s / 1e9
+        config = {"workload": wname, "rows": rows, "cols": cols, "nnz": nnz, "format": fmt,
+                  "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
+                  "symmetric_file_expanded": bool(getattr(keep, "expanded", False)),
+                  "partition": ("%s, x replicated, 1 all-gather(y)/step%s" % (
+                      ("rows/%d static chunks" % world) if ranges is None else ("%d row ranges of equal stored entries" % world),
+                      (", gather k overlaps multiply k+1 (%s)" % ("two alternating segment buffers" if op.pingpong else "snapshot copy"))
+                      if op.overlap else "")) if use_dist else "single GPU",
+                  "backend": args.backend if use_dist else None, "rehearsal_shared_gpu": bool(args.share_gpu)}
+        if fmt == "csr":
+            config.update({"algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]], "lanes_per_row": info["lanes_per_row"],
+                           "workgroups": info["workgroups"], "tiles": info["row_blocks"],
+                           "tiles_with_16bit_columns": info["narrow_tiles"], "uniform_tiles": info["uniform_tiles"],
+                           "shifted_tiles": info["shifted_tiles"], "tiles_with_x_window": info["xwin_tiles"],
+                           "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"]})
+        else:
+            config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
+                           "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],
+                           "tiles_with_16bit_columns": info["narrow_tiles"], "column_panel_tiles": info["panel_tiles"]})
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": kernel_name, "kernel_us": round(kern_s * 1e6, 2),
+                    "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
+                    "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
+                    "algorithmic_bytes_per_launch": int(local_bytes),
+                    # companions of `frac` (which prices the ALGORITHMIC bytes of SURVEY 8d and may exceed what the
+                    # kernel moves): the bytes the chosen tile classes stream, and the triad measured in this process
+                    "streamed_bytes_per_launch": int(streamed),
+                    "streamed_gbs": round(streamed_gbs, 1), "frac_streamed": round(streamed_gbs / HBM_PEAK_GBS, 4),
+                    "triad_gbs": round(triad_gbs, 1) if triad_gbs else None,
+                    "frac_of_triad": round(streamed_gbs / triad_gbs, 4) if triad_gbs else None,
+                    "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)}
+        if fmt == "csr" and local_nnz > 0:
+            roofline["share_of_entries_not_reading_column_index"] = round(info["shifted_entries"] / local_nnz, 4)
+            roofline["share_of_entries_with_16bit_columns"] = round(info["narrow_entries"] / local_nnz, 4)
+            roofline["share_of_rows_not_reading_row_ptr"] = round(info["uniform_rows"] / max(1, local_rows), 4)
         out = {
-            "metric": "spmv_csr_gflops", "value": round(gflops, 2), "unit": "GFLOP/s",
+            "metric": "spmv_%s_gflops" % fmt, "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wname, "rows": rows, "cols": cols, "nnz": nnz, "format": "csr",
-                       "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
-                       "algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
-                       "lanes_per_row": info["lanes_per_row"], "workgroups": info["workgroups"],
-                       "tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"],
-                       "uniform_tiles": info["uniform_tiles"], "shifted_tiles": info["shifted_tiles"],
-                       "tiles_with_x_window": info["xwin_tiles"], "block_window_tiles": info["blockwin_tiles"],
-                       "column_panel_tiles": info["panel_tiles"],
-                       "partition": ("%s, x replicated, 1 all-gather(y)/step%s" % (
-                           ("rows/%d static chunks" % world) if ranges is None else ("%d row ranges of equal stored entries" % world), ", gather k overlaps multiply k+1" if op.overlap else ""))
-                       if use_dist else "single GPU", "backend": args.backend if use_dist else None,
-                       "rehearsal_shared_gpu": bool(args.share_gpu)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "csr_%s" % capi.CSR_ALGORITHM_NAMES[info["algorithm"]],
-                         "kernel_us": round(kern_s * 1e6, 2), "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
-                         "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
-                         "algorithmic_bytes_per_launch": int(local_bytes),
-                         "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)},
-            "hbm_gbs_whole_step": round(synth.csr_bytes(rows, cols, nnz) / (ms_per_step * 1e-3) / 1e9, 1),
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if (spec is None or spec.startswith("synthetic:")) else "file",
+            "config": config, "roofline": roofline,
+            "hbm_gbs_whole_step": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "setup_s": round(setup_s, 1),
         }
         if gather_us is not None:
             recv = 8.0 * op.chunk * (world - 1)
+            # what the step can reach at best: the local multiply and the gather fully overlapped; the gather is bounded
+            # by the bytes a rank must RECEIVE over its 7 xGMI links (direct all-gather, all links busy)
+            model_gather_us = recv / (7 * XGMI_LINK_GBS * 1e9) * 1e6 if world > 1 else 0.0
             out["multi_gpu"] = {"local_kernel_us": round(kern_s * 1e6, 2), "all_gather_us": round(gather_us, 2),
                                 "all_gather_bytes_received_per_rank": int(recv),
                                 "all_gather_gbs_received_per_rank": round(recv / (gather_us * 1e-6) / 1e9, 1) if world > 1 else None,
                                 "overlap": bool(op.overlap),
+                                "model": {"formula": "predicted_us = max(local_kernel_us, received_bytes / (7 links x %.0f GB/s))" % XGMI_LINK_GBS,
+                                          "gather_us_at_link_rate": round(model_gather_us, 1),
+                                          "predicted_us": round(max(kern_s * 1e6, model_gather_us), 1),
+                                          "measured_us": round(ms_per_step * 1e3, 1)},
                                 "note": "all_gather_us: blocking collective alone, median of 5 after the timed region",
                                 "one_all_gather_after_the_k_multiplies": deferred}
         if gather_check:
             out["gather_check"] = gather_check
             if not gather_check["pass"]:
-                print(json.dumps(out), flush=True)
-                sys.exit("bench.py: gathered y does not match the owning rank's rows")
-        tr = pmc_traffic(out["roofline"]["kernel"], int(local_bytes))
+                code, message = 1, "bench.py: gathered y does not match the owning rank's rows"
+        tr = pmc_traffic(kernel_name, wname, int(local_bytes))
         if tr:
             out["roofline"]["traffic"] = tr[0]
-            out["roofline"]["traffic_source"] = "profiles/" + tr[1]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(
-                args, rows, cols, p, c, v, x, None if y_check is None else y_check.cpu().numpy())
+            out["roofline"]["traffic_source"] = "profiles/" + tr[1] + " (rocprofv3 PMC of an earlier run of this workload, not of this process)"
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args, fmt, rows, cols, host_arrays, x, y_check)
             if out["parity"] and not out["parity"]["pass"]:
-                print(json.dumps(out), flush=True)
-                sys.exit("bench.py: parity check failed: max relative error %.3e > 1e-10"
-                         % out["parity"]["max_rel_err"])
+                code, message = 1, "bench.py: parity check failed: max relative error %s > 1e-10" % out["parity"]["max_rel_err"]
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not use_dist and not args.no_reference_protocol and code == 0:
+            big = nnz > 200e6
+            rp = reference_protocol(args, fmt, 10 if big else 20)
+            if rp is not None:
+                out["reference_protocol"] = rp
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(code, message)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_VERSION 100 /* 1.0.0 */
+#define SPMV_HIP_VERSION 110 /* 1.1.0 */
 
 /* ---- error codes ---------------------------------------------------------- */
 #define SPMV_HIP_OK 0
@@ -84,6 +84,10 @@ extern "C" {
                                                   column panels (a copy of a scattered matrix cut into 8 column ranges,
                                                   one per group of workgroups that share an XCD's L2) */
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
+#define SPMV_HIP_FLAG_VERIFY_PLAN 0x8000u /* spmv_hip_csr_spmv: re-check on EVERY call that the column array still has the
+                                             contents the plan was compressed from (one extra pass over it per multiply;
+                                             by default this is checked on the first multiply only, see spmv_hip_plan_verify) */
+/* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
 typedef struct spmv_hip_plan spmv_hip_plan;
@@ -106,6 +110,12 @@ int spmv_hip_device_count(int *count);
  * reference (it has no device); called from Kernel::init. */
 int spmv_hip_create(spmv_hip_ctx **ctx, int device, unsigned flags);
 void spmv_hip_destroy(spmv_hip_ctx *ctx);
+
+/* Enqueue everything this context does from now on on the caller's `stream` (a hipStream_t on the
+ * context's device; NULL = the default stream), or, with use_own != 0, on the context's own stream
+ * again.  Lets a host program order the multiply against its own work (and time it with its own
+ * events: bench.py).  Waits for the stream in use before switching. */
+int spmv_hip_set_stream(spmv_hip_ctx *ctx, void *stream, int use_own);
 
 /* CSR algorithm for later uploads (default SPMV_HIP_CSR_AUTO);
  * lanes_per_row: 0 = choose, else 2,4,...,64 for SPMV_HIP_CSR_VECTOR. */
@@ -160,7 +170,8 @@ int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
  * [4] csr algorithm in use  [5] lanes per row (vector)  [6] workgroups per launch
  * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns
  * [11] shifted tiles  [12] tiles with an x window  [13] block-window tiles  [14] tiles of the
- * column-panel copy (see spmv_hip_plan_info) */
+ * column-panel copy (see spmv_hip_plan_info)  [15] bytes one run streams with the tile classes in
+ * use (see spmv_hip_plan_info [14]; formats without tiles: their algorithmic bytes) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================
@@ -184,8 +195,16 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  *  - tiles whose x entries fit 256 LDS slots and are each used at least twice: x staged through LDS;
  *  - blocks of 16 plain narrow tiles whose columns span <= 8192: marked for the block-window kernel.
  * Results are unchanged bit for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
- * pointer silently falls back to the 32-bit indices).  Synchronises `stream`. */
+ * pointer falls back to the 32-bit indices and uses nothing derived here).  Because a pointer can be
+ * the same while the contents are not (an allocator reusing the address for another matrix), the plan
+ * keeps a 64-bit checksum of the column array: it is re-computed and compared on the first multiply
+ * after this call, on every multiply with SPMV_HIP_FLAG_VERIFY_PLAN, and by spmv_hip_plan_verify;
+ * a mismatch is SPMV_HIP_ERR_STATE, never a silent wrong result.  Synchronises `stream`. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
+/* Content guard on demand: SPMV_HIP_OK if d_column_index is not the array the plan was compressed from
+ * (nothing derived will be used) or still has the same contents; SPMV_HIP_ERR_STATE if the contents
+ * changed.  One pass over the array; synchronises `stream`. */
+int spmv_hip_plan_verify(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
 /* Optional third planning step (done automatically by spmv_hip_upload_csr), after
  * spmv_hip_plan_csr_compress: for a matrix whose columns are scattered (in most tiles they reach
  * further than an eighth of the matrix, and the tiles are not shifted ones), with at least 4 entries per row, at least 2^20 entries and an x larger than one XCD's L2, the plan makes its
@@ -198,6 +217,11 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_inde
  * plan_info[13] tells.  Costs 12 bytes per entry + 32 bytes per row of device memory.  Synchronises. */
 int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
                              const double *d_value, void *stream);
+/* After changing the VALUES of a matrix whose plan holds column panels (plan_info[18] == 1): copy them
+ * into the panel copy again (structure unchanged; d_value may be a new array, which the plan then
+ * expects).  Does nothing when the plan has no panels.  Asynchronous on `stream`. */
+int spmv_hip_plan_csr_refresh_values(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
+                                     const double *d_value, void *stream);
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);
 /* out[]: [0] algorithm  [1] lanes per row  [2] workgroups  [3] row blocks
  *        [4] long-row blocks  [5] rows  [6] nnz  [7] metadata bytes on device
@@ -206,7 +230,13 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [10] shifted tiles (column offsets read for the first row only)
  *        [11] tiles whose column range fits a 256-entry window of x (x staged through LDS when most tiles qualify)
  *        [12] tiles multiplied by the block-window kernel (x staged through LDS per 16 tiles)
- *        [13] tiles of the column-panel copy (0 = no panels; see spmv_hip_plan_csr_repack) */
+ *        [13] tiles of the column-panel copy (0 = no panels; see spmv_hip_plan_csr_repack)
+ *        [14] bytes one multiply streams with the tile classes chosen: 8 B per value; per column 4 B
+ *             (32-bit), 2 B (16-bit) or nothing (shifted tiles: one first row, or a cached pattern);
+ *             row_ptr 4 B per row of a non-uniform tile; y 16 B per row; x once; 16 B per tile.  The
+ *             ALGORITHMIC bytes of SURVEY 8(d), 12 nnz + 4 (rows + 1) + 16 rows + 8 cols, never shrink
+ *        [15] stored entries in shifted tiles  [16] stored entries in 16-bit tiles
+ *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop
@@ -214,6 +244,15 @@ int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 int spmv_hip_csr_spmv(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
                       const int32_t *d_column_index, const double *d_value,
                       const double *d_x, double *d_y, void *stream);
+/* y_out = y_in + A*x: the same multiply reading the old y from one array and writing the new one to
+ * another (they must not overlap; y_in == y_out is spmv_hip_csr_spmv).  For a row-partitioned multiply
+ * whose previous y segment is still being sent (the all-gather of src/matrix/csr-matrix.cpp:77-95's
+ * row blocks across GPUs): two segment buffers alternate and no copy is needed.  Plans that add
+ * partial sums with atomics (split rows > 2048 entries, column panels) and the non-default
+ * algorithms copy y_in to y_out first. */
+int spmv_hip_csr_spmv_out(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
+                          const int32_t *d_column_index, const double *d_value,
+                          const double *d_x, const double *d_y_in, double *d_y_out, void *stream);
 
 /* y += A*x, COO in any order: wave-level segmented sums + fp64 atomics, i.e. the
  * semantics of coo_spmv_atomic (src/matrix/coo-matrix.cpp:287-309); equals

@@ -53,18 +53,48 @@ namespace {
             return fail_hip(e_, #call);                 \
     } while (0)
 
+// every documented SPMV_HIP_FLAG_* bit; anything else is refused (SPMV_HIP_ERR_INVALID)
+constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
+    SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
+    SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN
+#ifdef SPMV_HIP_EXPERIMENTS
+    | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
+#endif
+    ;
+
 bool aligned16(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kBlock = 256;
 constexpr int kTile = 2048;
-constexpr int kCUs = 256;
+// compute units of the current device (MI355X: 256); asked once per device, 256 if the query fails
+int cu_count()
+{
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void) hipGetLastError();
+        return 256;
+    }
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void) hipGetLastError();
+            n = 256;
+        }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 // wavetile: rows longer than kSplitThreshold entries are cut into kSplitChunk-entry
 // chunks handled by different waves (each adds its partial sum with one atomic)
 constexpr int kSplitThreshold = 2048;
 constexpr int kSplitChunk = 1024;
 
-int grid_for(long long work_items, int per_block, int max_blocks = kCUs * 8)
+int grid_for(long long work_items, int per_block, int max_blocks = 0)
 {
+    if (max_blocks <= 0)
+        max_blocks = cu_count() * 8;
     long long g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
     if (g > max_blocks) g = max_blocks;
@@ -107,13 +137,20 @@ struct spmv_hip_plan {
     int32_t * d_patterns = nullptr; // shared window-of-runs layouts (kernels: kPatStride words each)
     int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
+    int split_rows = 0;    // rows cut into chunks that are added to y with atomics
     size_t meta_bytes = 0;
+    // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
+    long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;
+    // content guard: checksum of the column array the 16-bit stream and the tile marks were derived from
+    unsigned long long column_checksum = 0;
+    bool verify_pending = false; // the first multiply after compress re-checks the checksum
 };
 
 struct spmv_hip_ctx {
     int device = 0;
     unsigned flags = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // where everything of this context is enqueued
+    hipStream_t own_stream = nullptr; // the stream spmv_hip_create made (destroyed with the context)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int format = 0; // 0 none, 1 csr, 2 coo, 3 ell, 4 hybrid (ell + coo remainder)
@@ -234,6 +271,117 @@ int spmv_hip_device_count(int * count)
     return SPMV_HIP_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// flags[0]: an index outside [0, limit); flags[1] (if asked): not non-decreasing
+int device_index_check(const int32_t * d_idx, long long n, int limit, bool want_sorted, bool * bad, bool * sorted, hipStream_t s)
+{
+    *bad = false;
+    if (sorted)
+        *sorted = true;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    int * d_flags = nullptr;
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMalloc((void **) &d_flags, sizeof(flags)));
+    hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(flags), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::index_check_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, limit,
+                           d_idx, d_flags, want_sorted ? 1 : 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_flags);
+    if (e != hipSuccess)
+        return fail_hip(e, "index check");
+    *bad = flags[0] != 0;
+    if (sorted)
+        *sorted = flags[1] == 0;
+    return SPMV_HIP_OK;
+}
+
+int device_column_checksum(const int32_t * d_col, long long n, unsigned long long * out, hipStream_t s)
+{
+    *out = 0;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    unsigned long long * d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_sum, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::column_checksum_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, d_col, d_sum);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_sum);
+    return e == hipSuccess ? SPMV_HIP_OK : fail_hip(e, "column checksum");
+}
+
+// The plan's derived data (16-bit column stream, tile marks, patterns) belong to ONE column array.
+// Pointer identity alone cannot tell a new matrix that an allocator placed at the old address, so
+// the contents are checked: on the first multiply after compress, on every multiply with
+// SPMV_HIP_FLAG_VERIFY_PLAN, and on demand (spmv_hip_plan_verify).
+int verify_plan(spmv_hip_plan * pl, const int32_t * d_column_index, hipStream_t s)
+{
+    pl->verify_pending = false;
+    if (!pl->d_col16 || pl->compressed_from != d_column_index)
+        return SPMV_HIP_OK; // another array: the plan falls back to its 32-bit path, nothing derived is used
+    unsigned long long sum = 0;
+    int rc = device_column_checksum(d_column_index, pl->nnz, &sum, s);
+    if (rc != SPMV_HIP_OK)
+        return rc;
+    if (sum != pl->column_checksum)
+        return fail(SPMV_HIP_ERR_STATE, "the column array at this address is not the one the plan was compressed from "
+                                        "(contents changed): make a new plan");
+    return SPMV_HIP_OK;
+}
+
+// Bytes one multiply streams with the tile classes chosen (bookkeeping for the roofline report):
+// values 8 B per entry; columns 4 B (wide), 2 B (16-bit), one first row (shifted) or nothing
+// (shifted with a pattern); row_ptr 4 B per row of a non-uniform tile; y 16 B per row; x once;
+// 16 B of descriptor per tile.
+int plan_account(spmv_hip_plan * pl, bool compressed)
+{
+    const long long algorithmic = 12LL * pl->nnz + 4LL * (pl->rows + 1LL) + 16LL * pl->rows + 8LL * pl->cols;
+    pl->streamed_bytes = algorithmic;
+    pl->shifted_entries = pl->narrow_entries = pl->uniform_rows = 0;
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0)
+        return SPMV_HIP_OK;
+    std::vector<int4> d((size_t) pl->ntiles + 1);
+    HIP_TRY(hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost));
+    long long bytes = 8LL * pl->cols;
+    for (int w = 0; w < pl->ntiles; ++w) {
+        const long long entries = (long long) d[(size_t) w + 1].y - d[(size_t) w].y;
+        const long long rows = (long long) (d[(size_t) w + 1].x & 0x7FFFFFFF) - (d[(size_t) w].x & 0x7FFFFFFF);
+        const int meta = d[(size_t) w].z;
+        const bool stream_tile = !(d[(size_t) w].x & 0x80000000) && entries > 0 && (meta & spmv::kTileMetaFast);
+        const bool shifted = compressed && stream_tile && (meta & spmv::kTileMetaShifted);
+        const bool narrow = compressed && stream_tile && (meta & spmv::kTileMetaNarrow);
+        const bool uniform = stream_tile && (meta & spmv::kTileMetaUniform);
+        long long col_bytes = 4 * entries;
+        if (shifted) {
+            col_bytes = (meta & spmv::kTileMetaPattern) ? 0 : 4LL * (meta & 0xFFFF);
+            pl->shifted_entries += entries;
+        } else if (narrow) {
+            col_bytes = 2 * entries;
+            pl->narrow_entries += entries;
+        }
+        if (uniform)
+            pl->uniform_rows += rows;
+        bytes += 8 * entries + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+    }
+    pl->streamed_bytes = bytes;
+    return SPMV_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
 /* ================================ Level 2 ======================================= */
 
 static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
@@ -262,6 +410,8 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
             return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
     if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_WAVETILE)
         return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
+    if (flags & ~kKnownFlags)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown flag bits");
     if (lanes_per_row != 0 &&
         (lanes_per_row < 2 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1))))
         return fail(SPMV_HIP_ERR_INVALID, "lanes_per_row must be 0 or a power of two in 2..64");
@@ -287,7 +437,7 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
         pl->workgroups = grid_for(rows, kBlock);
     } else if (algorithm == SPMV_HIP_CSR_VECTOR) {
         pl->lanes_per_row = lanes_per_row ? lanes_per_row : pick_lanes(mean);
-        pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, kCUs * 32);
+        pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, cu_count() * 32);
     } else if (algorithm == SPMV_HIP_CSR_WAVETILE) {
         // wave tiles: <= 64 rows and <= tile entries (from the 4-aligned start) per wave
         const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
@@ -336,6 +486,7 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
                 const long long len = (long long) p[r + 1] - p[r];
                 pl->long_blocks++;
                 if (!exact && len > kSplitThreshold) {
+                    pl->split_rows++;
                     for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
                         desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
                 } else {
@@ -412,6 +563,11 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
                 return rc;
             }
         }
+    }
+    int rc_acc = plan_account(pl, false);
+    if (rc_acc != SPMV_HIP_OK) {
+        spmv_hip_plan_destroy(pl);
+        return rc_acc;
     }
     *out = pl;
     return SPMV_HIP_OK;
@@ -581,7 +737,18 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     }
     pl->meta_bytes += bytes;
     pl->compressed_from = d_column_index;
-    return SPMV_HIP_OK;
+    int rc = device_column_checksum(d_column_index, pl->nnz, &pl->column_checksum, s);
+    if (rc == SPMV_HIP_OK)
+        rc = plan_account(pl, true);
+    pl->verify_pending = true;
+    return rc;
+}
+
+int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    return verify_plan(pl, d_column_index, static_cast<hipStream_t>(stream));
 }
 
 // defined in coo_sort.hip (hipCUB): out[i] = sum of in[0..i), n elements
@@ -602,7 +769,11 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         || !pl->d_col16 /* not compressed: the tile classes are unknown */
         || (long long) pl->rows * 8 + 1 > 0x7FFFFFF0LL)
         return SPMV_HIP_OK;
-    const bool force = (pl->flags & 0x4000u) != 0; // undocumented (tools/gather_locality.py): panels whatever the shape
+#ifdef SPMV_HIP_EXPERIMENTS
+    const bool force = (pl->flags & 0x4000u) != 0; // tools/gather_locality.py: panels whatever the shape
+#else
+    const bool force = false;
+#endif
     if (!force && (!scattered || (long long) pl->cols * 8 < 3 * 1024 * 1024 || (long long) pl->nnz < 4LL * pl->rows
                    || pl->nnz < (1 << 20) /* too small for the gather to matter; keeps small matrices bit-exact */))
         return SPMV_HIP_OK;
@@ -664,6 +835,36 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     pl->panels_from_col = d_column_index;
     pl->panels_from_val = d_value;
     pl->meta_bytes += (size_t) (vrows + 1) * sizeof(int32_t) + (size_t) pl->nnz * 12 + pl->inner->meta_bytes;
+    // what the panel copy streams: its own tiles, with y counted once per row and panel that has entries
+    {
+        long long nonempty = 0;
+        for (long long v = 0; v < vrows; ++v)
+            nonempty += vrow_ptr[(size_t) v + 1] > vrow_ptr[(size_t) v];
+        pl->streamed_bytes = pl->inner->streamed_bytes - 16LL * vrows + 16LL * nonempty;
+        pl->shifted_entries = pl->inner->shifted_entries;
+        pl->narrow_entries = pl->inner->narrow_entries;
+        pl->uniform_rows = 0;
+    }
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_plan_csr_refresh_values(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                                     const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (!pl->inner)
+        return SPMV_HIP_OK; // no snapshot: the multiply reads the caller's values
+    if (!d_row_ptr || !d_column_index || !d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (d_column_index != pl->panels_from_col)
+        return fail(SPMV_HIP_ERR_STATE, "the column panels were made from another column array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned) ((pl->rows + 255) / 256);
+    hipLaunchKernelGGL(spmv::csr_panel_scatter_kernel, dim3(grid), dim3(256), 0, s, pl->rows, (pl->cols + 7) / 8, d_row_ptr,
+                       d_column_index, d_value, pl->d_vrow_ptr, pl->d_pcol, pl->d_pval);
+    HIP_TRY(hipGetLastError());
+    pl->panels_from_val = d_value;
     return SPMV_HIP_OK;
 }
 
@@ -671,11 +872,12 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[14] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[19] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
-                           pl->inner ? pl->inner->ntiles : 0};
-    for (int i = 0; i < n && i < 14; ++i)
+                           pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
+                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0};
+    for (int i = 0; i < n && i < 19; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -683,15 +885,40 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j,
                       const double * a, const double * x, double * y, void * stream)
 {
+    return spmv_hip_csr_spmv_out(pl, p, j, a, x, y, y, stream);
+}
+
+int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
+                          const double * x, const double * y_in, double * y, void * stream)
+{
     if (!pl)
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
     if (pl->rows == 0)
         return SPMV_HIP_OK;
-    if (!p || !y || (pl->nnz > 0 && (!j || !a || !x)))
+    if (!p || !y || !y_in || (pl->nnz > 0 && (!j || !a || !x)))
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
     if (!aligned16(j) || !aligned16(a))
         return fail(SPMV_HIP_ERR_ALIGN, "column_index/value must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool panels_now = pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->inner && pl->panels_from_col == j
+        && pl->panels_from_val == a && pl->panel_blocks > 0;
+    if (y_in != y) {
+        const double * lo = y_in < y ? y_in : y, * hi = y_in < y ? y : y_in;
+        if (lo + pl->rows > hi)
+            return fail(SPMV_HIP_ERR_INVALID, "y_in and y_out overlap");
+        // kernels that read y_in and write y_out row by row take the pair as it is; the others
+        // (atomic partial sums: split long rows, column panels; the non-default algorithms) get
+        // y_out = y_in first and then accumulate in place
+        if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->split_rows > 0 || panels_now) {
+            HIP_TRY(hipMemcpyAsync(y, y_in, (size_t) pl->rows * sizeof(double), hipMemcpyDeviceToDevice, s));
+            y_in = y;
+        }
+    }
+    if (pl->verify_pending || (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN)) {
+        int rc = verify_plan(const_cast<spmv_hip_plan *>(pl), j, s);
+        if (rc != SPMV_HIP_OK)
+            return rc;
+    }
     switch (pl->algorithm) {
     case SPMV_HIP_CSR_SCALAR:
         hipLaunchKernelGGL((spmv::csr_scalar_kernel<kBlock>), dim3(pl->workgroups), dim3(kBlock), 0, s,
@@ -708,18 +935,18 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
         }
         break;
     case SPMV_HIP_CSR_WAVETILE:
-        if (pl->inner && pl->panels_from_col == j && pl->panels_from_val == a && pl->panel_blocks > 0) {
+        if (panels_now) {
             // column panels: the plan's panel-major copy, one panel per XCD label, atomic partial sums
             const spmv_hip_plan * in = pl->inner;
             const bool x32 = pl->cols < (1 << 29);
             const dim3 grid((unsigned) (8 * pl->panel_blocks));
             if (x32)
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, true>), grid, dim3(256), 0, s, in->ntiles,
-                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, pl->nnz, pl->cols, 0,
+                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, y, pl->nnz, pl->cols, 0,
                                    in->d_patterns, pl->pinfo);
             else
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, true>), grid, dim3(256), 0, s, in->ntiles,
-                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, pl->nnz, pl->cols, 0,
+                                   in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, y, pl->nnz, pl->cols, 0,
                                    in->d_patterns, pl->pinfo);
         } else if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
@@ -730,10 +957,12 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             const bool x32 = pl->cols < (1 << 29);
 #define SPMV_WT_LAUNCH(T, C, X, R)                                                                    \
     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<T, C, X, R>), dim3(pl->workgroups), dim3(256), 0, s, \
-                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{})
+                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{})
 #define SPMV_WT_X(T, C, R)  do { if (x32) SPMV_WT_LAUNCH(T, C, true, R); else SPMV_WT_LAUNCH(T, C, false, R); } while (0)
 #define SPMV_WT_C(T, R)     do { if (c16) SPMV_WT_X(T, true, R); else SPMV_WT_X(T, false, R); } while (0)
-            const int abl = (int) ((pl->flags >> 16) & 3); // undocumented timing experiments (kernel_sweep.py)
+#ifdef SPMV_HIP_EXPERIMENTS
+            const int abl = (int) ((pl->flags >> 16) & 3); // timing experiments (kernel_sweep.py): wrong results by design
+#endif
             // every tile belongs to the block-window kernel below: nothing for this launch to do
             const bool all_blockwin = c16 && pl->d_blocks && pl->blockwin_tiles == pl->ntiles;
             if (all_blockwin) {
@@ -744,12 +973,16 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
                 && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
-                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
-            } else if (abl && c16 && x32 && pl->tile == 512) {
-                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
-                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
-                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
-            } else if (pl->tile == 1024) {
+                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+            }
+#ifdef SPMV_HIP_EXPERIMENTS
+            else if (abl && c16 && x32 && pl->tile == 512) {
+                if (abl == 1) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 1>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+                else if (abl == 2) hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 2>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+                else hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 3>), dim3(pl->workgroups), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+            }
+#endif
+            else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
@@ -760,15 +993,18 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
             // the tiles marked for a block window were skipped above (only when the 16-bit column
             // stream is valid for this column array, like the marks themselves)
             if (c16 && pl->d_blocks) {
-                if (pl->flags & 0x2000u) { // undocumented (tools/kernel_sweep.py): one workgroup per block, no sliding window
+#ifdef SPMV_HIP_EXPERIMENTS
+                if (pl->flags & 0x2000u) { // tools/kernel_sweep.py: one workgroup per block, no sliding window
                     hipLaunchKernelGGL((spmv::csr_blockwin_kernel<512>), dim3(pl->nblocks16), dim3(1024), 0, s, pl->ntiles,
-                                       pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
-                } else {
+                                       pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y_in, y);
+                } else
+#endif
+                {
                     // persistent workgroups, one per CU, each walking through consecutive blocks
-                    const int groups = std::min(pl->nblocks16, kCUs);
+                    const int groups = std::min(pl->nblocks16, cu_count());
                     const int per_group = (pl->nblocks16 + groups - 1) / groups;
                     hipLaunchKernelGGL((spmv::csr_blockwin_stream_kernel<512>), dim3(groups), dim3(1024), 0, s, pl->ntiles,
-                                       pl->nblocks16, per_group, pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y);
+                                       pl->nblocks16, per_group, pl->d_tiles, pl->d_blocks, p, pl->d_col16, a, x, y_in, y);
                 }
             }
         }
@@ -785,10 +1021,14 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
     return SPMV_HIP_OK;
 }
 
-/* Not part of the ABI (tools/kernel_sweep.py, tests): 0 = default choice, 1 = always the
+#ifdef SPMV_HIP_EXPERIMENTS
+/* libspmv_hip_experiments.so only (tools/kernel_sweep.py): 0 = default choice, 1 = always the
  * 64-entries-per-wave kernel. */
 static int g_coo_variant = 0;
 void spmv_hip_coo_variant(int variant) { g_coo_variant = variant; }
+#else
+static const int g_coo_variant = 0;
+#endif
 
 int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32_t * ci,
                       const double * v, const double * x, double * y, void * stream)
@@ -805,7 +1045,7 @@ int spmv_hip_coo_spmv(int32_t rows, int32_t nnz, const int32_t * ri, const int32
         const unsigned grid = (unsigned) (((long long) nnz + 1023) / 1024);
         hipLaunchKernelGGL((spmv::coo_wide_kernel<false>), dim3(grid), dim3(256), 0, s, nnz, ri, ci, v, x, y, spmv::CooPanels{});
     } else {
-        const int grid = grid_for(nnz, kBlock, kCUs * 16);
+        const int grid = grid_for(nnz, kBlock, cu_count() * 16);
         hipLaunchKernelGGL((spmv::coo_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, nnz, ri, ci, v, x, y);
     }
     HIP_TRY(hipGetLastError());
@@ -825,7 +1065,7 @@ int spmv_hip_ell_to_column_major(int32_t rows, int32_t row_length, const int32_t
     if (!j_rm || !a_rm || !j_cm || !a_cm)
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(n, kBlock, kCUs * 16);
+    const int grid = grid_for(n, kBlock, cu_count() * 16);
     hipLaunchKernelGGL((spmv::ell_transpose_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, rows,
                        row_length, j_rm, a_rm, j_cm, a_cm);
     HIP_TRY(hipGetLastError());
@@ -845,7 +1085,7 @@ int spmv_hip_ell_spmv(int32_t rows, int32_t row_length, const int32_t * j, const
     if (!y || (n > 0 && (!j || !a || !x)))
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(rows, kBlock, kCUs * 16);
+    const int grid = grid_for(rows, kBlock, cu_count() * 16);
     hipLaunchKernelGGL((spmv::ell_kernel<kBlock>), dim3(grid), dim3(kBlock), 0, s, rows, row_length, j, a, x, y);
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
@@ -875,6 +1115,7 @@ int spmv_hip_triad(int64_t n, double * a, const double * b, const double * c, do
     return SPMV_HIP_OK;
 }
 
+#ifdef SPMV_HIP_EXPERIMENTS
 /* Not in the header: A/B variants of the triad for tools/kernel_sweep.py.
  * 0 = grid-stride unroll 4 on 8 workgroups per CU, 1 = one element per lane (flat grid),
  * 2 = flat + non-temporal stores (the shipped kernel),
@@ -885,7 +1126,7 @@ int spmv_hip_triad_variant(int64_t n, double * a, const double * b, const double
     if (n & 1)
         return spmv_hip_triad(n, a, b, c, q, stream);
     if (variant == 0) {
-        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(kCUs * 8), dim3(kBlock), 0, static_cast<hipStream_t>(stream), (long long) n, a, b, c, q);
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(cu_count() * 8), dim3(kBlock), 0, static_cast<hipStream_t>(stream), (long long) n, a, b, c, q);
         HIP_TRY(hipGetLastError());
         return SPMV_HIP_OK;
     }
@@ -898,13 +1139,14 @@ int spmv_hip_triad_variant(int64_t n, double * a, const double * b, const double
         else
             hipLaunchKernelGGL((spmv::triad_flat_kernel<kBlock, true>), dim3((unsigned) grid), dim3(kBlock), 0, s, n2, a, b, c, q);
     } else if (variant == 3) {
-        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(kCUs * 16), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 4>), dim3(cu_count() * 16), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
     } else {
-        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 8>), dim3(kCUs * 8), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
+        hipLaunchKernelGGL((spmv::triad_kernel<kBlock, 8>), dim3(cu_count() * 8), dim3(kBlock), 0, s, (long long) n, a, b, c, q);
     }
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
 }
+#endif
 
 /* ================================ Level 1 ======================================= */
 
@@ -921,13 +1163,16 @@ int spmv_hip_create(spmv_hip_ctx ** out, int device, unsigned flags)
     }
     if (device < 0 || device >= n)
         return fail(SPMV_HIP_ERR_INVALID, "device index out of range");
+    if (flags & ~kKnownFlags)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown flag bits");
     HIP_TRY(hipSetDevice(device));
     spmv_hip_ctx * c = new (std::nothrow) spmv_hip_ctx;
     if (!c)
         return fail(SPMV_HIP_ERR_ALLOC, "ctx allocation failed");
     c->device = device;
     c->flags = flags;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    c->stream = c->own_stream;
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -944,13 +1189,23 @@ void spmv_hip_destroy(spmv_hip_ctx * c)
     if (!c)
         return;
     (void) hipSetDevice(c->device);
-    if (c->stream)
+    if (c->own_stream)
         (void) hipStreamSynchronize(c->stream);
     free_ctx_matrix(c);
     if (c->ev0) (void) hipEventDestroy(c->ev0);
     if (c->ev1) (void) hipEventDestroy(c->ev1);
-    if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+int spmv_hip_set_stream(spmv_hip_ctx * c, void * stream, int use_own)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // nothing of the old stream is left behind
+    c->stream = use_own ? c->own_stream : static_cast<hipStream_t>(stream);
+    return SPMV_HIP_OK;
 }
 
 int spmv_hip_set_csr_algorithm(spmv_hip_ctx * c, int algorithm, int lanes_per_row)
@@ -973,9 +1228,6 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
     if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
         return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
-    for (int32_t k = 0; k < nnz; ++k)
-        if (column_index[k] < 0 || column_index[k] >= cols)
-            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_ctx_matrix(c);
@@ -994,7 +1246,14 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the column indices are range-checked where they now are, at HBM speed (row_ptr was checked by
+    // the plan builder); a bad file must not become an out-of-bounds gather
+    bool bad = false;
+    if ((rc = device_index_check(c->d_col, nnz, cols, false, &bad, nullptr, c->stream)) != 0) return rc;
+    if (bad) {
+        free_ctx_matrix(c);
+        return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
+    }
     if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
         if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
         // scattered columns and an x that does not fit one XCD's L2: column panels (the context owns
@@ -1066,12 +1325,6 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
     bool row_sorted = true;
-    for (int32_t k = 0; k < nnz; ++k) {
-        if (row_index[k] < 0 || row_index[k] >= rows || column_index[k] < 0 || column_index[k] >= cols)
-            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
-        if (k > 0 && row_index[k] < row_index[k - 1])
-            row_sorted = false;
-    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_ctx_matrix(c);
@@ -1088,7 +1341,15 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        bool bad_row = false, bad_col = false;
+        if ((rc = device_index_check(c->d_idx, nnz, rows, true, &bad_row, &row_sorted, c->stream)) != 0) return rc;
+        if ((rc = device_index_check(c->d_col, nnz, cols, false, &bad_col, nullptr, c->stream)) != 0) return rc;
+        if (bad_row || bad_col) {
+            free_ctx_matrix(c);
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+        }
+    }
     if (!row_sorted && !(c->flags & SPMV_HIP_FLAG_COO_KEEP_ORDER)) {
         if ((rc = spmv_hip_coo_sort_by_row(rows, nnz, c->d_idx, c->d_col, c->d_val, c->stream)) != 0) return rc;
         c->coo_sorted_on_device = true;
@@ -1111,9 +1372,6 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
         return fail(SPMV_HIP_ERR_OVERFLOW, "Integer overflow when computing number of non-zeros");
     if (n > 0 && (!column_index || !value))
         return fail(SPMV_HIP_ERR_INVALID, "null ELL arrays");
-    for (int32_t k = 0; k < n; ++k)
-        if (column_index[k] < 0 || column_index[k] >= cols)
-            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_ctx_matrix(c);
@@ -1142,7 +1400,12 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
         HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr.data(), ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        bool bad = false;
+        if ((rc = device_index_check(c->d_col, n, cols, false, &bad, nullptr, c->stream)) != 0) return rc;
+        if (bad) {
+            free_ctx_matrix(c);
+            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
+        }
         if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION))
             if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
     } else if (n > 0) {
@@ -1157,6 +1420,15 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
         e = hipMemcpyAsync(t_col, column_index, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(t_val, value, (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        bool bad = false;
+        if (e == hipSuccess && device_index_check(t_col, n, cols, false, &bad, nullptr, c->stream) != 0)
+            e = hipErrorUnknown;
+        if (e == hipSuccess && bad) {
+            (void) hipFree(t_col);
+            (void) hipFree(t_val);
+            free_ctx_matrix(c);
+            return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
+        }
         if (e == hipSuccess) {
             rc = spmv_hip_ell_to_column_major(rows, row_length, t_col, t_val, c->d_col, c->d_val, c->stream);
             e = hipStreamSynchronize(c->stream);
@@ -1183,28 +1455,38 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
-    for (int32_t k = 0; k < num_coo_entries; ++k)
-        if (coo_row_index[k] < 0 || coo_row_index[k] >= rows || coo_column_index[k] < 0 ||
-            coo_column_index[k] >= cols)
-            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
     // the ELL part is uploaded (validated, transposed) exactly like a plain ELLPACK matrix ...
     int rc = spmv_hip_upload_ell(c, rows, cols, ell_row_length, ell_column_index, ell_value);
     if (rc != 0)
         return rc;
-    // ... and the COO remainder rides along
+    // ... and the COO remainder rides along; should that fail, the context is left without a matrix
     c->format = 0;
     c->nnz2 = num_coo_entries;
-    if ((rc = dev_alloc(c, &c->d_idx, (size_t) num_coo_entries)) != 0) return rc;
-    if ((rc = dev_alloc(c, &c->d_col2, (size_t) num_coo_entries)) != 0) return rc;
-    if ((rc = dev_alloc(c, &c->d_val2, (size_t) num_coo_entries)) != 0) return rc;
-    if (num_coo_entries > 0) {
-        HIP_TRY(hipMemcpyAsync(c->d_idx, coo_row_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_col2, coo_column_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_val2, coo_value, (size_t) num_coo_entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    auto remainder = [&]() -> int {
+        int r;
+        if ((r = dev_alloc(c, &c->d_idx, (size_t) num_coo_entries)) != 0) return r;
+        if ((r = dev_alloc(c, &c->d_col2, (size_t) num_coo_entries)) != 0) return r;
+        if ((r = dev_alloc(c, &c->d_val2, (size_t) num_coo_entries)) != 0) return r;
+        if (num_coo_entries > 0) {
+            HIP_TRY(hipMemcpyAsync(c->d_idx, coo_row_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_col2, coo_column_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_val2, coo_value, (size_t) num_coo_entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        bool bad_row = false, bad_col = false;
+        if ((r = device_index_check(c->d_idx, num_coo_entries, rows, false, &bad_row, nullptr, c->stream)) != 0) return r;
+        if ((r = device_index_check(c->d_col2, num_coo_entries, cols, false, &bad_col, nullptr, c->stream)) != 0) return r;
+        if (bad_row || bad_col)
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+        // the remainder is in (row, column) order (hybrid-matrix.cpp:316-417): panels where it is scattered
+        return ctx_coo_panels(c, c->d_idx, c->d_col2, c->d_val2, num_coo_entries);
+    };
+    rc = remainder();
+    if (rc != 0) {
+        std::string const keep = g_last_error;
+        free_ctx_matrix(c);
+        g_last_error = keep;
+        return rc;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // the remainder is in (row, column) order (hybrid-matrix.cpp:316-417): panels where it is scattered
-    if ((rc = ctx_coo_panels(c, c->d_idx, c->d_col2, c->d_val2, num_coo_entries)) != 0) return rc;
     c->format = 4;
     return SPMV_HIP_OK;
 }
@@ -1305,8 +1587,16 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
 {
     if (!c || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
-    int64_t v[15] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0};
+    int64_t v[16] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0};
+    // [15] bytes one run streams: the plan's count where tiles are used, else the format's algorithmic bytes
+    switch (c->format) {
+    case 2: v[15] = 16LL * c->nnz + 16LL * c->rows + 8LL * c->cols; break;
+    case 3: v[15] = 12LL * c->nnz + 16LL * c->rows + 8LL * c->cols; break;
+    case 4: v[15] = 12LL * c->nnz + 16LL * c->nnz2 + 16LL * c->rows + 8LL * c->cols; break;
+    default: break;
+    }
     if (c->plan) {
+        v[15] = c->plan->streamed_bytes + (c->format == 4 ? 16LL * c->nnz2 : 0);
         v[4] = c->plan->algorithm;
         v[5] = c->plan->lanes_per_row;
         v[6] = c->plan->workgroups;
@@ -1321,7 +1611,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
     }
     if (c->d_prow)
         v[14] += c->coo_panel_blocks; // COO (part) in column panels: workgroups per panel
-    for (int i = 0; i < n && i < 15; ++i)
+    for (int i = 0; i < n && i < 16; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -619,9 +619,12 @@ template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool 
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
-    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y_arg,
+    const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
     int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo)
 {
+    // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
+    // different ones (a partitioned multiply whose previous result is still being gathered); every
+    // row is read and written by the same lane, so the in-place case needs no ordering.
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
     int w;
-    double * __restrict__ y = y_arg;
+    double * y = y_arg;
+    const double * y_in = y_in_arg;
     if (PANELS) {
         const int pk = (int) blockIdx.x & 7;
         w = pinfo.first[pk] + ((int) blockIdx.x >> 3) * 4 + wave;
@@ -680,7 +684,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             ps = pt[rowi];
             pe = pt[rowi + 1];
         }
-        const double yv = PANELS ? 0.0 : yt[rowi]; // panels: the partial sums are added atomically
+        const double * yin_t = y_in + r0;
+        const double yv = PANELS ? 0.0 : yin_t[rowi]; // panels: the partial sums are added atomically
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
         const bool second = nrows > kWave; // wave-uniform; implies one lane per row
         int psB = 0, peB = 0;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 peB = p[r0 + rowB + 1];
             }
             if (!PANELS)
-                yvB = yt[rowB];
+                yvB = yin_t[rowB];
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(y + r0 + r, z);
             else
-                y[r0 + r] += z;
+                y[r0 + r] = y_in[r0 + r] + z;
         }
     } else if (!exact_order) {
         // ---- one long row, or one chunk of a very long row: the wave strides it ----------
@@ -801,9 +806,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
         if (lane == 0) {
             if (partial || PANELS)
-                unsafeAtomicAdd(y + r0, z);
+                unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ
             else
-                y[r0] += z;
+                y[r0] = y_in[r0] + z;
         }
     } else {
         // ---- one long row in the reference's order: lane 0 adds tiles of products ---------
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(y + r0, z);
             else
-                y[r0] += z;
+                y[r0] = y_in[r0] + z;
         }
     }
 }
@@ -896,7 +901,7 @@ template <int TILE>
 __global__ __launch_bounds__(1024) void csr_blockwin_kernel(
     int ntiles, const int4 * __restrict__ desc, const int2 * __restrict__ blocks,
     const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
-    const double * __restrict__ x, double * __restrict__ y)
+    const double * __restrict__ x, const double * y_in, double * y)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     constexpr int QUADS = TILE / 256;
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(1024) void csr_blockwin_kernel(
             ps = p[r0 + rowi];
             pe = p[r0 + rowi + 1];
         }
-        yv = y[r0 + rowi];
+        yv = y_in[r0 + rowi];
         second = nrows > kWave;
         if (second) {
             const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(1024) void csr_blockwin_kernel(
                 psB = p[r0 + rowB];
                 peB = p[r0 + rowB + 1];
             }
-            yvB = y[r0 + rowB];
+            yvB = y_in[r0 + rowB];
         }
 #pragma unroll
         for (int q = 0; q < QUADS; ++q) {
@@ -1041,7 +1046,7 @@ struct BwTile {
 template <int TILE>
 __device__ __forceinline__ void bw_load_tile(
     BwTile<TILE / 256> & t, int w, int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
-    const uint16_t * __restrict__ j16, const double * __restrict__ a, const double * __restrict__ y, int lane)
+    const uint16_t * __restrict__ j16, const double * __restrict__ a, const double * y, int lane)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     constexpr int QUADS = TILE / 256;
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void bw_load_tile(
 
 template <int TILE>
 __device__ __forceinline__ void bw_compute_tile(
-    const BwTile<TILE / 256> & t, double * prod, const double * xring, double * __restrict__ y, int lane)
+    const BwTile<TILE / 256> & t, double * prod, const double * xring, double * y, int lane)
 {
     constexpr int QUADS = TILE / 256;
     const unsigned base = (unsigned) t.cbase;
@@ -1161,7 +1166,7 @@ template <int TILE>
 __global__ __launch_bounds__(1024) void csr_blockwin_stream_kernel(
     int ntiles, int nblocks, int blocks_per_group, const int4 * __restrict__ desc, const int2 * __restrict__ blocks,
     const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
-    const double * __restrict__ x, double * __restrict__ y)
+    const double * __restrict__ x, const double * y_in, double * y)
 {
     constexpr int XS = kBlockWinSlots / 1024; // window increments a thread may have to carry
     __shared__ double xring[kBlockRing];
@@ -1185,7 +1190,7 @@ __global__ __launch_bounds__(1024) void csr_blockwin_stream_kernel(
         const int span = __builtin_amdgcn_readfirstlane(bd.y);
         xs_lo = xs_from = __builtin_amdgcn_readfirstlane(bd.x);
         xs_hi = xs_lo + (span > 0 ? span : 0);
-        bw_load_tile<TILE>(nxt, b_begin * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y, lane);
+        bw_load_tile<TILE>(nxt, b_begin * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y_in, lane);
 #pragma unroll
         for (int k = 0; k < XS; ++k) {
             const int i = xs_from + tid + 1024 * k;
@@ -1217,7 +1222,7 @@ __global__ __launch_bounds__(1024) void csr_blockwin_stream_kernel(
             xs_hi = xs_lo + (span > 0 ? span : 0);
             // columns already in the ring stay valid if the new window starts inside the old one
             xs_from = (whi > wlo && xs_lo >= wlo && xs_lo <= whi) ? max(whi, xs_lo) : xs_lo;
-            bw_load_tile<TILE>(nxt, (b + 1) * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y, lane);
+            bw_load_tile<TILE>(nxt, (b + 1) * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y_in, lane);
 #pragma unroll
             for (int k = 0; k < XS; ++k) {
                 const int i = xs_from + tid + 1024 * k;
@@ -1718,6 +1723,48 @@ __global__ __launch_bounds__(BLOCK) void ell_transpose_kernel(
         j_cm[l * rows + i] = j_rm[k];
         a_cm[l * rows + i] = a_rm[k];
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Upload-time checks on the device (the host arrays are never walked entry by entry).
+// index_check_kernel: flags[0] |= 1 if any idx[k] is outside [0, limit); with `sorted_flag`,
+// flags[1] |= 1 if idx is not non-decreasing.  column_checksum_kernel: out += sum over k of
+// hash(k, j[k]) -- the plan's content guard (a different array at the same address changes it).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void index_check_kernel(
+    long long n, int limit, const int32_t * __restrict__ idx, int * __restrict__ flags, int sorted_flag)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    int bad = 0, unsorted = 0;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        const int v = idx[k];
+        bad |= (v < 0) | (v >= limit);
+        if (sorted_flag && k > 0)
+            unsorted |= v < idx[k - 1];
+    }
+    if (__any(bad) && (int) __lane_id() == 0)
+        atomicOr(flags, 1);
+    if (sorted_flag && __any(unsorted) && (int) __lane_id() == 0)
+        atomicOr(flags + 1, 1);
+}
+
+__global__ __launch_bounds__(256) void column_checksum_kernel(
+    long long n, const int32_t * __restrict__ j, unsigned long long * __restrict__ out)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    unsigned long long h = 0;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        unsigned long long t = (unsigned long long) k * 0x9E3779B97F4A7C15ull + (unsigned long long) (unsigned) j[k];
+        t ^= t >> 29;
+        t *= 0xBF58476D1CE4E5B9ull;
+        t ^= t >> 32;
+        h += t;
+    }
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1)
+        h += __shfl_xor(h, d);
+    if ((int) __lane_id() == 0)
+        atomicAdd(out, h);
 }
 
 // ---------------------------------------------------------------------------------

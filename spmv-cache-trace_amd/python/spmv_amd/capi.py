@@ -11,6 +11,10 @@ import numpy as np
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB_PATH = os.path.join(PKG_ROOT, "libspmv_hip.so")
+# tools/ only: SPMV_HIP_EXPERIMENTS=1 loads the build with the timing experiments compiled in
+EXPERIMENTS_LIB_PATH = os.path.join(PKG_ROOT, "libspmv_hip_experiments.so")
+if os.environ.get("SPMV_HIP_EXPERIMENTS") == "1":
+    LIB_PATH = EXPERIMENTS_LIB_PATH
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 
 OK = 0
@@ -20,6 +24,7 @@ FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG
 FLAG_NO_SHIFTED_TILES = 0x400
 FLAG_NO_X_WINDOW = 0x800
 FLAG_NO_COLUMN_PANELS = 0x1000
+FLAG_VERIFY_PLAN = 0x8000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -35,6 +40,7 @@ SIGNATURES = {
     "spmv_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "spmv_hip_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_uint]),
     "spmv_hip_destroy": (None, [_vp]),
+    "spmv_hip_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "spmv_hip_set_csr_algorithm": (C.c_int, [_vp, C.c_int, C.c_int]),
     "spmv_hip_upload_csr": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
     "spmv_hip_upload_coo": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
@@ -49,10 +55,13 @@ SIGNATURES = {
     "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_plan_csr": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _i32p, C.c_int, C.c_int, C.c_uint]),
     "spmv_hip_plan_csr_compress": (C.c_int, [_vp, _vp, _vp]),
+    "spmv_hip_plan_verify": (C.c_int, [_vp, _vp, _vp]),
     "spmv_hip_plan_csr_repack": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_plan_csr_refresh_values": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_plan_destroy": (None, [_vp]),
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_csr_spmv_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_coo_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_coo_sort_by_row": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_to_column_major": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
@@ -164,6 +173,11 @@ class Context:
         except Exception:
             pass
 
+    def set_stream(self, stream=None):
+        """Launch on the caller's stream (a raw hipStream_t, e.g. torch's cuda_stream); None = the
+        context's own stream again."""
+        check(self.lib.spmv_hip_set_stream(self.h, stream or 0, 1 if stream is None else 0))
+
     def set_csr_algorithm(self, algorithm, lanes_per_row=0):
         check(self.lib.spmv_hip_set_csr_algorithm(self.h, algorithm, lanes_per_row))
 
@@ -229,11 +243,11 @@ class Context:
         return ns.value
 
     def info(self):
-        out = np.zeros(15, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 15))
+        out = np.zeros(16, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 16))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
                 "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles",
-                "blockwin_tiles", "panel_tiles"]
+                "blockwin_tiles", "panel_tiles", "streamed_bytes"]
         return dict(zip(keys, out.tolist()))
 
 
@@ -259,10 +273,11 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(14, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 14))
+        out = np.zeros(19, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 19))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
-                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles"]
+                "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
+                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):
@@ -278,14 +293,29 @@ class CsrPlan:
         """All arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""
         check(self.lib.spmv_hip_csr_spmv(self.h, d_row_ptr, d_col, d_val, d_x, d_y, stream))
 
+    def spmv_out(self, d_row_ptr, d_col, d_val, d_x, d_y_in, d_y_out, stream=0):
+        """y_out = y_in + A*x (two different arrays, or the same one)."""
+        check(self.lib.spmv_hip_csr_spmv_out(self.h, d_row_ptr, d_col, d_val, d_x, d_y_in, d_y_out, stream))
+
+    def verify(self, d_col, stream=0):
+        """Raises SpmvHipError (ERR_STATE) if d_col no longer has the contents the plan was compressed from."""
+        check(self.lib.spmv_hip_plan_verify(self.h, d_col, stream))
+
+    def refresh_values(self, d_row_ptr, d_col, d_val, stream=0):
+        """Re-copy the values into the plan's column-panel copy (no-op without panels)."""
+        check(self.lib.spmv_hip_plan_csr_refresh_values(self.h, d_row_ptr, d_col, d_val, stream))
+
 
 def coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream=0):
     check(load().spmv_hip_coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream))
 
 
 def coo_variant(variant):
-    """Test / sweep hook, not part of the C ABI: 1 = always the 64-entries-per-wave COO kernel."""
+    """Sweep hook of libspmv_hip_experiments.so (SPMV_HIP_EXPERIMENTS=1), not part of the C ABI:
+    1 = always the 64-entries-per-wave COO kernel."""
     lib = load()
+    if not hasattr(lib, "spmv_hip_coo_variant"):
+        raise RuntimeError("spmv_hip_coo_variant needs the experiments build (SPMV_HIP_EXPERIMENTS=1)")
     lib.spmv_hip_coo_variant.argtypes = [C.c_int]
     lib.spmv_hip_coo_variant.restype = None
     lib.spmv_hip_coo_variant(variant)

@@ -12,12 +12,21 @@ contiguous split (``ranges``, e.g. partition.nnz_balanced_ranges for matrices wi
 uneven rows) pads every segment to the longest one; y() then drops the padding.
 
 With ``overlap=True`` the gather of multiply k runs on the collective's stream while
-multiply k+1 runs on the compute stream: the segment is snapshotted into a send buffer
-(the kernels accumulate into y_local, so it cannot be sent from in place), and the next
-snapshot waits for the previous gather.  Every multiply is still gathered exactly once.
+multiply k+1 runs on the compute stream.  The kernels accumulate (y += A*x), so the
+segment that is being sent must not be the one the next multiply writes:
 
-The local multiply is injected (``local_spmv``) so the partition / gather logic can
-be exercised with gloo on CPU tensors; the product constructor
+* ``pingpong=True`` (default): two segment buffers alternate.  Multiply k reads the old
+  segment from one and writes the new one to the other (spmv_hip_csr_spmv_out:
+  y_out = y_in + A*x), gather k sends what multiply k wrote, multiply k+1 only READS that
+  buffer and writes the first one again -- which gather k-1 must have finished sending, the
+  only wait on the compute stream.  No copy.
+* ``pingpong=False``: one buffer, snapshotted into a send buffer before every gather
+  (one extra read + write of the segment per step; round 1's scheme).
+
+Every multiply is still gathered exactly once.
+
+The local multiply is injected (``local_spmv``, optionally ``local_spmv_out``) so the
+partition / gather logic can be exercised with gloo on CPU tensors; the product constructor
 ``DistributedCsrSpmv.on_gpu`` wires in the HIP path and has no other option.
 """
 import numpy as np
@@ -29,7 +38,7 @@ from . import capi, partition
 
 class DistributedCsrSpmv:
     def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None, overlap=False,
-                 ranges=None):
+                 ranges=None, local_spmv_out=None, pingpong=True):
         self.rows, self.cols = rows, cols
         self.rank, self.world = rank, world
         if ranges is None:
@@ -49,16 +58,24 @@ class DistributedCsrSpmv:
         self.device = device
         self.group = group
         self.local_spmv = local_spmv
-        # padded local segment and the gathered vector (world * chunk >= rows)
-        self.y_local = torch.zeros(self.chunk, dtype=torch.float64, device=device)
-        self.y_full = torch.zeros(self.chunk * world, dtype=torch.float64, device=device)
+        if local_spmv_out is None:
+            def local_spmv_out(y_in, y_out):  # generic: copy, then accumulate in place
+                y_out.copy_(y_in)
+                local_spmv(y_out)
+        self.local_spmv_out = local_spmv_out
         self.overlap = overlap
-        self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device) if overlap else None
-        self.pending = None
+        self.pingpong = bool(pingpong and overlap)
+        # padded local segment(s) and the gathered vector (world * chunk >= rows)
+        self.seg = [torch.zeros(self.chunk, dtype=torch.float64, device=device) for _ in range(2 if self.pingpong else 1)]
+        self.cur = 0  # the segment buffer that holds the current y_local
+        self.y_full = torch.zeros(self.chunk * world, dtype=torch.float64, device=device)
+        self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device) if (overlap and not self.pingpong) else None
+        self.inflight = []  # outstanding gathers, oldest first
 
     @classmethod
     def on_gpu(cls, rows, cols, rank, world, device, p_local, c_local, v_local, x_host,
-               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False, ranges=None):
+               algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False, ranges=None,
+               pingpong=True):
         """Product path: local slice uploaded to `device`, multiplied by the HIP kernel
         on torch's current stream.  Raises if the HIP library or the GPU is missing."""
         local_rows = len(p_local) - 1
@@ -69,41 +86,68 @@ class DistributedCsrSpmv:
         tx = torch.from_numpy(np.ascontiguousarray(x_host, dtype=np.float64)).to(device)
         if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
             plan.compress(tc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            # column panels keep a snapshot of the values: this object holds the tensors it was taken
+            # from (self._keep) for as long as the plan lives, so it cannot go stale
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
         def local_spmv(y_local):
             plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_local.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
 
-        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group, overlap, ranges)
+        def local_spmv_out(y_in, y_out):
+            plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), y_in.data_ptr(), y_out.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+
+        self = cls(rows, cols, rank, world, device, local_rows, local_spmv, group, overlap, ranges,
+                   local_spmv_out=local_spmv_out, pingpong=pingpong)
         self.plan = plan
         self._keep = (tp, tc, tv, tx)
         return self
 
+    @property
+    def y_local(self):
+        """The padded segment holding this rank's current rows of y."""
+        return self.seg[self.cur]
+
+    def zero(self):
+        self.finish()
+        for s in self.seg:
+            s.zero_()
+
     def multiply_local(self):
         """y_local += A_local @ x (enqueue only)."""
-        self.local_spmv(self.y_local)
+        if self.pingpong:
+            # the buffer about to be written was the source of the gather before last
+            while len(self.inflight) >= 2:
+                self.inflight.pop(0).wait()
+            src, dst = self.seg[self.cur], self.seg[1 - self.cur]
+            self.local_spmv_out(src, dst)
+            self.cur = 1 - self.cur
+        else:
+            self.local_spmv(self.seg[0])
 
     def gather(self):
         """The one collective of the path: equal-count all-gather of the y segments."""
+        self.finish()
         if self.world == 1 and not dist.is_initialized():
             self.y_full.copy_(self.y_local)
         else:
             dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
 
     def gather_async(self):
-        """Snapshot y_local and start its all-gather without waiting for it; the previous one
-        must have finished with the send buffer first."""
-        if self.pending is not None:
-            self.pending.wait()
-        self.send_buf.copy_(self.y_local)
-        self.pending = dist.all_gather_into_tensor(self.y_full, self.send_buf, group=self.group, async_op=True)
+        """Start the all-gather of the current segment without waiting for it."""
+        if self.pingpong:
+            self.inflight.append(dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group, async_op=True))
+            return
+        # one buffer: the previous gather must have finished with the send buffer, then snapshot
+        self.finish()
+        self.send_buf.copy_(self.seg[0])
+        self.inflight.append(dist.all_gather_into_tensor(self.y_full, self.send_buf, group=self.group, async_op=True))
 
     def finish(self):
-        """Wait for the last outstanding gather (no-op without overlap)."""
-        if self.pending is not None:
-            self.pending.wait()
-            self.pending = None
+        """Wait for the outstanding gathers (no-op without overlap)."""
+        while self.inflight:
+            self.inflight.pop(0).wait()
 
     def step(self):
         self.multiply_local()

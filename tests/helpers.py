@@ -58,10 +58,8 @@ def parse_mtx_text(text):
 def abs_products(rows, row_ptr, col, val, x):
     """(|A||x|)_i: the scale a reordered sum's rounding error is proportional to."""
     lens = np.diff(np.asarray(row_ptr, dtype=np.int64))
-    r = np.repeat(np.arange(rows), lens)
-    out = np.zeros(rows)
-    np.add.at(out, r, np.abs(val) * np.abs(x[col]))
-    return out
+    r = np.repeat(np.arange(rows, dtype=np.int32 if rows < 2**31 else np.int64), lens)
+    return np.bincount(r, weights=np.abs(val) * np.abs(x[col]), minlength=rows)
 
 
 def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what=""):

@@ -46,7 +46,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False):
+def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False, pingpong=True):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -76,7 +76,8 @@ def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False):
         y[:e - b] = O.csr_spmv(e - b, pl, cl, vl, x, y=y[:e - b])
 
     op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, overlap=overlap,
-                            ranges=ranges)
+                            ranges=ranges, pingpong=pingpong)
+    assert op.pingpong == (overlap and pingpong) and len(op.seg) == (2 if op.pingpong else 1)
     for _ in range(steps):
         op.step()
     want = O.csr_spmv(rows, p, c, v, x, runs=steps)
@@ -92,11 +93,15 @@ def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap,balanced", [(2, False, False), (3, False, False), (2, True, False),
-                                                    (3, False, True), (2, True, True)])
-def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced):
+@pytest.mark.parametrize("world,overlap,balanced,pingpong", [(2, False, False, True), (3, False, False, True),
+                                                             (2, True, False, True), (2, True, False, False),
+                                                             (3, False, True, True), (2, True, True, True),
+                                                             (3, True, True, False)])
+def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced, pingpong):
+    """overlap + pingpong: two segment buffers alternate (y_out = y_in + A*x), several gathers may be in
+    flight; overlap without it: one buffer and a snapshot copy; 5 steps so both buffers are reused."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 3, str(tmp_path), overlap, balanced), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 5, str(tmp_path), overlap, balanced, pingpong), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"

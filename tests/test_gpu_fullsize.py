@@ -1,0 +1,258 @@
+"""BASELINE.json's configurations at FULL size on the MI355X, whole vector against the oracle.
+
+configs[1] Poisson 4096^2 exactly as bench.py times it (compressed + repacked plan: 16-bit /
+shifted / pattern / 128-row tiles), and the same matrix as ELLPACK (L = 5) and COO through the
+context API; configs[2..4] through the structure-faithful generators of
+host/matrix/synthetic.cpp (queen-, kkt-, webbase-like; the SuiteSparse files cannot be fetched
+here), every row of y compared with the oracle's multi-threaded CSR loop.
+
+Tolerances: bit-exact where every row is summed by one lane in the reference's order
+(rows of <= 16 entries in CSR wave tiles, ELLPACK); 1e-10 relative otherwise (BASELINE.json).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitexact, assert_close, abs_products
+from spmv_amd import capi, hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+THREADS = 16
+
+
+def _plan_multiply(A, x, compress=True, flags=0, runs=1, y0=None):
+    """y0 + runs * A x through the device-pointer API with the plan bench.py builds."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(A.rows, A.cols, A.row_ptr, capi.CSR_AUTO, 0, flags)
+    tp, tc, tv = (torch.from_numpy(np.asarray(t)).to(dev) for t in (A.row_ptr, A.column_index, A.value))
+    tx = torch.from_numpy(x).to(dev)
+    if compress:
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+    ty = torch.zeros(A.rows, dtype=torch.float64, device=dev) if y0 is None else torch.from_numpy(y0).to(dev)
+    for _ in range(runs):
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    info = plan.info()
+    y = ty.cpu().numpy()
+    plan.close()
+    del tp, tc, tv, tx, ty
+    torch.cuda.empty_cache()
+    return y, info
+
+
+def test_poisson4096_compressed_plan_whole_vector_bitexact(oracle):
+    """The configuration bench.py times: CSR_AUTO + compress + repack.  > 90 % of the tiles must be
+    shifted ones (columns not read), and all 16 777 216 rows must equal the oracle bit for bit."""
+    A = hostapi.load("synthetic:poisson2d:4096", "csr")
+    assert A.rows == 16777216 and A.stored == 83869696
+    x = synth.x_vector(A.cols, seed=12345)
+    y, info = _plan_multiply(A, x)
+    assert info["shifted_tiles"] > 0.9 * info["row_blocks"], info
+    assert info["narrow_tiles"] == info["row_blocks"] and info["panel_tiles"] == 0
+    assert info["shifted_entries"] > 0.9 * A.stored
+    assert info["streamed_bytes"] < 12 * A.stored  # the tile classes stream less than the algorithmic bytes
+    want = oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS)
+    assert_bitexact(y, want, "poisson 4096^2, compressed plan")
+    # and twice more on top (y += A x accumulates)
+    y3, _ = _plan_multiply(A, x, runs=2, y0=y)
+    want3 = oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, x, y=want, num_threads=THREADS, runs=2)
+    assert_bitexact(y3, want3, "poisson 4096^2, three accumulating runs")
+    A.close()
+
+
+@pytest.mark.parametrize("fmt", ["ell", "coo"])
+def test_poisson4096_alt_formats_context_api(oracle, fmt):
+    """The same matrix as ELLPACK (L = 5, row-major in place as uniform wave tiles: bit-exact with
+    ell_spmv_inner_loop) and as COO (row-sorted triplets: 1e-10)."""
+    M = hostapi.load("synthetic:poisson2d:4096", fmt)
+    x = synth.x_vector(M.cols, seed=12345)
+    with capi.Context(0) as ctx:
+        if fmt == "ell":
+            assert M.row_length == 5
+            ctx.upload_ell(M.rows, M.cols, M.row_length, M.column_index, M.value)
+        else:
+            ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
+        ctx.set_x(x)
+        ctx.run()
+        y = ctx.get_y()
+        info = ctx.info()
+    if fmt == "ell":
+        want = oracle.ell_spmv(M.rows, M.row_length, M.column_index, M.value, x, num_threads=THREADS)
+        assert info["row_blocks"] > 0  # ran as wave tiles
+        assert_bitexact(y, want, "poisson 4096^2 ELL")
+    else:
+        want = oracle.coo_spmv(M.rows, M.row_index, M.column_index, M.value, x)
+        assert_close(y, want, scale=np.full(M.rows, 8.0), what="poisson 4096^2 COO")
+    M.close()
+
+
+@pytest.mark.parametrize("spec,min_rows,min_nnz", [
+    ("synthetic:queen", 4147110, 320000000),      # configs[2]: Queen_4147-like, ~329.5 M entries, ~79/row
+    ("synthetic:kkt:200", 16240000, 430000000),   # configs[3]: nlpkkt200-like, N = 16.24 M, ~436 M entries
+    ("synthetic:webbase", 1000005, 3105536),      # configs[4]: webbase-1M-like
+    ("synthetic:powerlaw", 1000005, 3105536),     # the same row lengths, uniformly scattered columns
+])
+def test_baseline_configs_full_size_whole_vector(oracle, spec, min_rows, min_nnz):
+    A = hostapi.load(spec, "csr")
+    assert A.rows == min_rows and A.stored >= min_nnz
+    x = synth.x_vector(A.cols, seed=12345)
+    y, info = _plan_multiply(A, x)
+    want = oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS)
+    lens = np.diff(A.row_ptr)
+    if lens.max() <= 16 and info["panel_tiles"] == 0:
+        assert_bitexact(y, want, spec)
+    else:
+        assert_close(y, want, scale=abs_products(A.rows, A.row_ptr, A.column_index, A.value, x), what=spec)
+        # rows of <= 16 entries are summed by one lane in the reference's order whenever their tile holds no longer row;
+        # at least the tiles of short rows only must be exact: most rows
+        short = lens <= 16
+        same = (y.view(np.uint64) == want.view(np.uint64))
+        if info["panel_tiles"] == 0:
+            assert same[short].mean() > 0.5, (spec, same[short].mean())
+    A.close()
+
+
+@pytest.mark.parametrize("fmt", ["coo", "hybrid"])
+def test_webbase_alt_formats(oracle, fmt):
+    """configs[4]: webbase-1M-like in COO and in the hybrid ELL+COO format; ELLPACK itself overflows
+    int32 exactly like the reference's converter (rows * 4700 > 2^31 - 1)."""
+    M = hostapi.load("synthetic:webbase", fmt)
+    x = synth.x_vector(M.cols, seed=12345)
+    A = hostapi.load("synthetic:webbase", "csr")
+    want = oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS)
+    scale = abs_products(A.rows, A.row_ptr, A.column_index, A.value, x)
+    with capi.Context(0) as ctx:
+        if fmt == "coo":
+            ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
+        else:
+            ctx.upload_hybrid(M.rows, M.cols, M.row_length, M.column_index, M.value,
+                              M.coo_row_index, M.coo_column_index, M.coo_value)
+        ctx.set_x(x)
+        ctx.run(2)
+        y = ctx.get_y()
+    assert_close(y, 2.0 * want, scale=2.0 * scale, what="webbase " + fmt)
+    M.close()
+    A.close()
+
+
+def test_webbase_ellpack_overflows_like_the_reference():
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.load("synthetic:webbase", "ell")
+    assert "Integer overflow" in str(e.value)  # src/matrix/ell-matrix.cpp:199-205
+
+
+def test_y_in_y_out_and_plan_guards(oracle):
+    """spmv_hip_csr_spmv_out (two segment buffers, as the partitioned multiply uses them), the plan's
+    content guard, and the refresh of a column-panel value snapshot."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, gen in (("poisson", lambda: synth.poisson2d(300)), ("powerlaw", lambda: synth.powerlaw(40000, 40000, seed=3)),
+                      ("band", lambda: synth.banded(30000, range(-20, 21), seed=2))):
+        rows, cols, p, c, v = gen()
+        x = synth.x_vector(cols, seed=5)
+        y0 = synth.x_vector(rows, seed=6)
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+        scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+        tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+        for algo in (capi.CSR_AUTO, capi.CSR_SCALAR, capi.CSR_ADAPTIVE):
+            plan = capi.CsrPlan(rows, cols, p, algo)
+            plan.compress(tc.data_ptr(), stream)
+            ya = torch.from_numpy(y0).to(dev)
+            yb = torch.full((rows,), 123.0, dtype=torch.float64, device=dev)
+            plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ya.data_ptr(), yb.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(ya.cpu().numpy(), y0), "y_in must not change"
+            assert_close(yb.cpu().numpy(), want, scale, what="%s y_out algo %d" % (name, algo))
+            # and back: y_a = y_b + A x
+            plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), yb.data_ptr(), ya.data_ptr(), stream)
+            torch.cuda.synchronize()
+            want2 = oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4)
+            assert_close(ya.cpu().numpy(), want2, 2 * scale, what="%s y_out twice algo %d" % (name, algo))
+            with pytest.raises(capi.SpmvHipError) as e:  # overlapping buffers are refused
+                plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ya.data_ptr(), ya.data_ptr() + 8, stream)
+            assert e.value.code == capi.ERR_INVALID
+            plan.close()
+        # content guard: same address, different columns -> ERR_STATE, not a wrong y
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO)
+        plan.compress(tc.data_ptr(), stream)
+        plan.verify(tc.data_ptr(), stream)
+        saved = tc.clone()
+        tc[: min(64, len(c))] = torch.flip(tc[: min(64, len(c))], dims=[0]) if len(c) > 1 else tc
+        tc[0] = (tc[0] + 1) % cols
+        torch.cuda.synchronize()
+        with pytest.raises(capi.SpmvHipError) as e:
+            plan.verify(tc.data_ptr(), stream)
+        assert e.value.code == capi.ERR_STATE
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        with pytest.raises(capi.SpmvHipError) as e:  # the first multiply after compress checks by itself
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        assert e.value.code == capi.ERR_STATE
+        tc.copy_(saved)
+        plan.close()
+    # unknown flag bits are refused
+    with pytest.raises(capi.SpmvHipError) as e:
+        capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, 0x2000)
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.SpmvHipError) as e:
+        capi.Context(0, flags=0x40000000)
+    assert e.value.code == capi.ERR_INVALID
+
+
+def test_column_panel_value_snapshot_refresh(oracle):
+    """A scattered matrix gets column panels (a copy of the values inside the plan): plan_info says so,
+    and after the caller changes the values refresh_values brings the copy up to date."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rows, cols, p, c, v = synth.random_uniform(600000, 600000, 8, seed=3)
+    x = synth.x_vector(cols, seed=5)
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO)
+    plan.compress(tc.data_ptr(), stream)
+    plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+    info = plan.info()
+    assert info["panel_tiles"] > 0 and info["value_snapshot"] == 1, info
+    scale = abs_products(rows, p, c, v, x)
+
+    def mul():
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return ty.cpu().numpy()
+
+    assert_close(mul(), oracle.csr_spmv(rows, p, c, v, x, num_threads=8), scale, what="panels")
+    v2 = v * 3.0 + 0.25
+    tv.copy_(torch.from_numpy(v2).to(dev))
+    plan.refresh_values(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+    assert_close(mul(), oracle.csr_spmv(rows, p, c, v2, x, num_threads=8), abs_products(rows, p, c, v2, x), what="panels after refresh")
+    plan.close()
+
+
+def test_context_on_callers_stream(oracle):
+    """spmv_hip_set_stream: the context's launches are ordered on the caller's stream (torch events see them)."""
+    import torch
+    rows, cols, p, c, v = synth.poisson2d(200)
+    x = synth.x_vector(cols, seed=1)
+    s = torch.cuda.Stream()
+    with capi.Context(0) as ctx:
+        ctx.set_stream(s.cuda_stream)
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s):
+            e0.record()
+            ctx.run(50, sync=False)
+            e1.record()
+        s.synchronize()
+        assert e0.elapsed_time(e1) > 0.0
+        y = ctx.get_y()
+        ctx.set_stream(None)  # back on its own stream
+        ctx.run()
+        y2 = ctx.get_y()
+    want = oracle.csr_spmv(rows, p, c, v, x, runs=50)
+    assert_bitexact(y, want, "50 runs on the caller's stream")
+    assert_bitexact(y2, oracle.csr_spmv(rows, p, c, v, x, y=want), "51st run on the own stream")

@@ -4,6 +4,7 @@ columns drawn from 256 K, 512 K, 1 M, 2 M and 4 M columns (x = 2 ... 32 MB): if 
 XCD's 4 MB L2) is much faster, column panels per XCD would pay for scattered matrices."""
 import os
 import sys
+os.environ.setdefault("SPMV_HIP_EXPERIMENTS", "1")  # --force needs the experiments build
 
 import numpy as np
 

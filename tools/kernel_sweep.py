@@ -13,6 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
+# the A/B and ablation variants live in libspmv_hip_experiments.so only (same sources, -DSPMV_HIP_EXPERIMENTS)
+os.environ.setdefault("SPMV_HIP_EXPERIMENTS", "1")
 
 
 def main():
@@ -28,7 +30,13 @@ def main():
     import torch
     from spmv_amd import capi, synth
 
-    if args.workload == "poisson2d":
+    keep = None
+    if args.workload.startswith("synthetic:"):
+        # the generators of host/matrix/synthetic.cpp: synthetic:queen, synthetic:kkt[:n], synthetic:webbase, synthetic:powerlaw
+        from spmv_amd import hostapi
+        keep = hostapi.load(args.workload, "csr")
+        rows, cols, p, c, v = keep.rows, keep.cols, keep.row_ptr, keep.column_index, keep.value
+    elif args.workload == "poisson2d":
         rows, cols, p, c, v = synth.poisson2d(args.grid)
     elif args.workload == "stencil27":
         rows, cols, p, c, v = synth.stencil27_like(160, 160, 160)

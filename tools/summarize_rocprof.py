@@ -91,6 +91,22 @@ def main():
             w = write[name]
             k["WRITE_SIZE_KiB_per_launch"] = round(sum(w) / len(w), 1)
             k["write_bytes"] = int(sum(w) / len(w) * 1024)
+        # optional diagnostic passes (PROFILE_EXTRA=1): per-launch means of every counter collected
+        for sub in ("pmc_l2", "pmc_l1", "pmc_sq"):
+            for f in find(os.path.join(out, sub), "*counter_collection.csv"):
+                acc = defaultdict(list)
+                for r in csv.DictReader(open(f)):
+                    if r.get("Kernel_Name") == name:
+                        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                for cname, vals in acc.items():
+                    k.setdefault("counters", {})[cname] = round(sum(vals) / len(vals), 1)
+        c = k.get("counters", {})
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+            k["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        if c.get("SQ_WAVE_CYCLES"):
+            k["wave_cycle_split"] = {"waiting_on_memory": round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3),
+                                     "waiting_to_issue": round(c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3),
+                                     "issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)}
         if "fetch_bytes_corrected_x2" in k and "write_bytes" in k:
             k["hbm_traffic_bytes_per_launch"] = k["fetch_bytes_corrected_x2"] + k["write_bytes"]
             k["hbm_traffic_bytes_per_launch_uncorrected"] = k["fetch_bytes_raw"] + k["write_bytes"]
@@ -116,6 +132,12 @@ def main():
                 k["kernel"], k.get("calls"), k.get("avg_us"), k.get("median_us"), k.get("min_us"),
                 k.get("FETCH_SIZE_KiB_per_launch"), k.get("WRITE_SIZE_KiB_per_launch"),
                 k.get("hbm_traffic_bytes_per_launch")))
+        extra = [k for k in kernels if "counters" in k]
+        if extra:
+            f.write("\nDiagnostic counters (per-launch means; L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS); wave-cycle split per MI355X_MICROARCH.md \"rocprofv3 PMC slots\"):\n\n")
+            for k in extra:
+                f.write("* `%s`: L2 hit rate %s, wave cycles %s, counters %s\n" % (
+                    k["kernel"], k.get("l2_hit_rate"), json.dumps(k.get("wave_cycle_split")), json.dumps(k["counters"])))
         f.write("\n" + summary["note"] + "\n")
     print(open(os.path.join(root, tag + "_summary.md")).read())
 
