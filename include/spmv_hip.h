@@ -87,6 +87,12 @@ extern "C" {
 #define SPMV_HIP_FLAG_VERIFY_PLAN 0x8000u /* spmv_hip_csr_spmv: re-check on EVERY call that the column array still has the
                                              contents the plan was compressed from (one extra pass over it per multiply;
                                              by default this is checked on the first multiply only, see spmv_hip_plan_verify) */
+#define SPMV_HIP_FLAG_NO_BALANCED_TILES 0x40000u /* wavetile: never switch to tiles filled by entries (up to 512 in up to 256
+                                             rows, row sums by segmented reduction: csr_segtile_kernel).  By default a matrix
+                                             whose row-owned tiles come out less than half full because its rows are skewed
+                                             (longest row > 16 entries) gets them: a web graph runs in a fifth of the waves.
+                                             Rows that span lanes are then added in another order than the reference's
+                                             (1e-10, not bit-identical; SPMV_HIP_FLAG_EXACT_ORDER also keeps row-owned tiles) */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -236,7 +242,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             row_ptr 4 B per row of a non-uniform tile; y 16 B per row; x once; 16 B per tile.  The
  *             ALGORITHMIC bytes of SURVEY 8(d), 12 nnz + 4 (rows + 1) + 16 rows + 8 cols, never shrink
  *        [15] stored entries in shifted tiles  [16] stored entries in 16-bit tiles
- *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels) */
+ *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels)
+ *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

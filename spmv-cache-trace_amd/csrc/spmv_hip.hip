@@ -57,7 +57,7 @@ namespace {
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
-    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -138,6 +138,7 @@ struct spmv_hip_plan {
     int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     int split_rows = 0;    // rows cut into chunks that are added to y with atomics
+    bool balanced = false; // tiles filled by entries, row sums by segmented reduction (csr_segtile_kernel)
     size_t meta_bytes = 0;
     // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
     long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;
@@ -167,7 +168,8 @@ struct spmv_hip_ctx {
     double * d_pval = nullptr;
     spmv::CooPanels coo_panels{};
     int coo_panel_blocks = 0;
-    bool ell_as_tiles = false; // ELLPACK with short rows runs as uniform CSR tiles (row-major, in place)
+    bool ell_as_tiles = false; // ELLPACK runs as uniform CSR tiles (row-major, in place)
+    bool as_csr = false;       // COO / hybrid were turned into one row-major matrix on the device: run = the CSR plan
 };
 
 namespace {
@@ -207,6 +209,7 @@ void free_ctx_matrix(spmv_hip_ctx * c)
     c->rows = c->cols = c->nnz = c->row_length = c->nnz2 = 0;
     c->coo_sorted_on_device = false;
     c->ell_as_tiles = false;
+    c->as_csr = false;
     c->bytes = 0;
 }
 
@@ -507,6 +510,51 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
             }
             r = r1;
         }
+        // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
+        // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
+        // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
+        // Regular matrices (every tile already full, or only short rows) keep the tiles above and with
+        // them the reference's summation order.
+        {
+            int longest = 0;
+            for (int32_t q = 0; q < rows; ++q)
+                longest = std::max(longest, (int) (p[q + 1] - p[q]));
+            const long long stream_entries = (long long) p[rows] - p[0];
+            const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
+                && !(flags & SPMV_HIP_FLAG_XCD_REMAP) && longest > 16 && 2 * stream_entries < (long long) desc.size() * tile;
+            if (want) {
+                desc.clear();
+                pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
+                r = 0;
+                while (r < rows) {
+                    const int32_t kb = p[r] & ~3;
+                    int32_t r1 = r;
+                    int32_t maxlen = 0;
+                    while (r1 < rows && (r1 - r) < spmv::kSegMaxRows && (long long) p[r1 + 1] - kb <= tile) {
+                        maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
+                        ++r1;
+                    }
+                    if (r1 == r) { // one row longer than a tile
+                        const long long len = (long long) p[r + 1] - p[r];
+                        pl->long_blocks++;
+                        if (len > kSplitThreshold) {
+                            pl->split_rows++;
+                            for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                                desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+                        } else {
+                            desc.push_back(make_int4(r, p[r], 0, 0));
+                        }
+                        r1 = r + 1;
+                    } else {
+                        pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+                        const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+                        desc.push_back(make_int4(r, p[r], maxlen | (fast ? (1 << 25) : 0) | spmv::kTileMetaSeg, 0));
+                    }
+                    r = r1;
+                }
+                pl->balanced = true;
+            }
+        }
         pl->ntiles = (int) desc.size();
         if (break_rows > 0) {
             while (next_panel <= 8)
@@ -694,7 +742,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->spread_tiles = counts[4];
     // block windows (x staged through LDS per 16 tiles) for what has no cheaper path: first count
     // the tiles that would qualify, and only if they are the majority mark them
-    if (e == hipSuccess && pl->tile == 512 && pl->ntiles >= 4 * spmv::kBlockWinTiles
+    if (e == hipSuccess && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * spmv::kBlockWinTiles
         && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
         const int nb = (pl->ntiles + spmv::kBlockWinTiles - 1) / spmv::kBlockWinTiles;
         hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile, pl->d_tiles,
@@ -764,7 +812,7 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
     // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
     const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
-    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->rows < 1024
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->balanced || pl->nnz == 0 || pl->rows < 1024
         || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
         || !pl->d_col16 /* not compressed: the tile classes are unknown */
         || (long long) pl->rows * 8 + 1 > 0x7FFFFFF0LL)
@@ -872,12 +920,12 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[19] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[20] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
-                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0};
-    for (int i = 0; i < n && i < 19; ++i)
+                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0};
+    for (int i = 0; i < n && i < 20; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -948,6 +996,19 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
                 hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, true>), grid, dim3(256), 0, s, in->ntiles,
                                    in->d_tiles, pl->d_vrow_ptr, pl->d_pcol, in->d_col16, pl->d_pval, x, y, y, pl->nnz, pl->cols, 0,
                                    in->d_patterns, pl->pinfo);
+        } else if (pl->balanced && pl->ntiles > 0) {
+            // tiles filled by entries, row sums by segmented reduction (skewed rows)
+            const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
+            const bool x32 = pl->cols < (1 << 29);
+            const dim3 grid((unsigned) pl->workgroups);
+            if (c16 && x32)
+                hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
+            else if (c16)
+                hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, false>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
+            else if (x32)
+                hipLaunchKernelGGL((spmv::csr_segtile_kernel<false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
+            else
+                hipLaunchKernelGGL((spmv::csr_segtile_kernel<false, false>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
         } else if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
@@ -1317,6 +1378,36 @@ static int ctx_coo_run(spmv_hip_ctx * c, int32_t nnz, const int32_t * d_row, con
     return spmv_hip_coo_spmv(c->rows, nnz, d_row, d_col, d_val, c->d_x, c->d_y, c->stream);
 }
 
+// Row-sorted triplets ARE a CSR matrix whose row_ptr is the run-length of the row stream: build it on
+// the device, fetch it (rows + 1 integers) for the tile builder, and give the context a CSR plan for
+// (d_ptr, d_col, d_val).  After that the row-index stream is not needed any more: the multiply
+// streams 12 instead of 16 bytes per entry, needs no atomics, and gets every tile class of the CSR
+// path (16-bit columns, shifted tiles, balanced tiles, column panels).
+static int ctx_csr_from_sorted_rows(spmv_hip_ctx * c, const int32_t * d_rows_sorted, int32_t nnz, std::vector<int32_t> * host_ptr_out)
+{
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_ptr, (size_t) c->rows + 1)) != 0) return rc;
+    hipLaunchKernelGGL(spmv::rowptr_from_sorted_kernel, dim3((unsigned) grid_for((long long) nnz + 1, kBlock, cu_count() * 16)), dim3(256), 0,
+                       c->stream, (long long) nnz, (int) c->rows, d_rows_sorted, c->d_ptr);
+    HIP_TRY(hipGetLastError());
+    host_ptr_out->resize((size_t) c->rows + 1);
+    HIP_TRY(hipMemcpyAsync(host_ptr_out->data(), c->d_ptr, host_ptr_out->size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+static int ctx_plan_device_csr(spmv_hip_ctx * c, const std::vector<int32_t> & host_ptr, unsigned extra_flags)
+{
+    int rc = spmv_hip_plan_csr(&c->plan, c->rows, c->cols, host_ptr.data(), SPMV_HIP_CSR_WAVETILE, 0, c->flags | extra_flags);
+    if (rc != 0)
+        return rc;
+    if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
+        if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
+        if ((rc = spmv_hip_plan_csr_repack(c->plan, c->d_ptr, c->d_col, c->d_val, c->stream)) != 0) return rc;
+    }
+    return SPMV_HIP_OK;
+}
+
 int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz,
                         const int32_t * row_index, const int32_t * column_index, const double * value)
 {
@@ -1350,12 +1441,21 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
             return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
         }
     }
-    if (!row_sorted && !(c->flags & SPMV_HIP_FLAG_COO_KEEP_ORDER)) {
-        if ((rc = spmv_hip_coo_sort_by_row(rows, nnz, c->d_idx, c->d_col, c->d_val, c->stream)) != 0) return rc;
-        c->coo_sorted_on_device = true;
+    if (!(c->flags & SPMV_HIP_FLAG_COO_KEEP_ORDER) && nnz > 0 && rows > 0) {
+        // default: sort by row once if need be (stably: a row keeps its file order), then multiply the
+        // triplets as the row-major matrix they are (see ctx_csr_from_sorted_rows)
+        if (!row_sorted) {
+            if ((rc = spmv_hip_coo_sort_by_row(rows, nnz, c->d_idx, c->d_col, c->d_val, c->stream)) != 0) return rc;
+            c->coo_sorted_on_device = true;
+        }
+        std::vector<int32_t> host_ptr;
+        if ((rc = ctx_csr_from_sorted_rows(c, c->d_idx, nnz, &host_ptr)) != 0) return rc;
+        if ((rc = ctx_plan_device_csr(c, host_ptr, 0)) != 0) return rc;
+        (void) hipFree(c->d_idx); // the row stream has done its work
+        c->d_idx = nullptr;
+        c->bytes -= (size_t) nnz * sizeof(int32_t) + 64;
+        c->as_csr = true;
     }
-    if (row_sorted || c->coo_sorted_on_device)
-        if ((rc = ctx_coo_panels(c, c->d_idx, c->d_col, c->d_val, nnz)) != 0) return rc;
     c->format = 2;
     return SPMV_HIP_OK;
 }
@@ -1388,7 +1488,9 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     // kernel in place, one lane per row -- the reference's order -- with no transposed copy
     // (measured against the column-major kernel: L=5 202 vs 265 us, L=27 229 vs 285, L=81 337 vs 368).
     // Longer rows take the column-major one-lane-per-row kernel, which keeps the order for any length.
-    c->ell_as_tiles = n > 0 && row_length <= 256 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR);
+    // (rows of more than half a tile get a tile -- or, beyond 512 entries, a wave -- to themselves and
+    // are still added up by one lane: the streams, not that lane, are what the time goes into)
+    c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR);
     if (c->ell_as_tiles) {
         std::vector<int32_t> row_ptr((size_t) rows + 1);
         for (int32_t i = 0; i <= rows; ++i)
@@ -1455,7 +1557,7 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
-    // the ELL part is uploaded (validated, transposed) exactly like a plain ELLPACK matrix ...
+    // the ELL part is uploaded (validated) exactly like a plain ELLPACK matrix ...
     int rc = spmv_hip_upload_ell(c, rows, cols, ell_row_length, ell_column_index, ell_value);
     if (rc != 0)
         return rc;
@@ -1472,12 +1574,65 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
             HIP_TRY(hipMemcpyAsync(c->d_col2, coo_column_index, (size_t) num_coo_entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(c->d_val2, coo_value, (size_t) num_coo_entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
-        bool bad_row = false, bad_col = false;
-        if ((r = device_index_check(c->d_idx, num_coo_entries, rows, false, &bad_row, nullptr, c->stream)) != 0) return r;
+        bool bad_row = false, bad_col = false, sorted = true;
+        if ((r = device_index_check(c->d_idx, num_coo_entries, rows, true, &bad_row, &sorted, c->stream)) != 0) return r;
         if ((r = device_index_check(c->d_col2, num_coo_entries, cols, false, &bad_col, nullptr, c->stream)) != 0) return r;
         if (bad_row || bad_col)
             return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
-        // the remainder is in (row, column) order (hybrid-matrix.cpp:316-417): panels where it is scattered
+        // One fused multiply: the reference adds the ELL part and then the remainder into the same y
+        // (hybrid_matrix::spmv, src/matrix/hybrid-matrix.cpp:535-567); here the two parts are merged on
+        // the device into ONE row-major matrix -- row r = its ELL entries, padding included, then its
+        // remainder entries -- so a run is one launch over balanced tiles instead of an ELL launch
+        // followed by an atomic COO launch (webbase-like: 10.8 + 18.9 us before).  The remainder is in
+        // (row, column) order (hybrid-matrix.cpp:316-417); any other order is sorted by row first.
+        const long long merged = (long long) c->nnz + num_coo_entries;
+        if (c->ell_as_tiles && !(c->flags & (SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_EXACT_ORDER)) && merged <= INT32_MAX && rows > 0) {
+            if (!sorted && (r = spmv_hip_coo_sort_by_row(rows, num_coo_entries, c->d_idx, c->d_col2, c->d_val2, c->stream)) != 0) return r;
+            // the ELL arrays sit in d_col / d_val with their plan; keep them aside, build the merged ones
+            int32_t * ell_col = c->d_col, * coo_ptr = nullptr;
+            double * ell_val = c->d_val;
+            spmv_hip_plan_destroy(c->plan);
+            c->plan = nullptr;
+            (void) hipFree(c->d_ptr);
+            c->d_ptr = nullptr;
+            c->d_col = nullptr;
+            c->d_val = nullptr;
+            auto cleanup = [&] { (void) hipFree(ell_col); (void) hipFree(ell_val); };
+            std::vector<int32_t> host_ptr;
+            if ((r = ctx_csr_from_sorted_rows(c, c->d_idx, num_coo_entries, &host_ptr)) != 0) { cleanup(); return r; }
+            coo_ptr = c->d_ptr; // row_ptr of the remainder alone
+            c->d_ptr = nullptr;
+            for (int32_t q = 0; q <= rows; ++q)
+                host_ptr[(size_t) q] += q * ell_row_length;
+            hipError_t e = hipSuccess;
+            if ((r = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0 || (r = dev_alloc(c, &c->d_col, (size_t) merged)) != 0
+                || (r = dev_alloc(c, &c->d_val, (size_t) merged)) != 0) {
+                cleanup();
+                (void) hipFree(coo_ptr);
+                return r;
+            }
+            e = hipMemcpyAsync(c->d_ptr, host_ptr.data(), host_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::hybrid_merge_kernel, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, c->stream, (int) rows,
+                                   (int) ell_row_length, ell_col, ell_val, coo_ptr, c->d_col2, c->d_val2, c->d_col, c->d_val);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            cleanup();
+            (void) hipFree(coo_ptr);
+            if (e != hipSuccess)
+                return fail_hip(e, "hybrid merge");
+            void * parts[] = {c->d_idx, c->d_col2, c->d_val2};
+            for (void * q : parts)
+                (void) hipFree(q);
+            c->d_idx = c->d_col2 = nullptr;
+            c->d_val2 = nullptr;
+            c->ell_as_tiles = false;
+            c->as_csr = true;
+            return ctx_plan_device_csr(c, host_ptr, 0);
+        }
+        // two launches (file order kept, exact ELL order asked for, or the merged matrix would not fit
+        // int32): scattered remainders get column panels
         return ctx_coo_panels(c, c->d_idx, c->d_col2, c->d_val2, num_coo_entries);
     };
     rc = remainder();
@@ -1541,13 +1696,20 @@ int spmv_hip_run(spmv_hip_ctx * c)
     int rc = SPMV_HIP_OK;
     switch (c->format) {
     case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
-    case 2: rc = ctx_coo_run(c, c->nnz, c->d_idx, c->d_col, c->d_val); break;
+    case 2:
+        rc = c->as_csr ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
+                       : ctx_coo_run(c, c->nnz, c->d_idx, c->d_col, c->d_val);
+        break;
     case 3:
         rc = c->ell_as_tiles
             ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
             : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
         break;
     case 4:
+        if (c->as_csr) { // ELL part and remainder merged into one row-major matrix: one launch
+            rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+            break;
+        }
         rc = c->ell_as_tiles
             ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
             : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
@@ -1596,7 +1758,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
     default: break;
     }
     if (c->plan) {
-        v[15] = c->plan->streamed_bytes + (c->format == 4 ? 16LL * c->nnz2 : 0);
+        v[15] = c->plan->streamed_bytes + (c->format == 4 && !c->as_csr ? 16LL * c->nnz2 : 0);
         v[4] = c->plan->algorithm;
         v[5] = c->plan->lanes_per_row;
         v[6] = c->plan->workgroups;

@@ -1,0 +1,191 @@
+"""Balanced tiles (csr_segtile_kernel): tiles filled by entries, row sums by segmented reduction.
+
+Chosen by the plan for matrices whose row-owned tiles come out less than half full because the
+rows are skewed.  Checked here against the oracle on matrices built to hit the corners of the
+reduction: rows that begin / end exactly on a lane's 8-entry boundary, rows spanning many lanes,
+runs of empty rows, single-entry rows, tiles capped by rows (256) and by entries (512), long rows
+(own tile / split with atomics) in between, tiles that start off a 4-entry boundary, the ragged end
+of the arrays; also the COO and hybrid uploads that now run through the same kernel.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitexact, assert_close, abs_products
+from spmv_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr_from_lens(lens, cols, rng, local=None):
+    lens = np.asarray(lens, dtype=np.int64)
+    rows = len(lens)
+    p = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    Z = int(p[-1])
+    r = np.repeat(np.arange(rows), lens)
+    if local is None:
+        c = rng.integers(0, cols, size=Z)
+    else:
+        c = np.clip(r * cols // max(rows, 1) + rng.integers(-local, local + 1, size=Z), 0, cols - 1)
+    order = np.lexsort((c, r))
+    c = c[order].astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=Z)
+    return rows, cols, p.astype(np.int32), c, v
+
+
+def _multiply(rows, cols, p, c, v, x, y0, flags=0, compress=True, runs=1):
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c if len(c) else np.zeros(4, np.int32), v if len(v) else np.zeros(4), x))
+    if compress:
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+    ty = torch.from_numpy(y0.copy()).to(dev)
+    for _ in range(runs):
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    info = plan.info()
+    plan.close()
+    return ty.cpu().numpy(), info
+
+
+CASES = {
+    # most rows 1..5 entries, a long one every so often: what a web graph looks like
+    "web": lambda rng: np.where(rng.random(40000) < 0.02, rng.integers(17, 400, 40000), rng.integers(1, 6, 40000)),
+    # rows of exactly 8 and 16 entries (lane boundaries of the 8-entry shares) mixed with long ones
+    "lane_aligned": lambda rng: np.where(rng.random(20000) < 0.12, 8 * rng.integers(3, 60, 20000), 8 * rng.integers(1, 3, 20000)),
+    # runs of empty rows, single entries, and rows of 100-500
+    "holes": lambda rng: np.where(rng.random(30000) < 0.6, 0, np.where(rng.random(30000) < 0.05, rng.integers(100, 513, 30000), 1)),
+    # rows of 1 and 2 entries with a 300-entry row now and then: tiles capped by 256 rows
+    "row_cap": lambda rng: np.where(rng.random(60000) < 0.002, 300, rng.integers(1, 3, 60000)),
+    # long rows in between: exactly a tile, more than a tile (own wave), more than 2048 (split, atomics)
+    "long_between": lambda rng: np.where(rng.random(5000) < 0.01, rng.choice([509, 512, 513, 700, 2048, 2049, 5000], 5000), rng.integers(0, 7, 5000)),
+    # odd lengths so tiles start off a 4-entry boundary all the time
+    "odd_starts": lambda rng: np.where(rng.random(30000) < 0.04, 2 * rng.integers(10, 120, 30000) + 1, 2 * rng.integers(0, 3, 30000) + 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("seed", [1, 2])
+def test_balanced_tiles_against_oracle(oracle, name, seed):
+    rng = np.random.default_rng(1000 * seed + len(name))
+    lens = CASES[name](rng)
+    rows, cols, p, c, v = _csr_from_lens(lens, 50000, rng, local=None if seed == 1 else 20000)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = _multiply(rows, cols, p, c, v, x, y0)
+    assert info["balanced"] == 1, (name, info)
+    assert_close(got, want, scale, what="balanced %s seed %d" % (name, seed))
+    # far fewer tiles than the row-owned tiling of the same matrix, and the same y up to rounding
+    got_r, info_r = _multiply(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BALANCED_TILES)
+    assert info_r["balanced"] == 0 and info_r["row_blocks"] > 1.5 * info["row_blocks"], (info, info_r)
+    assert_close(got_r, want, scale, what="row-owned %s seed %d" % (name, seed))
+    # without index compression (32-bit columns) and accumulating twice
+    got2, info2 = _multiply(rows, cols, p, c, v, x, y0, compress=False, runs=2)
+    assert info2["balanced"] == 1
+    want2 = oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4)
+    assert_close(got2, want2, 2 * scale, what="balanced uncompressed x2 %s" % name)
+    # rows whose entries lie inside one lane's share are summed in the reference's order: with single-entry
+    # and two-entry rows in the majority, most of y is bit-identical
+    if name in ("holes", "row_cap"):
+        same = got.view(np.uint64) == want.view(np.uint64)
+        assert same.mean() > 0.7, same.mean()
+
+
+def test_balanced_is_deterministic_and_not_chosen_for_regular_matrices(oracle):
+    rng = np.random.default_rng(5)
+    lens = CASES["web"](rng)
+    rows, cols, p, c, v = _csr_from_lens(lens, 80000, rng)
+    x = synth.x_vector(cols, seed=3)
+    y0 = np.zeros(rows)
+    a, info = _multiply(rows, cols, p, c, v, x, y0)
+    b, _ = _multiply(rows, cols, p, c, v, x, y0)
+    assert info["balanced"] == 1
+    assert_bitexact(a, b, "two runs of the balanced kernel")
+    for gen in (lambda: synth.poisson2d(300), lambda: synth.banded(40000, range(-40, 41), seed=2),
+                lambda: synth.stencil27_like(30, 30, 30), lambda: _csr_from_lens(np.full(50000, 2), 50000, rng)):
+        rows, cols, p, c, v = gen()
+        _, info = _multiply(rows, cols, p, c, v, synth.x_vector(cols, seed=1), np.zeros(rows))
+        assert info["balanced"] == 0, info
+    # the exact-order flag keeps row-owned tiles (and the reference's bits) on a skewed matrix
+    rows, cols, p, c, v = _csr_from_lens(lens, 80000, rng)
+    got, info = _multiply(rows, cols, p, c, v, x, np.zeros(rows), flags=capi.FLAG_EXACT_ORDER)
+    assert info["balanced"] == 0
+    assert_bitexact(got, oracle.csr_spmv(rows, p, c, v, x, num_threads=4), "exact order on a skewed matrix")
+
+
+@pytest.mark.parametrize("order", ["row", "column", "shuffled"])
+def test_coo_upload_runs_as_row_major_tiles(oracle, order):
+    """spmv_hip_upload_coo: triplets in any order are sorted by row once (stably) and multiplied through
+    the CSR plan built from the device-side row_ptr; KEEP_ORDER keeps the atomic COO kernel."""
+    rng = np.random.default_rng(9)
+    lens = CASES["web"](rng)[:20000]
+    rows, cols, p, c, v = _csr_from_lens(lens, 30000, rng)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    r, cc = (i - 1).astype(np.int32), (j - 1).astype(np.int32)
+    perm = {"row": np.arange(len(a)), "column": np.lexsort((r, cc)), "shuffled": rng.permutation(len(a))}[order]
+    r, cc, vv = np.ascontiguousarray(r[perm]), np.ascontiguousarray(cc[perm]), np.ascontiguousarray(a[perm])
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.coo_spmv(rows, r, cc, vv, x, y=y0, runs=2)
+    scale = 2 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    for flags in (0, capi.FLAG_COO_KEEP_ORDER):
+        with capi.Context(0, flags=flags) as ctx:
+            ctx.upload_coo(rows, cols, r, cc, vv)
+            info = ctx.info()
+            assert (info["row_blocks"] > 0) == (flags == 0), info  # tiles only on the default path
+            ctx.set_x(x)
+            ctx.set_y(y0)
+            ctx.run(2)
+            assert_close(ctx.get_y(), want, scale, what="coo %s flags %x" % (order, flags))
+    # bad indices are found on the device, and the context is left empty
+    bad = r.copy()
+    bad[len(bad) // 2] = rows
+    with capi.Context(0) as ctx:
+        with pytest.raises(capi.SpmvHipError) as e:
+            ctx.upload_coo(rows, cols, bad, cc, vv)
+        assert e.value.code == capi.ERR_INVALID
+        assert ctx.info()["format"] == 0
+
+
+def test_hybrid_upload_is_one_fused_multiply(oracle):
+    """spmv_hip_upload_hybrid merges the ELL part (padding included) and the COO remainder into one
+    row-major matrix on the device: one launch per run, same y as hybrid_matrix::spmv within 1e-10;
+    NaN / Inf in x reach y through the padding exactly like in the reference (0.0 * Inf = NaN)."""
+    rows, cols, p, c, v = synth.powerlaw(30000, 30000, seed=4, max_len=600)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    H = oracle.hybrid_from_coordinate(rows, i, j, a)
+    assert H["row_length"] >= 1 and len(H["coo_val"]) > 0
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.hybrid_spmv(rows, H, x, y=y0, runs=2)
+    scale = 2 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    with capi.Context(0) as ctx:
+        ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+        info = ctx.info()
+        assert info["format"] == 4 and info["row_blocks"] > 0
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run(2)
+        assert_close(ctx.get_y(), want, scale, what="hybrid merged")
+        # a non-finite x entry: every row whose ELL padding points at that column becomes NaN in the reference
+        x2 = x.copy()
+        hot = int(H["ell_col"][H["row_length"] - 1])  # the last (possibly padded) slot of row 0
+        x2[hot] = np.inf
+        ctx.set_x(x2)
+        ctx.set_y(np.zeros(rows))
+        ctx.run()
+        got = ctx.get_y()
+        ref = oracle.hybrid_spmv(rows, H, x2)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    # KEEP_ORDER: the two-launch path (ELL tiles, then the atomic COO kernel)
+    with capi.Context(0, flags=capi.FLAG_COO_KEEP_ORDER) as ctx:
+        ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run(2)
+        assert_close(ctx.get_y(), want, scale, what="hybrid two launches")
