@@ -450,6 +450,7 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
         desc.reserve((size_t) rows / 48 + 16);
         int32_t r = 0;
         int next_panel = 0;
+        long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
         while (r < rows) {
             if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
                 while (next_panel <= 8 && next_panel <= r / break_rows)
@@ -505,6 +506,8 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
                 const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
                 if (uniform)
                     pl->uniform_tiles++;
+                stream_tiles++;
+                stream_tile_entries += (long long) p[r1] - p[r];
                 desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
                                                       (uniform ? (1 << 26) : 0), 0));
             }
@@ -519,9 +522,9 @@ static int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, c
             int longest = 0;
             for (int32_t q = 0; q < rows; ++q)
                 longest = std::max(longest, (int) (p[q + 1] - p[q]));
-            const long long stream_entries = (long long) p[rows] - p[0];
+            // (rows with a wave or more to themselves are the same in both tilings and do not count)
             const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
-                && !(flags & SPMV_HIP_FLAG_XCD_REMAP) && longest > 16 && 2 * stream_entries < (long long) desc.size() * tile;
+                && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
             if (want) {
                 desc.clear();
                 pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
@@ -1001,14 +1004,15 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
             const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
             const bool x32 = pl->cols < (1 << 29);
             const dim3 grid((unsigned) pl->workgroups);
-            if (c16 && x32)
-                hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
-            else if (c16)
-                hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, false>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
-            else if (x32)
-                hipLaunchKernelGGL((spmv::csr_segtile_kernel<false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
-            else
-                hipLaunchKernelGGL((spmv::csr_segtile_kernel<false, false>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols);
+            const bool xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) != 0;
+#define SPMV_SEG_LAUNCH(C, X, R) \
+    hipLaunchKernelGGL((spmv::csr_segtile_kernel<C, X, R>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols)
+#define SPMV_SEG_X(C, R) do { if (x32) SPMV_SEG_LAUNCH(C, true, R); else SPMV_SEG_LAUNCH(C, false, R); } while (0)
+#define SPMV_SEG_C(R) do { if (c16) SPMV_SEG_X(true, R); else SPMV_SEG_X(false, R); } while (0)
+            if (xcd) SPMV_SEG_C(true); else SPMV_SEG_C(false);
+#undef SPMV_SEG_C
+#undef SPMV_SEG_X
+#undef SPMV_SEG_LAUNCH
         } else if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
             const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;

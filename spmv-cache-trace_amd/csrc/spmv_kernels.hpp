@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 constexpr int kSegMaxRows = 256;
 constexpr int kTileMetaSeg = 1 << 21;
 
-template <bool C16, bool X32>
+template <bool C16, bool X32, bool XCD>
 __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
@@ -874,7 +874,10 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
-    const int w = (int) blockIdx.x * 4 + wave;
+    // XCD: workgroups b, b + 8, b + 16, ... share an XCD and its L2; give each XCD one contiguous run of
+    // tiles, so that the x entries its rows refer to (a web graph links mostly within the neighbourhood
+    // of the row) collect in ONE L2 instead of being fetched over the fabric into all eight
+    const int w = (XCD ? xcd_remap((int) blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
     if (w >= ntiles)
         return; // whole wave leaves; no workgroup barrier in this kernel
     double * prod = prod_all[wave];

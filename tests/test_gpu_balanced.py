@@ -61,7 +61,7 @@ CASES = {
     # rows of 1 and 2 entries with a 300-entry row now and then: tiles capped by 256 rows
     "row_cap": lambda rng: np.where(rng.random(60000) < 0.002, 300, rng.integers(1, 3, 60000)),
     # long rows in between: exactly a tile, more than a tile (own wave), more than 2048 (split, atomics)
-    "long_between": lambda rng: np.where(rng.random(5000) < 0.01, rng.choice([509, 512, 513, 700, 2048, 2049, 5000], 5000), rng.integers(0, 7, 5000)),
+    "long_between": lambda rng: np.where(rng.random(40000) < 0.0015, rng.choice([509, 512, 513, 700, 2048, 2049, 5000], 40000), rng.integers(0, 7, 40000)),
     # odd lengths so tiles start off a 4-entry boundary all the time
     "odd_starts": lambda rng: np.where(rng.random(30000) < 0.04, 2 * rng.integers(10, 120, 30000) + 1, 2 * rng.integers(0, 3, 30000) + 1),
 }
