@@ -117,6 +117,19 @@ int spmv_hip_device_count(int *count);
 int spmv_hip_create(spmv_hip_ctx **ctx, int device, unsigned flags);
 void spmv_hip_destroy(spmv_hip_ctx *ctx);
 
+/* One context over `num_gpus` devices (0 .. num_gpus-1) of this process: SURVEY 8b / 8e.
+ * spmv_hip_upload_csr then cuts the rows into num_gpus contiguous blocks by the reference's static
+ * rule, chunk = ceil(rows / num_gpus) (src/matrix/csr-matrix.cpp:77-95, src/matrix/csr-matrix-spmv.cpp:154-161:
+ * devices take the place of OpenMP threads), device g holds block g, the whole x, and its own copy of
+ * the whole y.  spmv_hip_run multiplies on every device (y_g += A_g x into slot g of that device's y)
+ * and then assembles y everywhere with ONE in-place ncclAllGather (RCCL over xGMI) issued for all
+ * devices inside a group call; spmv_hip_sync waits for all of them; spmv_hip_get_y reads device 0's y.
+ * Only CSR can be uploaded (the other upload_* return SPMV_HIP_ERR_STATE), spmv_hip_set_stream is
+ * refused.  librccl.so is loaded at run time, and only when num_gpus > 1 (or SPMV_HIP_FORCE_RCCL=1
+ * is set, which runs the collective with one device too); num_gpus = 1 is an ordinary context with
+ * the same calling sequence. */
+int spmv_hip_create_multi(spmv_hip_ctx **ctx, int num_gpus, unsigned flags);
+
 /* Enqueue everything this context does from now on on the caller's `stream` (a hipStream_t on the
  * context's device; NULL = the default stream), or, with use_own != 0, on the context's own stream
  * again.  Lets a host program order the multiply against its own work (and time it with its own
@@ -170,6 +183,10 @@ int spmv_hip_run(spmv_hip_ctx *ctx);
 int spmv_hip_sync(spmv_hip_ctx *ctx);
 /* Device time of the last spmv_hip_run (hipEvent pair), valid after a sync. */
 int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
+/* The same with the collective apart: kernel_ns = the slowest device's multiply, gather_ns
+ * = the longest span from the end of a device's multiply to the end of its all-gather (0 for a
+ * single-device context).  Either pointer may be NULL. */
+int spmv_hip_last_run_times(spmv_hip_ctx *ctx, uint64_t *kernel_ns, uint64_t *gather_ns);
 
 /* Descriptive numbers for JSON output / tests.  out[] receives up to n of:
  * [0] format (0 none, 1 csr, 2 coo, 3 ell, 4 hybrid)  [1] rows  [2] cols  [3] stored entries
@@ -177,7 +194,8 @@ int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
  * [7] row blocks / tiles  [8] long-row blocks  [9] device bytes held  [10] tiles with 16-bit columns
  * [11] shifted tiles  [12] tiles with an x window  [13] block-window tiles  [14] tiles of the
  * column-panel copy (see spmv_hip_plan_info)  [15] bytes one run streams with the tile classes in
- * use (see spmv_hip_plan_info [14]; formats without tiles: their algorithmic bytes) */
+ * use (see spmv_hip_plan_info [14]; formats without tiles: their algorithmic bytes)
+ * [16] devices (1, or the num_gpus of spmv_hip_create_multi: [6..15] are then sums over the devices) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================

@@ -7,6 +7,9 @@
 #include "spmv_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl.so is dlopen'ed by spmv_hip_create_multi when G > 1
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -170,6 +173,24 @@ struct spmv_hip_ctx {
     int coo_panel_blocks = 0;
     bool ell_as_tiles = false; // ELLPACK runs as uniform CSR tiles (row-major, in place)
     bool as_csr = false;       // COO / hybrid were turned into one row-major matrix on the device: run = the CSR plan
+    bool y_borrowed = false;   // d_y points into memory owned by a multi-GPU front context
+    double * borrowed_y = nullptr;
+    // ---- multi-GPU front (spmv_hip_create_multi): parts[g] is an ordinary context on device g that holds
+    // the rows [g * chunk, min(rows, (g + 1) * chunk)) of the matrix, a full x, and -- as its y -- slot g of
+    // yfull[g], that device's copy of the whole y.  A run multiplies on every device and then gathers the
+    // slots with ONE in-place all-gather (RCCL), after which every yfull[g] holds the same y.
+    bool multi = false;
+    std::vector<spmv_hip_ctx *> parts;
+    std::vector<double *> yfull;
+    std::vector<hipEvent_t> ev_gather; // recorded after the all-gather on each part's stream
+    int32_t chunk = 0;
+    void * rccl_lib = nullptr;
+    std::vector<ncclComm_t> comms;
+    ncclResult_t (*p_all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*p_group_start)() = nullptr;
+    ncclResult_t (*p_group_end)() = nullptr;
+    ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
+    const char * (*p_error_string)(ncclResult_t) = nullptr;
 };
 
 namespace {
@@ -196,6 +217,8 @@ void free_ctx_matrix(spmv_hip_ctx * c)
         spmv_hip_plan_destroy(c->plan);
         c->plan = nullptr;
     }
+    if (c->y_borrowed)
+        c->d_y = nullptr;
     void * ptrs[] = {c->d_ptr, c->d_idx, c->d_col, c->d_col2, c->d_val, c->d_val2, c->d_x, c->d_y, c->d_prow, c->d_pcol, c->d_pval};
     for (void * p : ptrs)
         if (p)
@@ -231,8 +254,12 @@ int ctx_common_vectors(spmv_hip_ctx * c)
 {
     int rc;
     if ((rc = dev_alloc(c, &c->d_x, (size_t) c->cols)) != 0) return rc;
-    if ((rc = dev_alloc(c, &c->d_y, (size_t) c->rows)) != 0) return rc;
     HIP_TRY(hipMemsetAsync(c->d_x, 0, (size_t) c->cols * sizeof(double), c->stream));
+    if (c->y_borrowed) {
+        c->d_y = c->borrowed_y; // a slot of the front context's gathered y (already zeroed there)
+        return SPMV_HIP_OK;
+    }
+    if ((rc = dev_alloc(c, &c->d_y, (size_t) c->rows)) != 0) return rc;
     HIP_TRY(hipMemsetAsync(c->d_y, 0, (size_t) c->rows * sizeof(double), c->stream));
     return SPMV_HIP_OK;
 }
@@ -1213,6 +1240,20 @@ int spmv_hip_triad_variant(int64_t n, double * a, const double * b, const double
 }
 #endif
 
+} // extern "C"
+namespace {
+void multi_free_matrix(spmv_hip_ctx * c);
+int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_ptr,
+                     const int32_t * column_index, const double * value);
+int multi_set_x(spmv_hip_ctx * c, const double * x);
+int multi_set_y(spmv_hip_ctx * c, const double * y);
+int multi_get_y(spmv_hip_ctx * c, double * y);
+int multi_run(spmv_hip_ctx * c);
+int multi_sync(spmv_hip_ctx * c);
+int multi_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns);
+} // namespace
+extern "C" {
+
 /* ================================ Level 1 ======================================= */
 
 int spmv_hip_create(spmv_hip_ctx ** out, int device, unsigned flags)
@@ -1253,6 +1294,20 @@ void spmv_hip_destroy(spmv_hip_ctx * c)
 {
     if (!c)
         return;
+    if (c->multi) {
+        multi_free_matrix(c);
+        for (size_t g = 0; g < c->comms.size(); ++g)
+            if (c->comms[g] && c->p_comm_destroy)
+                (void) c->p_comm_destroy(c->comms[g]);
+        for (hipEvent_t ev : c->ev_gather)
+            if (ev)
+                (void) hipEventDestroy(ev);
+        for (spmv_hip_ctx * part : c->parts)
+            spmv_hip_destroy(part);
+        // librccl.so stays loaded (dlclose of a library with live device state is not safe)
+        delete c;
+        return;
+    }
     (void) hipSetDevice(c->device);
     if (c->own_stream)
         (void) hipStreamSynchronize(c->stream);
@@ -1267,6 +1322,8 @@ int spmv_hip_set_stream(spmv_hip_ctx * c, void * stream, int use_own)
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context runs on its own per-device streams");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream)); // nothing of the old stream is left behind
     c->stream = use_own ? c->own_stream : static_cast<hipStream_t>(stream);
@@ -1289,6 +1346,8 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return multi_upload_csr(c, rows, cols, nnz, row_ptr, column_index, value);
     if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!column_index || !value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
     if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
@@ -1417,6 +1476,8 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
     if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
     bool row_sorted = true;
@@ -1469,6 +1530,8 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
     if (rows < 0 || cols < 0 || row_length < 0)
         return fail(SPMV_HIP_ERR_INVALID, "bad ELL arguments");
     int32_t n;
@@ -1559,6 +1622,8 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
     // the ELL part is uploaded (validated) exactly like a plain ELLPACK matrix ...
@@ -1656,6 +1721,8 @@ int spmv_hip_set_x(spmv_hip_ctx * c, const double * x)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/x null");
     if (c->format == 0)
         return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    if (c->multi)
+        return multi_set_x(c, x);
     HIP_TRY(hipSetDevice(c->device));
     if (c->cols > 0)
         HIP_TRY(hipMemcpyAsync(c->d_x, x, (size_t) c->cols * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1669,6 +1736,8 @@ int spmv_hip_set_y(spmv_hip_ctx * c, const double * y)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/y null");
     if (c->format == 0)
         return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    if (c->multi)
+        return multi_set_y(c, y);
     HIP_TRY(hipSetDevice(c->device));
     if (c->rows > 0)
         HIP_TRY(hipMemcpyAsync(c->d_y, y, (size_t) c->rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1682,6 +1751,8 @@ int spmv_hip_get_y(spmv_hip_ctx * c, double * y)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/y null");
     if (c->format == 0)
         return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    if (c->multi)
+        return multi_get_y(c, y);
     HIP_TRY(hipSetDevice(c->device));
     if (c->rows > 0)
         HIP_TRY(hipMemcpyAsync(y, c->d_y, (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1695,6 +1766,8 @@ int spmv_hip_run(spmv_hip_ctx * c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->format == 0)
         return fail(SPMV_HIP_ERR_STATE, "no matrix uploaded");
+    if (c->multi)
+        return multi_run(c);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     int rc = SPMV_HIP_OK;
@@ -1732,6 +1805,8 @@ int spmv_hip_sync(spmv_hip_ctx * c)
 {
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return multi_sync(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SPMV_HIP_OK;
 }
@@ -1740,6 +1815,8 @@ int spmv_hip_last_run_ns(spmv_hip_ctx * c, uint64_t * kernel_ns)
 {
     if (!c || !kernel_ns)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
+    if (c->multi)
+        return multi_times(c, kernel_ns, nullptr);
     if (!c->timed)
         return fail(SPMV_HIP_ERR_STATE, "no run recorded");
     HIP_TRY(hipEventSynchronize(c->ev1));
@@ -1753,7 +1830,25 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
 {
     if (!c || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
-    int64_t v[16] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0};
+    if (c->multi) {
+        // the whole matrix: sizes from the front, tile counts / bytes summed over the devices, [16] = devices
+        int64_t v[17] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (int64_t) c->parts.size()};
+        for (size_t g = 0; g < c->parts.size(); ++g) {
+            int64_t w[16] = {0};
+            if (c->parts[g]->format != 0)
+                spmv_hip_ctx_info(c->parts[g], w, 16);
+            v[4] = w[4] ? w[4] : v[4];
+            v[5] = w[5];
+            for (int i : {6, 7, 8, 9, 10, 11, 12, 13, 14, 15})
+                v[i] += w[i];
+            if (c->yfull[g])
+                v[9] += (int64_t) c->chunk * (int64_t) c->parts.size() * 8;
+        }
+        for (int i = 0; i < n && i < 17; ++i)
+            out[i] = v[i];
+        return SPMV_HIP_OK;
+    }
+    int64_t v[17] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0, 1};
     // [15] bytes one run streams: the plan's count where tiles are used, else the format's algorithmic bytes
     switch (c->format) {
     case 2: v[15] = 16LL * c->nnz + 16LL * c->rows + 8LL * c->cols; break;
@@ -1777,9 +1872,272 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
     }
     if (c->d_prow)
         v[14] += c->coo_panel_blocks; // COO (part) in column panels: workgroups per panel
-    for (int i = 0; i < n && i < 16; ++i)
+    for (int i = 0; i < n && i < 17; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
+}
+
+} // extern "C"
+
+/* ---- multi-GPU front ------------------------------------------------------------------------------
+ * One process, G devices: rows are cut by the reference's static rule,
+ * chunk = ceil(rows / G) (src/matrix/csr-matrix.cpp:77-95, devices take the place of threads), x is
+ * replicated, and a run is G local multiplies followed by ONE in-place ncclAllGather of the y slots
+ * inside a group call.  librccl.so is loaded with dlopen only when G > 1 (or when
+ * SPMV_HIP_FORCE_RCCL=1 asks for the collective with one device): a single-GPU build has no
+ * dependency on it, and a process that already holds another RCCL (PyTorch's) is not handed a second
+ * one behind its back. */
+namespace {
+
+int multi_fail_nccl(spmv_hip_ctx * c, ncclResult_t r, const char * what)
+{
+    std::string msg = std::string(what) + ": " + (c->p_error_string ? c->p_error_string(r) : "RCCL error");
+    return fail(SPMV_HIP_ERR_HIP, msg.c_str());
+}
+
+int multi_load_rccl(spmv_hip_ctx * c, int num_gpus)
+{
+    const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char * n : names)
+        if ((c->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+            break;
+    if (!c->rccl_lib)
+        return fail(SPMV_HIP_ERR_STATE, "librccl.so could not be loaded: a multi-GPU context needs RCCL");
+    auto p_init_all = reinterpret_cast<ncclResult_t (*)(ncclComm_t *, int, const int *)>(dlsym(c->rccl_lib, "ncclCommInitAll"));
+    c->p_all_gather = reinterpret_cast<decltype(c->p_all_gather)>(dlsym(c->rccl_lib, "ncclAllGather"));
+    c->p_group_start = reinterpret_cast<decltype(c->p_group_start)>(dlsym(c->rccl_lib, "ncclGroupStart"));
+    c->p_group_end = reinterpret_cast<decltype(c->p_group_end)>(dlsym(c->rccl_lib, "ncclGroupEnd"));
+    c->p_comm_destroy = reinterpret_cast<decltype(c->p_comm_destroy)>(dlsym(c->rccl_lib, "ncclCommDestroy"));
+    c->p_error_string = reinterpret_cast<decltype(c->p_error_string)>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+    if (!p_init_all || !c->p_all_gather || !c->p_group_start || !c->p_group_end || !c->p_comm_destroy)
+        return fail(SPMV_HIP_ERR_STATE, "librccl.so lacks ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd");
+    std::vector<int> devs((size_t) num_gpus);
+    for (int g = 0; g < num_gpus; ++g)
+        devs[(size_t) g] = g;
+    c->comms.assign((size_t) num_gpus, nullptr);
+    ncclResult_t r = p_init_all(c->comms.data(), num_gpus, devs.data());
+    if (r != ncclSuccess) {
+        c->comms.clear();
+        return multi_fail_nccl(c, r, "ncclCommInitAll");
+    }
+    return SPMV_HIP_OK;
+}
+
+void multi_free_matrix(spmv_hip_ctx * c)
+{
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        (void) hipSetDevice(c->parts[g]->device);
+        (void) hipStreamSynchronize(c->parts[g]->stream);
+        free_ctx_matrix(c->parts[g]);
+        c->parts[g]->borrowed_y = nullptr;
+        if (g < c->yfull.size() && c->yfull[g]) {
+            (void) hipFree(c->yfull[g]);
+            c->yfull[g] = nullptr;
+        }
+    }
+    c->format = 0;
+    c->rows = c->cols = c->nnz = 0;
+    c->chunk = 0;
+    c->timed = false;
+}
+
+int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_ptr,
+                     const int32_t * column_index, const double * value)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
+        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
+    multi_free_matrix(c);
+    const int G = (int) c->parts.size();
+    const int32_t chunk = std::max<int32_t>(1, (int32_t) (((long long) rows + G - 1) / G)); // ceil(rows / G): the reference's rule
+    c->chunk = chunk;
+    std::vector<int32_t> local_ptr;
+    for (int g = 0; g < G; ++g) {
+        spmv_hip_ctx * part = c->parts[(size_t) g];
+        HIP_TRY(hipSetDevice(part->device));
+        // the device's copy of the whole y: G slots of `chunk` doubles (the last ones padded), zeroed
+        const size_t ybytes = (size_t) chunk * (size_t) G * sizeof(double) + 64;
+        HIP_TRY(hipMalloc((void **) &c->yfull[(size_t) g], ybytes));
+        HIP_TRY(hipMemsetAsync(c->yfull[(size_t) g], 0, ybytes, part->stream));
+        const int32_t b = (int32_t) std::min<long long>(rows, (long long) g * chunk);
+        const int32_t e = (int32_t) std::min<long long>(rows, (long long) (g + 1) * chunk);
+        local_ptr.resize((size_t) (e - b) + 1);
+        for (int32_t r = b; r <= e; ++r)
+            local_ptr[(size_t) (r - b)] = row_ptr[r] - row_ptr[b];
+        part->y_borrowed = true;
+        part->borrowed_y = c->yfull[(size_t) g] + (size_t) g * (size_t) chunk;
+        part->csr_algorithm = c->csr_algorithm;
+        part->csr_lanes = c->csr_lanes;
+        int rc = spmv_hip_upload_csr(part, e - b, cols, row_ptr[e] - row_ptr[b], local_ptr.data(),
+                                     column_index ? column_index + row_ptr[b] : nullptr, value ? value + row_ptr[b] : nullptr);
+        if (rc != 0) {
+            std::string const keep = g_last_error;
+            multi_free_matrix(c);
+            g_last_error = keep;
+            return rc;
+        }
+    }
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = nnz;
+    c->format = 1;
+    return SPMV_HIP_OK;
+}
+
+int multi_set_x(spmv_hip_ctx * c, const double * x)
+{
+    for (spmv_hip_ctx * part : c->parts) {
+        int rc = spmv_hip_set_x(part, x);
+        if (rc != 0)
+            return rc;
+    }
+    return SPMV_HIP_OK;
+}
+
+int multi_set_y(spmv_hip_ctx * c, const double * y)
+{
+    for (size_t g = 0; g < c->parts.size(); ++g) { // every device gets the whole y, as after a gather
+        spmv_hip_ctx * part = c->parts[g];
+        HIP_TRY(hipSetDevice(part->device));
+        if (c->rows > 0)
+            HIP_TRY(hipMemcpyAsync(c->yfull[g], y, (size_t) c->rows * sizeof(double), hipMemcpyHostToDevice, part->stream));
+        HIP_TRY(hipStreamSynchronize(part->stream));
+    }
+    return SPMV_HIP_OK;
+}
+
+int multi_get_y(spmv_hip_ctx * c, double * y)
+{
+    spmv_hip_ctx * part = c->parts[0];
+    HIP_TRY(hipSetDevice(part->device));
+    if (c->rows > 0)
+        HIP_TRY(hipMemcpyAsync(y, c->yfull[0], (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, part->stream));
+    HIP_TRY(hipStreamSynchronize(part->stream));
+    return SPMV_HIP_OK;
+}
+
+int multi_run(spmv_hip_ctx * c)
+{
+    const int G = (int) c->parts.size();
+    for (spmv_hip_ctx * part : c->parts) { // every device multiplies its rows into its slot of its y
+        int rc = spmv_hip_run(part);
+        if (rc != 0)
+            return rc;
+    }
+    if (!c->comms.empty()) {
+        // the one collective of the path: every device sends its slot and receives the others', in place
+        ncclResult_t r = c->p_group_start();
+        if (r != ncclSuccess)
+            return multi_fail_nccl(c, r, "ncclGroupStart");
+        for (int g = 0; g < G && r == ncclSuccess; ++g)
+            r = c->p_all_gather(c->yfull[(size_t) g] + (size_t) g * (size_t) c->chunk, c->yfull[(size_t) g], (size_t) c->chunk, ncclDouble,
+                                c->comms[(size_t) g], c->parts[(size_t) g]->stream);
+        ncclResult_t r2 = c->p_group_end();
+        if (r != ncclSuccess || r2 != ncclSuccess)
+            return multi_fail_nccl(c, r != ncclSuccess ? r : r2, "ncclAllGather");
+    }
+    for (int g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(c->parts[(size_t) g]->device));
+        HIP_TRY(hipEventRecord(c->ev_gather[(size_t) g], c->parts[(size_t) g]->stream));
+    }
+    c->timed = true;
+    return SPMV_HIP_OK;
+}
+
+int multi_sync(spmv_hip_ctx * c)
+{
+    for (spmv_hip_ctx * part : c->parts) {
+        HIP_TRY(hipSetDevice(part->device));
+        HIP_TRY(hipStreamSynchronize(part->stream));
+    }
+    return SPMV_HIP_OK;
+}
+
+// slowest device's multiply, and the longest wait from the end of a device's multiply to the end of its gather
+int multi_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns)
+{
+    if (!c->timed)
+        return fail(SPMV_HIP_ERR_STATE, "no run recorded");
+    float kmax = 0.f, gmax = 0.f;
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        spmv_hip_ctx * part = c->parts[g];
+        HIP_TRY(hipSetDevice(part->device));
+        HIP_TRY(hipEventSynchronize(c->ev_gather[g]));
+        float k = 0.f, ga = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k, part->ev0, part->ev1));
+        HIP_TRY(hipEventElapsedTime(&ga, part->ev1, c->ev_gather[g]));
+        kmax = std::max(kmax, k);
+        gmax = std::max(gmax, ga);
+    }
+    if (kernel_ns) *kernel_ns = (uint64_t) (kmax * 1.0e6 + 0.5);
+    if (gather_ns) *gather_ns = (uint64_t) (gmax * 1.0e6 + 0.5);
+    return SPMV_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
+{
+    if (!out)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void) hipGetLastError();
+        return fail(SPMV_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (num_gpus < 1 || num_gpus > n)
+        return fail(SPMV_HIP_ERR_INVALID, "num_gpus must be between 1 and the number of visible devices");
+    if (flags & ~kKnownFlags)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown flag bits");
+    spmv_hip_ctx * c = new (std::nothrow) spmv_hip_ctx;
+    if (!c)
+        return fail(SPMV_HIP_ERR_ALLOC, "ctx allocation failed");
+    c->multi = true;
+    c->flags = flags;
+    c->yfull.assign((size_t) num_gpus, nullptr);
+    int rc = SPMV_HIP_OK;
+    for (int g = 0; g < num_gpus && rc == SPMV_HIP_OK; ++g) {
+        spmv_hip_ctx * part = nullptr;
+        rc = spmv_hip_create(&part, g, flags);
+        if (rc == SPMV_HIP_OK) {
+            c->parts.push_back(part);
+            hipEvent_t ev = nullptr;
+            if (hipEventCreate(&ev) != hipSuccess)
+                rc = fail(SPMV_HIP_ERR_HIP, "hipEventCreate");
+            c->ev_gather.push_back(ev);
+        }
+    }
+    const char * force = std::getenv("SPMV_HIP_FORCE_RCCL");
+    if (rc == SPMV_HIP_OK && (num_gpus > 1 || (force && force[0] == '1')))
+        rc = multi_load_rccl(c, num_gpus);
+    if (rc != SPMV_HIP_OK) {
+        std::string const keep = g_last_error;
+        spmv_hip_destroy(c);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = c;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_last_run_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi)
+        return multi_times(c, kernel_ns, gather_ns);
+    if (gather_ns)
+        *gather_ns = 0;
+    uint64_t k = 0;
+    int rc = spmv_hip_last_run_ns(c, &k);
+    if (rc == SPMV_HIP_OK && kernel_ns)
+        *kernel_ns = k;
+    return rc;
 }
 
 } // extern "C"

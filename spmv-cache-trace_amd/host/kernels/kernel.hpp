@@ -26,6 +26,9 @@ public:
 // cache simulation (src/cache-simulation/replacement.hpp).  The simulation is not part of this
 // engine; the type is kept so that the interface stays source-compatible.
 typedef std::vector<std::pair<uintptr_t, int>> MemoryReferenceString;
+// the reference spells the type replacement::MemoryReferenceString (src/cache-simulation/replacement.hpp:29):
+// a Kernel subclass written against the reference's header compiles against this one unchanged
+namespace replacement { using MemoryReferenceString = ::MemoryReferenceString; }
 
 class Kernel
 {

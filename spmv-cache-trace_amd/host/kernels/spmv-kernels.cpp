@@ -322,9 +322,11 @@ public:
         if (is_master()) {
             check(spmv_hip_run(ctx), "run");
             check(spmv_hip_sync(ctx), "sync");
-            std::uint64_t ns = 0;
-            if (spmv_hip_last_run_ns(ctx, &ns) == SPMV_HIP_OK)
+            std::uint64_t ns = 0, gns = 0;
+            if (spmv_hip_last_run_times(ctx, &ns, &gns) == SPMV_HIP_OK) {
                 device_ns = ns;
+                gather_ns = gns;
+            }
         }
     }
 
@@ -350,7 +352,10 @@ public:
 protected:
     void create_context()
     {
-        int rc = spmv_hip_create(&ctx, options.device, options.hip_flags);
+        // --gpus G: one context over G devices (row blocks by the reference's static rule, one in-place
+        // RCCL all-gather of y per run); otherwise one device
+        int rc = options.num_gpus > 0 ? spmv_hip_create_multi(&ctx, options.num_gpus, options.hip_flags)
+                                      : spmv_hip_create(&ctx, options.device, options.hip_flags);
         if (rc != SPMV_HIP_OK)
             throw kernel_error(matrix_path + ": " + spmv_hip_strerror(rc) + ": " + spmv_hip_last_error());
         check(spmv_hip_set_csr_algorithm(ctx, options.csr_algorithm, options.csr_lanes_per_row), "set_csr_algorithm");
@@ -367,8 +372,8 @@ protected:
 
     std::ostream & print_device(std::ostream & o) const
     {
-        std::int64_t info[15] = {0};
-        spmv_hip_ctx_info(ctx, info, 15);
+        std::int64_t info[17] = {0};
+        spmv_hip_ctx_info(ctx, info, 17);
         static char const * const algo[] = {"auto", "scalar", "vector", "adaptive", "wavetile"};
         o << ",\n\"device\": {\"backend\": \"hip\", \"index\": " << options.device;
         if (info[0] == 1)
@@ -378,7 +383,12 @@ protected:
               << ", \"tiles_x_window\": " << info[12] << ", \"tiles_block_window\": " << info[13]
               << ", \"tiles_column_panels\": " << info[14];
         o << ", \"workgroups\": " << info[6] << ", \"device_bytes\": " << info[9]
-          << ", \"last_run_device_ns\": " << device_ns << "}";
+          << ", \"streamed_bytes_per_run\": " << info[15] << ", \"gpus\": " << info[16]
+          << ", \"last_run_device_ns\": " << device_ns;
+        if (info[16] > 1 || options.num_gpus > 0)
+            o << ", \"last_run_all_gather_ns\": " << gather_ns
+              << ", \"partition\": \"rows/" << info[16] << " static chunks, x replicated, 1 in-place all-gather(y) per run\"";
+        o << "}";
         return o;
     }
 
@@ -386,7 +396,7 @@ protected:
     SpmvOptions options;
     spmv_hip_ctx * ctx = nullptr;
     aligned_vector<double> x, y;
-    std::uint64_t device_ns = 0;
+    std::uint64_t device_ns = 0, gather_ns = 0;
     std::string prepare_error;
 };
 

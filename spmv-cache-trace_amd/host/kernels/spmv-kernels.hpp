@@ -30,6 +30,7 @@ struct SpmvOptions
 {
     bool expand_symmetric = false; // EXTENSION: mirror symmetric files
     int device = 0;                // HIP device index
+    int num_gpus = 0;              // > 0: rows partitioned over devices 0..num_gpus-1 (spmv_hip_create_multi; CSR only)
     int csr_algorithm = 0;         // SPMV_HIP_CSR_*
     int csr_lanes_per_row = 0;
     unsigned hip_flags = 0;        // SPMV_HIP_FLAG_*

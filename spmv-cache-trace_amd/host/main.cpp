@@ -81,6 +81,7 @@ enum Key
     key_check,
     key_synthetic,
     key_x,
+    key_gpus,
 };
 
 bool parse_count(char const * arg, long long & out)
@@ -165,6 +166,11 @@ error_t parse_option(int key, char * arg, argp_state * state)
         a.threads = (int) n;
         break;
     case key_check: a.check = true; break;
+    case key_gpus:
+        if (!parse_count(arg, n) || n < 1 || n > 64)
+            argp_error(state, "gpus: expected a positive integer");
+        a.spmv.num_gpus = (int) n;
+        break;
     case key_synthetic:
         if (a.kernel_type == KernelType::none)
             a.kernel_type = KernelType::spmv;
@@ -264,6 +270,9 @@ int main(int argc, char ** argv)
          "Where the kernel runs: cpu (default, the reference's kernels) or hip (MI355X, no fallback). The environment "
          "variable SPMV_DEVICE=hip changes the default, so that --csr/--coo/--ell PATH run on the GPU", 3},
         {"gpu", key_gpu, "INDEX", 0, "HIP device index (default 0)", 3},
+        {"gpus", key_gpus, "G", 0,
+         "hip-csr only: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
+         "x replicated, one RCCL all-gather of y per run", 3},
         {"csr-algorithm", key_csr_algorithm, "NAME", 0, "auto, scalar, vector, adaptive or wavetile", 3},
         {"lanes-per-row", key_lanes, "L", 0, "lanes per row of the vector algorithm (2..64, power of two)", 3},
         {"exact-order", key_exact_order, nullptr, 0, "sum every row left to right like the CPU loop (bit-exact)", 3},

@@ -40,6 +40,7 @@ SIGNATURES = {
     "spmv_hip_last_error": (C.c_char_p, []),
     "spmv_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "spmv_hip_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_uint]),
+    "spmv_hip_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_uint]),
     "spmv_hip_destroy": (None, [_vp]),
     "spmv_hip_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "spmv_hip_set_csr_algorithm": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     "spmv_hip_run": (C.c_int, [_vp]),
     "spmv_hip_sync": (C.c_int, [_vp]),
     "spmv_hip_last_run_ns": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "spmv_hip_last_run_times": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_plan_csr": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _i32p, C.c_int, C.c_int, C.c_uint]),
     "spmv_hip_plan_csr_compress": (C.c_int, [_vp, _vp, _vp]),
@@ -150,10 +152,15 @@ _EMPTY_F64 = np.zeros(1, dtype=np.float64)
 class Context:
     """Level-1 API: host arrays in, host arrays out (what the C++ adapters use)."""
 
-    def __init__(self, device=0, flags=0):
+    def __init__(self, device=0, flags=0, num_gpus=None):
+        """One device (`device`), or, with num_gpus, a multi-GPU context over devices 0..num_gpus-1
+        (row blocks + one in-place RCCL all-gather per run; CSR only)."""
         self.lib = load()
         h = _vp()
-        check(self.lib.spmv_hip_create(C.byref(h), device, flags))
+        if num_gpus is None:
+            check(self.lib.spmv_hip_create(C.byref(h), device, flags))
+        else:
+            check(self.lib.spmv_hip_create_multi(C.byref(h), num_gpus, flags))
         self.h = h
         self.rows = self.cols = 0
 
@@ -243,12 +250,18 @@ class Context:
         check(self.lib.spmv_hip_last_run_ns(self.h, C.byref(ns)))
         return ns.value
 
+    def last_run_times(self):
+        """(kernel_ns, gather_ns) of the last run."""
+        k, g = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.spmv_hip_last_run_times(self.h, C.byref(k), C.byref(g)))
+        return k.value, g.value
+
     def info(self):
-        out = np.zeros(16, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 16))
+        out = np.zeros(17, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 17))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
                 "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles",
-                "blockwin_tiles", "panel_tiles", "streamed_bytes"]
+                "blockwin_tiles", "panel_tiles", "streamed_bytes", "devices"]
         return dict(zip(keys, out.tolist()))
 
 

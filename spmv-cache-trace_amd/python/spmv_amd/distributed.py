@@ -15,8 +15,9 @@ With ``overlap=True`` the gather of multiply k runs on the collective's stream w
 multiply k+1 runs on the compute stream.  The kernels accumulate (y += A*x), so the
 segment that is being sent must not be the one the next multiply writes:
 
-* ``pingpong=True`` (default): two segment buffers alternate.  Multiply k reads the old
-  segment from one and writes the new one to the other (spmv_hip_csr_spmv_out:
+* ``pingpong=True`` (default): two gathered vectors alternate, each holding this rank's segment in
+  its own slot, so every all-gather is IN PLACE (nothing is copied for the rank's own rows).
+  Multiply k reads the old segment from one and writes the new one to the other (spmv_hip_csr_spmv_out:
   y_out = y_in + A*x), gather k sends what multiply k wrote, multiply k+1 only READS that
   buffer and writes the first one again -- which gather k-1 must have finished sending, the
   only wait on the compute stream.  No copy.
@@ -65,11 +66,19 @@ class DistributedCsrSpmv:
         self.local_spmv_out = local_spmv_out
         self.overlap = overlap
         self.pingpong = bool(pingpong and overlap)
-        # padded local segment(s) and the gathered vector (world * chunk >= rows)
-        self.seg = [torch.zeros(self.chunk, dtype=torch.float64, device=device) for _ in range(2 if self.pingpong else 1)]
-        self.cur = 0  # the segment buffer that holds the current y_local
-        self.y_full = torch.zeros(self.chunk * world, dtype=torch.float64, device=device)
-        self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device) if (overlap and not self.pingpong) else None
+        # The gathered vector(s) (world * chunk >= rows); this rank's padded segment LIVES INSIDE at
+        # [rank * chunk, (rank + 1) * chunk), so the all-gather is in place (send buffer = the rank's
+        # slot of the receive buffer): the collective moves only what comes from other ranks and the
+        # rank's own segment is never copied.  Two such vectors alternate with pingpong.
+        self.full = [torch.zeros(self.chunk * world, dtype=torch.float64, device=device) for _ in range(2 if self.pingpong else 1)]
+        self.seg = [f[rank * self.chunk:(rank + 1) * self.chunk] for f in self.full]
+        self.cur = 0  # the buffer that holds the current y_local (and, after its gather, the current y)
+        self.send_buf = None
+        if overlap and not self.pingpong:
+            # snapshot scheme: the segment keeps accumulating while an older copy of it is being gathered, so it
+            # must NOT live inside the receive buffer (the gather would write the old copy over it)
+            self.seg = [torch.zeros(self.chunk, dtype=torch.float64, device=device)]
+            self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device)
         self.inflight = []  # outstanding gathers, oldest first
 
     @classmethod
@@ -106,13 +115,18 @@ class DistributedCsrSpmv:
 
     @property
     def y_local(self):
-        """The padded segment holding this rank's current rows of y."""
+        """The padded segment holding this rank's current rows of y (a view into y_full)."""
         return self.seg[self.cur]
+
+    @property
+    def y_full(self):
+        """The vector the current segment is gathered into."""
+        return self.full[self.cur]
 
     def zero(self):
         self.finish()
-        for s in self.seg:
-            s.zero_()
+        for f in self.full + self.seg:
+            f.zero_()
 
     def multiply_local(self):
         """y_local += A_local @ x (enqueue only)."""
@@ -129,10 +143,9 @@ class DistributedCsrSpmv:
     def gather(self):
         """The one collective of the path: equal-count all-gather of the y segments."""
         self.finish()
-        if self.world == 1 and not dist.is_initialized():
-            self.y_full.copy_(self.y_local)
-        else:
-            dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
+        if self.world > 1 or dist.is_initialized():
+            dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)  # in place
+        # one rank and no process group: the segment already is the gathered vector
 
     def gather_async(self):
         """Start the all-gather of the current segment without waiting for it."""

@@ -9,6 +9,8 @@ here), every row of y compared with the oracle's multi-threaded CSR loop.
 Tolerances: bit-exact where every row is summed by one lane in the reference's order
 (rows of <= 16 entries in CSR wave tiles, ELLPACK); 1e-10 relative otherwise (BASELINE.json).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -274,3 +276,62 @@ def test_context_on_callers_stream(oracle):
     want = oracle.csr_spmv(rows, p, c, v, x, runs=50)
     assert_bitexact(y, want, "50 runs on the caller's stream")
     assert_bitexact(y2, oracle.csr_spmv(rows, p, c, v, x, y=want), "51st run on the own stream")
+
+
+def test_multi_gpu_context_with_one_device(oracle):
+    """spmv_hip_create_multi: the in-process row partition + in-place RCCL all-gather.  This box has one
+    GPU, so G = 1: without RCCL (the gather is a no-op) and, with SPMV_HIP_FORCE_RCCL=1, with
+    ncclCommInitAll + a grouped ncclAllGather over one device -- the calls the G > 1 path makes."""
+    import os
+    rows, cols, p, c, v = synth.powerlaw(30000, 30000, seed=3)
+    x = synth.x_vector(cols, seed=5)
+    y0 = synth.x_vector(rows, seed=6)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=3)
+    scale = 3 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    for force in ("0", "1"):
+        os.environ["SPMV_HIP_FORCE_RCCL"] = force
+        try:
+            with capi.Context(num_gpus=1) as ctx:
+                ctx.upload_csr(rows, cols, p, c, v)
+                ctx.set_x(x)
+                ctx.set_y(y0)
+                ctx.run(3)
+                assert_close(ctx.get_y(), want, scale, what="multi ctx, G=1, rccl=%s" % force)
+                info = ctx.info()
+                assert info["devices"] == 1 and info["format"] == 1 and info["rows"] == rows
+                k_ns, g_ns = ctx.last_run_times()
+                assert k_ns > 0 and g_ns < 5_000_000
+                i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+                with pytest.raises(capi.SpmvHipError) as e:  # only CSR is partitioned
+                    ctx.upload_coo(rows, cols, i - 1, j - 1, a)
+                assert e.value.code == capi.ERR_STATE
+                ctx.upload_csr(rows, cols, p, c, v)  # a second upload replaces the first
+                ctx.set_x(x)
+                ctx.run()
+                assert_close(ctx.get_y(), oracle.csr_spmv(rows, p, c, v, x, num_threads=4), scale, what="re-upload")
+        finally:
+            os.environ.pop("SPMV_HIP_FORCE_RCCL", None)
+    with pytest.raises(capi.SpmvHipError) as e:
+        capi.Context(num_gpus=capi.device_count() + 1)
+    assert e.value.code == capi.ERR_INVALID
+
+
+def test_cli_synthetic_full_size_gpus_and_check():
+    """The C++ CLI at full size without a file: --synthetic poisson2d:4096 on the GPU, the reference's
+    timed loop (sync per run), --gpus 1 (multi-GPU context), --x uniform --check against the CPU kernel."""
+    import json
+    import subprocess
+    import hostlib
+    r = subprocess.run([hostlib.CLI, "--synthetic", "poisson2d:4096", "--spmv-format", "hip-csr", "--gpus", "1", "--threads", "1",
+                        "--profile", "5", "--x", "uniform", "--check"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["kernel"]["name"] == "hip-csr-spmv" and d["kernel"]["rows"] == 16777216 and d["kernel"]["nonzeros"] == 83869696
+    assert d["kernel"]["device"]["gpus"] == 1 and "last_run_all_gather_ns" in d["kernel"]["device"]
+    assert d["execution_time"]["samples"] == 5 and 100_000 < d["execution_time"]["median"] < 2_000_000
+    assert d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
+    # SPMV_DEVICE=hip flips the default of the README spelling; NaN in the result fails the gate (not hides in it)
+    r = subprocess.run([hostlib.CLI, "--synthetic", "webbase:20000,62000,300,75", "--spmv-format", "coo", "--threads", "1", "--profile", "2",
+                        "--check"], env=dict(os.environ, SPMV_DEVICE="hip"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["kernel"]["name"] == "hip-coo-spmv"

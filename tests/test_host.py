@@ -5,6 +5,7 @@ import gzip
 import io
 import json
 import os
+import subprocess
 import tarfile
 
 import numpy as np
@@ -13,6 +14,8 @@ import pytest
 import helpers
 import hostlib
 from helpers import GOLDEN, unhex, assert_bitexact
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from spmv_amd import synth
 
 
@@ -590,3 +593,25 @@ def test_loader_rejects_doubled_signs(host):
     i, j, a = host.mm_entries(h)
     assert (i[0], j[0], a[0]) == (1, 2, 0.5)
     host.mm_free(h)
+
+
+def test_integration_md_adapter_compiles_verbatim(tmp_path):
+    """The adapter printed in INTEGRATION.md (what a maintainer of the reference adds as
+    src/kernels/hip-csr-spmv.cpp) must compile AS PRINTED against this repo's headers: the Kernel
+    interface is source-compatible with the reference's (src/kernels/kernel.hpp:18-45), a subclass that
+    implements only the reference's six virtuals is not abstract, and every C-ABI call it makes exists."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```cpp\n(.*?class hip_csr_spmv_kernel.*?)```", text, flags=re.S)
+    assert m, "INTEGRATION.md lost its adapter"
+    src = tmp_path / "hip-csr-spmv.cpp"
+    src.write_text(m.group(1) + """
+// instantiate it: an abstract class (a pure virtual the adapter does not implement) would not compile
+std::ostream & hip_csr_spmv_kernel::print(std::ostream & o) const { return o; }
+Kernel * make_it() { return new hip_csr_spmv_kernel("A.mtx"); }
+""")
+    host = os.path.join(ROOT, "spmv-cache-trace_amd", "host")
+    cmd = ["g++", "-std=c++17", "-fopenmp", "-fsyntax-only", "-Wall", "-I", os.path.join(host, "kernels"), "-I", host,
+           "-I", os.path.join(ROOT, "include"), str(src)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout

@@ -1,0 +1,113 @@
+"""The generated stand-ins of BASELINE.json's SuiteSparse configurations (host/matrix/synthetic.cpp)
+and the host C ABI that hands them -- and files -- to non-C++ callers (include/spmv_host.h).
+CPU only."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spmv_amd import hostapi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_header_symbols_all_exported():
+    text = open(os.path.join(ROOT, "include", "spmv_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(spmv_host_[a-z0-9_]+)\s*\(", text)))
+    assert len(syms) == 6, syms
+    lib = C.CDLL(hostapi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libspmv_host.so does not export %s" % s
+    # the test hooks are NOT part of the product library any more
+    assert not hasattr(lib, "host_mm_from_buffer")
+
+
+def test_poisson2d_matches_the_numpy_generator():
+    A = hostapi.load("synthetic:poisson2d:37")
+    rows, cols, p, c, v = synth.poisson2d(37)
+    assert (A.rows, A.cols) == (rows, cols)
+    assert np.array_equal(A.row_ptr, p) and np.array_equal(A.column_index, c) and np.array_equal(A.value, v)
+
+
+def _check_sorted_unique(A):
+    d = np.diff(A.column_index.astype(np.int64))
+    inner = np.ones(len(d), dtype=bool)
+    starts = A.row_ptr[1:-1]
+    inner[starts[(starts > 0) & (starts <= len(d))] - 1] = False
+    assert (d[inner] > 0).all()
+    assert A.column_index.min() >= 0 and A.column_index.max() < A.cols
+
+
+@pytest.mark.parametrize("spec,rows", [("synthetic:kkt:7", 2 * 343 + 6 * 49), ("synthetic:queen:6,5,7", 3 * 210)])
+def test_kkt_and_queen_are_symmetric_with_ascending_columns(spec, rows):
+    import scipy.sparse as sp
+    A = hostapi.load(spec)
+    assert A.rows == rows == A.cols
+    _check_sorted_unique(A)
+    M = sp.csr_matrix((A.value, A.column_index, A.row_ptr), shape=(A.rows, A.cols))
+    assert abs(M - M.T).max() == 0.0  # structure AND values
+    if "kkt" in spec:
+        n = 7
+        lens = np.diff(A.row_ptr)
+        assert (lens[343:343 + 6 * 49] == 2).all()                # control rows
+        assert lens[:343].max() == 28 and lens[343 + 294:].max() <= 30  # state rows: 1 + 27; constraint rows: 27 + faces
+        assert M[343 + 294:, 343 + 294:].nnz == 0                 # the zero block of [H A'; A 0]
+
+
+def test_row_ranges_equal_slices_of_the_whole_matrix():
+    for spec in ("synthetic:kkt:6", "synthetic:queen:5,4,6", "synthetic:poisson2d:19", "synthetic:webbase:5000,16000,90,70"):
+        A = hostapi.load(spec)
+        for b, e in ((0, 0), (0, A.rows), (A.rows // 3, 2 * A.rows // 3), (A.rows - 1, A.rows)):
+            S = hostapi.load_csr_rows(spec, b, e)
+            assert S.rows == e - b and S.rows_total == A.rows and S.cols == A.cols
+            k0, k1 = int(A.row_ptr[b]), int(A.row_ptr[e])
+            assert np.array_equal(S.row_ptr, A.row_ptr[b:e + 1] - k0)
+            assert np.array_equal(S.column_index, A.column_index[k0:k1]) and np.array_equal(S.value, A.value[k0:k1])
+
+
+def test_webbase_like_has_the_published_shape():
+    """N = 1 000 005, Z = 3 105 536, every row at least one entry, longest row 4700 (webbase-1M's
+    published figures); the scattered variant has the same row lengths."""
+    A = hostapi.load("synthetic:webbase")
+    B = hostapi.load("synthetic:powerlaw")
+    for M in (A, B):
+        lens = np.diff(M.row_ptr)
+        assert M.rows == M.cols == 1000005 and M.stored == 3105536
+        assert lens.min() == 1 and lens.max() == 4700 and (lens == 4700).sum() == 1
+        assert 0.6 < (lens <= 3).mean() < 0.95          # mostly short rows ...
+        assert (lens > 64).sum() > 1000                  # ... with a heavy tail
+        _check_sorted_unique(M)
+    assert np.array_equal(np.diff(A.row_ptr), np.diff(B.row_ptr))
+    r = np.repeat(np.arange(A.rows), np.diff(A.row_ptr))
+    near_a = (np.abs(A.column_index.astype(np.int64) - r) < 50000).mean()
+    near_b = (np.abs(B.column_index.astype(np.int64) - r) < 50000).mean()
+    assert near_a > 0.6 and near_b < 0.2  # host-local links vs uniformly scattered columns
+
+
+def test_other_formats_and_errors_through_the_host_abi(tmp_path):
+    M = hostapi.load("synthetic:webbase:3000,9500,80,75", "hybrid")
+    assert M.format == "hybrid" and M.stored == M.rows * M.row_length and M.num_coo_entries > 0
+    assert M.num_entries == 9500
+    C_ = hostapi.load("synthetic:webbase:3000,9500,80,75", "coo")
+    assert C_.stored == 9500 and len(C_.row_index) == 9500
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.load("synthetic:nosuchfamily")
+    assert "unknown synthetic matrix family" in str(e.value)
+    with pytest.raises(hostapi.HostError):
+        hostapi.load(str(tmp_path / "missing.mtx"))
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.load("synthetic:webbase", "ell")  # rows * 4700 > 2^31 - 1, like the reference's converter
+    assert "Integer overflow" in str(e.value)
+    # a file goes through the same entry point, symmetric ones unexpanded unless asked
+    path = tmp_path / "s.mtx"
+    path.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 4\n1 1 2.0\n2 1 -1.0\n3 2 -1.0\n3 3 2.0\n")
+    A = hostapi.load(str(path))
+    assert A.stored == 4 and not A.expanded
+    E = hostapi.load(str(path), expand_symmetric=True)
+    assert E.stored == 6 and E.expanded
+    # and the reordering suffix works on generated matrices too
+    R = hostapi.load("synthetic:poisson2d:12__RCM")
+    assert R.rows == 144 and R.stored == hostapi.load("synthetic:poisson2d:12").stored
