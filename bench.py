@@ -421,7 +421,8 @@ def main():
         rows, cols, nnz = M.rows, M.cols, M.num_entries
         begin, end, ranges = 0, rows, None
         x = synth.x_vector(cols, "uniform", seed=12345)
-        op = ContextOperator(fmt, M, x, local_rank, flags, stream)
+        # the timed region brackets K runs with its own event pair: no per-run events inside it
+        op = ContextOperator(fmt, M, x, local_rank, flags | capi.FLAG_NO_RUN_EVENTS, stream)
         local_rows, local_nnz = rows, nnz
         local_bytes = total_bytes = format_bytes(fmt, rows, cols, nnz, M.stored, M.num_coo_entries)
         info = op.ctx.info()

@@ -93,6 +93,10 @@ extern "C" {
                                              (longest row > 16 entries) gets them: a web graph runs in a fifth of the waves.
                                              Rows that span lanes are then added in another order than the reference's
                                              (1e-10, not bit-identical; SPMV_HIP_FLAG_EXACT_ORDER also keeps row-owned tiles) */
+#define SPMV_HIP_FLAG_NO_RUN_EVENTS 0x80000u /* ctx: spmv_hip_run does not bracket the launch with a HIP event pair (each
+                                             record is a barrier packet between back-to-back runs, ~5 us per run);
+                                             spmv_hip_last_run_ns then returns SPMV_HIP_ERR_STATE.  For callers that time a
+                                             whole region themselves (bench.py); the Kernel adapters keep the events */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;

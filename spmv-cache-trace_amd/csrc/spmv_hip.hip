@@ -60,7 +60,7 @@ namespace {
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
-    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -1769,7 +1769,9 @@ int spmv_hip_run(spmv_hip_ctx * c)
     if (c->multi)
         return multi_run(c);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const bool timed = !(c->flags & SPMV_HIP_FLAG_NO_RUN_EVENTS);
+    if (timed)
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
     int rc = SPMV_HIP_OK;
     switch (c->format) {
     case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
@@ -1796,8 +1798,10 @@ int spmv_hip_run(spmv_hip_ctx * c)
     }
     if (rc != 0)
         return rc;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
     return SPMV_HIP_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include <sys/stat.h>
@@ -16,7 +17,7 @@ namespace matrix_market
 namespace
 {
 
-char const kMagic[8] = {'S', 'P', 'M', 'V', 'M', 'M', '0', '1'};
+char const kMagic[8] = {'S', 'P', 'M', 'V', 'M', 'M', '0', '2'}; // 02: payload checksum at the end
 
 struct Identity
 {
@@ -63,21 +64,51 @@ bool put(std::FILE * f, T const & v) { return std::fwrite(&v, sizeof(T), 1, f) =
 template <typename T>
 bool get(std::FILE * f, T & v) { return std::fread(&v, sizeof(T), 1, f) == 1; }
 
-template <typename T>
-bool put_array(std::FILE * f, std::vector<T> const & a)
+// Payload checksum: a multiply-and-add hash over the arrays' bytes (order-dependent; one pass at
+// memory speed).  A flipped or missing byte anywhere makes the cache file unusable -> the source is parsed.
+std::uint64_t checksum(void const * data, std::size_t bytes, std::uint64_t h)
 {
-    std::uint64_t n = a.size();
-    return put(f, n) && (n == 0 || std::fwrite(a.data(), sizeof(T), (std::size_t) n, f) == n);
+    unsigned char const * p = static_cast<unsigned char const *>(data);
+    std::size_t const words = bytes / 8;
+    for (std::size_t k = 0; k < words; ++k) {
+        std::uint64_t w;
+        std::memcpy(&w, p + 8 * k, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    }
+    for (std::size_t k = 8 * words; k < bytes; ++k)
+        h = (h ^ p[k]) * 0x100000001B3ull;
+    return h;
 }
 
 template <typename T>
-bool get_array(std::FILE * f, std::vector<T> & a, std::uint64_t limit)
+bool put_array(std::FILE * f, std::vector<T> const & a, std::uint64_t & sum)
+{
+    std::uint64_t n = a.size();
+    sum = checksum(a.data(), (std::size_t) n * sizeof(T), sum ^ n);
+    return put(f, n) && (n == 0 || std::fwrite(a.data(), sizeof(T), (std::size_t) n, f) == n);
+}
+
+// `budget` = bytes the cache file still has: an array can never be longer than what is left of the
+// file, whatever its header claims (a corrupt count must not become a multi-gigabyte allocation)
+template <typename T>
+bool get_array(std::FILE * f, std::vector<T> & a, std::uint64_t limit, std::uint64_t & budget, std::uint64_t & sum)
 {
     std::uint64_t n = 0;
-    if (!get(f, n) || n > limit)
+    if (budget < sizeof n || !get(f, n) || n > limit)
         return false;
-    a.resize((std::size_t) n);
-    return n == 0 || std::fread(a.data(), sizeof(T), (std::size_t) n, f) == n;
+    budget -= sizeof n;
+    if (n > budget / sizeof(T))
+        return false;
+    try {
+        a.resize((std::size_t) n);
+    } catch (std::bad_alloc const &) {
+        return false;
+    }
+    if (n != 0 && std::fread(a.data(), sizeof(T), (std::size_t) n, f) != n)
+        return false;
+    budget -= n * sizeof(T);
+    sum = checksum(a.data(), (std::size_t) n * sizeof(T), sum ^ n);
+    return true;
 }
 
 } // namespace
@@ -135,11 +166,28 @@ bool load_cached(std::string const & source, std::string const & directory, Matr
         if (len && std::fread(&c[0], 1, (std::size_t) len, f) != len)
             return false;
     }
+    // array format stores rows * columns values; coordinate format at most INT32_MAX entries
+    if (nnz > INT32_MAX || ((Format) format == Format::array && nnz != (std::int64_t) rows * (std::int64_t) cols))
+        return false;
     std::uint64_t const limit = (std::uint64_t) nnz;
+    std::uint64_t budget = 0;
+    {
+        long const here = std::ftell(f);
+        if (here < 0 || std::fseek(f, 0, SEEK_END) != 0)
+            return false;
+        long const end = std::ftell(f);
+        if (end < here || std::fseek(f, here, SEEK_SET) != 0)
+            return false;
+        budget = (std::uint64_t) (end - here);
+    }
     std::vector<index_type> i, j;
     std::vector<real_type> a, imag;
-    if (!get_array(f, i, limit) || !get_array(f, j, limit) || !get_array(f, a, limit) || !get_array(f, imag, limit))
+    std::uint64_t sum = 0x5350'4D56ull, stored = 0;
+    if (!get_array(f, i, limit, budget, sum) || !get_array(f, j, limit, budget, sum) || !get_array(f, a, limit, budget, sum)
+        || !get_array(f, imag, limit, budget, sum))
         return false;
+    if (!get(f, stored) || stored != sum)
+        return false; // truncated or altered payload: parse the source instead
     Field const fld = (Field) field;
     bool const coordinate = (Format) format == Format::coordinate;
     if (coordinate && (i.size() != limit || j.size() != limit))
@@ -184,8 +232,10 @@ void store_cached(std::string const & source, std::string const & directory, Mat
             ok = ok && put(f, len) && (len == 0 || std::fwrite(c.data(), 1, (std::size_t) len, f) == len);
         }
         std::vector<real_type> const a = m.field() == Field::pattern ? std::vector<real_type>() : m.values_real();
-        ok = ok && put_array(f, m.row_indices()) && put_array(f, m.column_indices()) && put_array(f, a)
-             && put_array(f, m.values_imag());
+        std::uint64_t sum = 0x5350'4D56ull;
+        ok = ok && put_array(f, m.row_indices(), sum) && put_array(f, m.column_indices(), sum) && put_array(f, a, sum)
+             && put_array(f, m.values_imag(), sum);
+        ok = ok && put(f, sum);
         ok = ok && std::fflush(f) == 0;
     }
     if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0)

@@ -26,6 +26,7 @@ FLAG_NO_X_WINDOW = 0x800
 FLAG_NO_COLUMN_PANELS = 0x1000
 FLAG_VERIFY_PLAN = 0x8000
 FLAG_NO_BALANCED_TILES = 0x40000
+FLAG_NO_RUN_EVENTS = 0x80000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

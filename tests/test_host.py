@@ -571,6 +571,26 @@ def test_matrix_cache_round_trip(host, tmp_path, monkeypatch, name):
     again = _mm_snapshot(host, h)
     host.mm_free(h)
     assert again[0] == plain[0] and np.array_equal(again[3].view(np.uint64), plain[3].view(np.uint64))
+    # ... and so is one with a flipped payload byte (checksum), or a count that claims more than the file holds
+    # (no multi-gigabyte allocation from a corrupt header): both fall back to parsing the source
+    files = sorted(f for f in os.listdir(cache) if f.endswith(".mmbin"))
+    blob = bytearray(open(cache / files[0], "rb").read())
+    for damage in ("flip", "count"):
+        bad = bytearray(blob)
+        if damage == "flip":
+            bad[len(bad) - 40] ^= 0x5A
+        else:
+            # the first array's 64-bit length sits right behind the header and the comments: find it by value
+            n = plain[0]["num_entries"]
+            at = bytes(bad).find(int(n).to_bytes(8, "little"), 8 + 16 + 24 + 8)
+            assert at > 0
+            bad[at:at + 8] = (2**40).to_bytes(8, "little")
+        open(cache / files[0], "wb").write(bytes(bad))
+        h = host.mm_load(src)
+        again = _mm_snapshot(host, h)
+        host.mm_free(h)
+        assert again[0] == plain[0] and np.array_equal(again[1], plain[1]) and \
+            np.array_equal(again[3].view(np.uint64), plain[3].view(np.uint64)), damage
 
 
 def test_cli_matrix_cache_option(tmp_path):
