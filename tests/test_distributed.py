@@ -77,7 +77,7 @@ def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False, pi
 
     op = DistributedCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, overlap=overlap,
                             ranges=ranges, pingpong=pingpong)
-    assert op.pingpong == (overlap and pingpong) and len(op.seg) == (2 if op.pingpong else 1)
+    assert op.pingpong == (overlap and pingpong) and len(op.full) == (2 if op.pingpong else 1)
     for _ in range(steps):
         op.step()
     want = O.csr_spmv(rows, p, c, v, x, runs=steps)
