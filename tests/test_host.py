@@ -635,3 +635,21 @@ Kernel * make_it() { return new hip_csr_spmv_kernel("A.mtx"); }
            "-I", os.path.join(ROOT, "include"), str(src)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_cli_check_gate_fails_on_non_finite_values(tmp_path):
+    """--check must not pass a result it cannot compare: an infinity in y (and in the reference's y) makes the
+    difference NaN, which used to be swallowed by std::max and reported as error 0 / pass."""
+    path = tmp_path / "inf.mtx"
+    path.write_text("%%MatrixMarket matrix coordinate real general\n3 3 4\n1 1 2.0\n2 1 inf\n3 2 -1.0\n3 3 2.0\n")
+    for fmt in ("coo", "ell", "csr"):
+        r = subprocess.run([hostlib.CLI, "--matrix", str(path), "--spmv-format", fmt, "--threads", "1", "--profile", "1", "--check"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "parity check failed" in r.stderr, (fmt, r.stderr)
+        d = json.loads(r.stdout)  # still one valid JSON document, with the verdict in it
+        assert d["parity"]["pass"] is False and d["parity"]["max_relative_error"] == "nan"
+    # the same matrix with finite values passes
+    path.write_text("%%MatrixMarket matrix coordinate real general\n3 3 4\n1 1 2.0\n2 1 0.5\n3 2 -1.0\n3 3 2.0\n")
+    r = subprocess.run([hostlib.CLI, "--matrix", str(path), "--spmv-format", "ell", "--threads", "2", "--profile", "3", "--check", "--x", "uniform"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and json.loads(r.stdout)["parity"]["pass"] is True
