@@ -97,10 +97,6 @@ extern "C" {
                                              record is a barrier packet between back-to-back runs, ~5 us per run);
                                              spmv_hip_last_run_ns then returns SPMV_HIP_ERR_STATE.  For callers that time a
                                              whole region themselves (bench.py); the Kernel adapters keep the events */
-#define SPMV_HIP_FLAG_NO_COLUMN_RUNS 0x100000u /* plan_csr_compress: do not look for tiles whose columns come in runs of 2, 3 or 4
-                                              consecutive ones (the dense blocks of a finite-element matrix with that many
-                                              unknowns per node); such tiles keep one 16-bit offset per run, 8 + 2/g bytes per
-                                              entry instead of 10.  Results are unchanged bit for bit */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -225,9 +221,7 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  *  - equally long rows that repeat the first row's columns shifted by the row distance (stencil
  *    interiors, bands; any column range): only the first row's columns are read, 8 bytes/entry;
  *  - tiles whose x entries fit 256 LDS slots and are each used at least twice: x staged through LDS;
- *  - blocks of 16 plain narrow tiles whose columns span <= 8192: marked for the block-window kernel;
- *  - what is then still a plain 16-bit tile and has its columns in runs of 2, 3 or 4 consecutive ones (dense
- *    blocks of a finite-element matrix): one offset per run, 8 + 2/g bytes per entry.
+ *  - blocks of 16 plain narrow tiles whose columns span <= 8192: marked for the block-window kernel.
  * Results are unchanged bit for bit.  The plan then expects the same d_column_index in spmv_hip_csr_spmv (a different
  * pointer falls back to the 32-bit indices and uses nothing derived here).  Because a pointer can be
  * the same while the contents are not (an allocator reusing the address for another matrix), the plan
@@ -271,8 +265,7 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             ALGORITHMIC bytes of SURVEY 8(d), 12 nnz + 4 (rows + 1) + 16 rows + 8 cols, never shrink
  *        [15] stored entries in shifted tiles  [16] stored entries in 16-bit tiles
  *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels)
- *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES)
- *        [20] tiles with run-length columns (see SPMV_HIP_FLAG_NO_COLUMN_RUNS)  [21] stored entries in them */
+ *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

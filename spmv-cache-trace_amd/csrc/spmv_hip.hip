@@ -60,7 +60,7 @@ namespace {
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
-    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_COLUMN_RUNS
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -141,11 +141,10 @@ struct spmv_hip_plan {
     int npatterns = 0;
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     int split_rows = 0;    // rows cut into chunks that are added to y with atomics
-    int runs_tiles = 0;    // narrow tiles whose columns are stored as runs of 2-4 consecutive ones
     bool balanced = false; // tiles filled by entries, row sums by segmented reduction (csr_segtile_kernel)
     size_t meta_bytes = 0;
     // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
-    long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0, runs_entries = 0;
+    long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;
     // content guard: checksum of the column array the 16-bit stream and the tile marks were derived from
     unsigned long long column_checksum = 0;
     bool verify_pending = false; // the first multiply after compress re-checks the checksum
@@ -379,7 +378,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
 {
     const long long algorithmic = 12LL * pl->nnz + 4LL * (pl->rows + 1LL) + 16LL * pl->rows + 8LL * pl->cols;
     pl->streamed_bytes = algorithmic;
-    pl->shifted_entries = pl->narrow_entries = pl->uniform_rows = pl->runs_entries = 0;
+    pl->shifted_entries = pl->narrow_entries = pl->uniform_rows = 0;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0)
         return SPMV_HIP_OK;
     std::vector<int4> d((size_t) pl->ntiles + 1);
@@ -398,11 +397,8 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             col_bytes = (meta & spmv::kTileMetaPattern) ? 0 : 4LL * (meta & 0xFFFF);
             pl->shifted_entries += entries;
         } else if (narrow) {
-            const int g = ((meta & spmv::kTileMetaRunsMask) >> spmv::kTileMetaRunsShift) + 1; // 1 = one offset per entry
-            col_bytes = 2 * ((entries + g - 1) / g);
+            col_bytes = 2 * entries;
             pl->narrow_entries += entries;
-            if (g > 1)
-                pl->runs_entries += entries;
         }
         if (uniform)
             pl->uniform_rows += rows;
@@ -799,20 +795,6 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
             }
         }
     }
-    // run-length columns for what is still a plain narrow tile (finite-element blocks: 8 + 2/g instead of 10 B per entry)
-    if (e == hipSuccess && !pl->balanced && pl->tile == 512 && !(pl->flags & SPMV_HIP_FLAG_NO_COLUMN_RUNS)) {
-        int rc2[2] = {0, 0};
-        e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(spmv::csr_tile_runs_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s, pl->ntiles, pl->tile, pl->d_tiles,
-                               d_column_index, pl->d_col16, d_count);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(rc2, d_count, sizeof(rc2), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess)
-            pl->runs_tiles = rc2[0];
-    }
     if (d_count)
         (void) hipFree(d_count);
     if (d_fp)
@@ -939,7 +921,6 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         pl->streamed_bytes = pl->inner->streamed_bytes - 16LL * vrows + 16LL * nonempty;
         pl->shifted_entries = pl->inner->shifted_entries;
         pl->narrow_entries = pl->inner->narrow_entries;
-        pl->runs_entries = pl->inner->runs_entries;
         pl->uniform_rows = 0;
     }
     return SPMV_HIP_OK;
@@ -969,13 +950,12 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[22] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[20] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
-                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0,
-                           pl->inner ? pl->inner->runs_tiles : pl->runs_tiles, pl->runs_entries};
-    for (int i = 0; i < n && i < 22; ++i)
+                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0};
+    for (int i = 0; i < n && i < 20; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -266,11 +266,6 @@ constexpr int kTileFlagPartial = (int) 0x80000000u;
 constexpr int kTileMetaLanesShift = 16;
 constexpr int kTileMetaBlockWin = 1 << 20; // the tile belongs to csr_blockwin_kernel; csr_wavetile_kernel skips it
 constexpr int kTileMetaPattern = 1 << 19; // shifted tile: desc.w is a pattern number (first-row columns = first row + pattern)
-// narrow tile whose columns come in runs of g = 2, 3 or 4 consecutive ones counted from the tile's first
-// entry (the dense blocks of a finite-element matrix with g unknowns per node): bits 22-23 hold g - 1,
-// and the front of the tile's 16-bit slots holds one offset per run instead of one per entry
-constexpr int kTileMetaRunsShift = 22;
-constexpr int kTileMetaRunsMask = 3 << kTileMetaRunsShift;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
@@ -398,56 +393,6 @@ __device__ __forceinline__ void tile_products_narrow(
             const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
             const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
             const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c3 << 3));
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-}
-
-// Run-length columns: entry t of the tile (counted from its first entry) has column
-// base + run[t / g] + t % g.  The <= 256 run offsets are staged in the wave's LDS table (2 bytes each, one
-// coalesced read), so the tile streams 8 + 2/g bytes per entry instead of 10.  Purely positional: no
-// row bounds are involved, the plan has checked every entry of the tile against this formula.
-template <int QUADS>
-__device__ __forceinline__ void tile_products_runs(
-    double * prod, uint16_t * tab, const uint16_t * __restrict__ runs, const double * __restrict__ at,
-    const double * __restrict__ xt, unsigned limit, int last, int lane, int g, int lead, int nruns)
-{
-    static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
-    v2d va[QUADS], vb[QUADS];
-    for (int i = lane; i < nruns; i += kWave)
-        tab[i] = runs[i];
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last;
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned magic = ((1u << 22) + (unsigned) g - 1u) / (unsigned) g; // wave-uniform
-    const unsigned rlast = (unsigned) (nruns - 1);
-    const char * xb = reinterpret_cast<const char *>(xt);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            unsigned c[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // entries in front of the tile / behind its end share a quad with it: multiplied, never read back
-                const int ti = o + i - lead;
-                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-                const unsigned r = (t * magic) >> 22;
-                c[i] = min((unsigned) tab[min(r, rlast)] + (t - r * (unsigned) g), limit);
-            }
-            const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c[0] << 3));
-            const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c[1] << 3));
-            const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c[2] << 3));
-            const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c[3] << 3));
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
             dst[0] = v2d{q0, q1};
             dst[1] = v2d{q2, q3};
@@ -783,11 +728,6 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0],
                                               pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                               a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb);
-        }
-        else if (C16 && (meta & kTileMetaNarrow) && (meta & kTileMetaRunsMask)) {
-            const int g = ((meta & kTileMetaRunsMask) >> kTileMetaRunsShift) + 1;
-            tile_products_runs<QUADS>(prod, reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]), j16 + k0, a + kb, x + cbase,
-                                      (unsigned) (cols - 1 - cbase), last, lane, g, k0 - kb, (k1 - k0 + g - 1) / g);
         }
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
@@ -1676,50 +1616,6 @@ __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
             atomicAdd(counts + 1, 1);
         if (xwin)
             atomicAdd(counts + 2, 1);
-    }
-}
-
-// Plan-time, after every other classification (one wave per tile): a plain narrow tile -- not shifted, no
-// x window, not in a block window -- whose columns come in runs of g = 4, 3 or 2 consecutive ones counted
-// from its first entry gets its run offsets written over the front of its own 16-bit slots and g - 1 in
-// its descriptor; counts[0] += 1, counts[1] += its entries.  The check is positional and complete: every
-// entry t must equal the first entry of its run plus t % g, so whatever the rows look like the decoded
-// columns are the stored ones.
-__global__ __launch_bounds__(256) void csr_tile_runs_kernel(
-    int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j, uint16_t * __restrict__ j16,
-    int * __restrict__ counts)
-{
-    const int wave = (int) threadIdx.x >> 6;
-    const int lane = (int) __lane_id();
-    const int w = blockIdx.x * 4 + wave;
-    if (w >= ntiles)
-        return;
-    const int4 d0 = desc[w];
-    const int k0 = d0.y, k1 = desc[w + 1].y;
-    const int m = d0.z;
-    if ((d0.x & kTileFlagPartial) || k1 - k0 < 8 || k1 - (k0 & ~3) > tile || tile > 512 || !(m & kTileMetaNarrow) || !(m & kTileMetaFast)
-        || (m & (kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | kTileMetaBlockWin | kTileMetaSeg)))
-        return;
-    const int n = k1 - k0;
-    int ok4 = 1, ok3 = 1, ok2 = 1;
-    for (int t = lane; t < n; t += kWave) {
-        const int c = j[k0 + t];
-        ok4 &= (c == j[k0 + (t & ~3)] + (t & 3));
-        ok3 &= (c == j[k0 + t - t % 3] + t % 3);
-        ok2 &= (c == j[k0 + (t & ~1)] + (t & 1));
-    }
-    const int g = __all(ok4) ? 4 : (__all(ok3) ? 3 : (__all(ok2) ? 2 : 0));
-    if (g == 0)
-        return;
-    // all lanes have read what they need of j (the 32-bit array is not touched); now the 16-bit slots
-    const int base = d0.w;
-    const int nruns = (n + g - 1) / g;
-    for (int i = lane; i < nruns; i += kWave)
-        j16[k0 + i] = (uint16_t) (j[k0 + g * i] - base);
-    if (lane == 0) {
-        desc[w].z = m | ((g - 1) << kTileMetaRunsShift);
-        atomicAdd(counts, 1);
-        atomicAdd(counts + 1, n);
     }
 }
 

@@ -27,7 +27,6 @@ FLAG_NO_COLUMN_PANELS = 0x1000
 FLAG_VERIFY_PLAN = 0x8000
 FLAG_NO_BALANCED_TILES = 0x40000
 FLAG_NO_RUN_EVENTS = 0x80000
-FLAG_NO_COLUMN_RUNS = 0x100000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -289,11 +288,11 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(22, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 22))
+        out = np.zeros(20, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 20))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
-                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "runs_tiles", "runs_entries"]
+                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

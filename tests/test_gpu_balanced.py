@@ -189,52 +189,3 @@ def test_hybrid_upload_is_one_fused_multiply(oracle):
         ctx.set_y(y0)
         ctx.run(2)
         assert_close(ctx.get_y(), want, scale, what="hybrid two launches")
-
-
-@pytest.mark.parametrize("g", [2, 3, 4])
-def test_run_length_column_tiles_bit_identical(oracle, g):
-    """Tiles whose columns come in runs of g consecutive ones (dense g x g blocks of a finite-element matrix)
-    keep one 16-bit offset per run.  Same bits as without the class, and as the oracle where rows are summed
-    by one lane; mixed with rows that break the runs, partial last runs, and the queen-like generator."""
-    import torch
-    from spmv_amd import hostapi
-    rng = np.random.default_rng(40 + g)
-    nodes = 20000
-    per_node = rng.integers(2, 8, size=nodes)                      # neighbour nodes of every node
-    nb = np.sort(np.clip(np.arange(nodes)[:, None] + rng.integers(-5000, 5000, size=(nodes, 8)), 0, nodes - 1), axis=1)
-    rows_c, rows_len = [], []
-    for n in range(nodes):
-        cols_n = np.unique(nb[n, :per_node[n]])
-        cc = (g * cols_n[:, None] + np.arange(g)[None, :]).reshape(-1)
-        for a in range(g):                                           # the g rows of a node share its columns
-            if n % 97 == 0 and a == 1:
-                cc2 = np.delete(cc, 1)                               # a row that breaks the runs now and then
-                rows_c.append(cc2); rows_len.append(len(cc2))
-            else:
-                rows_c.append(cc); rows_len.append(len(cc))
-    rows = cols = g * nodes
-    p = np.zeros(rows + 1, dtype=np.int32)
-    np.cumsum(rows_len, out=p[1:])
-    c = np.concatenate(rows_c).astype(np.int32)
-    v = rng.uniform(-1, 1, size=len(c))
-    x = synth.x_vector(cols, seed=3)
-    y0 = synth.x_vector(rows, seed=4)
-    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
-    got, info = _multiply(rows, cols, p, c, v, x, y0)
-    ref, info0 = _multiply(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_COLUMN_RUNS)
-    assert info["runs_tiles"] > 0.5 * info["row_blocks"] and info0["runs_tiles"] == 0, (info, info0)
-    assert info["streamed_bytes"] < info0["streamed_bytes"]
-    assert_bitexact(got, ref, "runs of %d vs one offset per entry" % g)
-    assert_close(got, want, abs_products(rows, p, c, v, x) + np.abs(y0), what="runs of %d" % g)
-    if np.max(rows_len) <= 16:
-        assert_bitexact(got, want, "runs of %d vs oracle" % g)
-    if g == 3:  # the generator of BASELINE configs[2] at a small size: 3 unknowns per node
-        A = hostapi.load("synthetic:queen:60,40,12")
-        xq = synth.x_vector(A.cols, seed=5)
-        gq, iq = _multiply(A.rows, A.cols, np.array(A.row_ptr), np.array(A.column_index), np.array(A.value), xq, np.zeros(A.rows))
-        rq, _ = _multiply(A.rows, A.cols, np.array(A.row_ptr), np.array(A.column_index), np.array(A.value), xq, np.zeros(A.rows),
-                          flags=capi.FLAG_NO_COLUMN_RUNS)
-        assert iq["runs_tiles"] > 0.8 * iq["row_blocks"], iq
-        assert_bitexact(gq, rq, "queen-like, runs of 3")
-        assert_close(gq, oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, xq, num_threads=4),
-                     abs_products(A.rows, A.row_ptr, A.column_index, A.value, xq), what="queen-like")
