@@ -41,7 +41,8 @@ sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-XGMI_LINK_GBS = 64.0       # per direction and link, 7 links per GPU (the figure DESIGN.md section 6 uses)
+XGMI_LINK_GBS = 64.0       # per direction and link, 7 links per GPU: the conservative figure DESIGN.md section 6 uses
+XGMI_LINK_GBS_QUOTED = 153.0  # the per-link figure usually quoted for MI355X; the truth for one direction lies in between
 CLI = os.path.join(ROOT, "spmv-cache-trace_amd", "spmv-cache-trace-hip")
 
 
@@ -633,13 +634,16 @@ def main():
             # what the step can reach at best: the local multiply and the gather fully overlapped; the gather is bounded
             # by the bytes a rank must RECEIVE over its 7 xGMI links (direct all-gather, all links busy)
             model_gather_us = recv / (7 * XGMI_LINK_GBS * 1e9) * 1e6 if world > 1 else 0.0
+            model_gather_us_fast = recv / (7 * XGMI_LINK_GBS_QUOTED * 1e9) * 1e6 if world > 1 else 0.0
             out["multi_gpu"] = {"local_kernel_us": round(kern_s * 1e6, 2), "all_gather_us": round(gather_us, 2),
                                 "all_gather_bytes_received_per_rank": int(recv),
                                 "all_gather_gbs_received_per_rank": round(recv / (gather_us * 1e-6) / 1e9, 1) if world > 1 else None,
                                 "overlap": bool(op.overlap),
                                 "model": {"formula": "predicted_us = max(local_kernel_us, received_bytes / (7 links x %.0f GB/s))" % XGMI_LINK_GBS,
                                           "gather_us_at_link_rate": round(model_gather_us, 1),
+                                          "gather_us_at_%.0f_GBs_per_link" % XGMI_LINK_GBS_QUOTED: round(model_gather_us_fast, 1),
                                           "predicted_us": round(max(kern_s * 1e6, model_gather_us), 1),
+                                          "predicted_us_at_%.0f_GBs_per_link" % XGMI_LINK_GBS_QUOTED: round(max(kern_s * 1e6, model_gather_us_fast), 1),
                                           "measured_us": round(ms_per_step * 1e3, 1)},
                                 "note": "all_gather_us: blocking collective alone, median of 5 after the timed region",
                                 "one_all_gather_after_the_k_multiplies": deferred}
