@@ -1698,6 +1698,9 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
             c->d_val2 = nullptr;
             c->ell_as_tiles = false;
             c->as_csr = true;
+            // what the context holds now: the merged matrix, x and y (the parts it was made from are gone)
+            c->bytes = ((size_t) rows + 1) * sizeof(int32_t) + (size_t) merged * (sizeof(int32_t) + sizeof(double))
+                + ((size_t) cols + (size_t) rows) * sizeof(double) + 5 * 64;
             return ctx_plan_device_csr(c, host_ptr, 0);
         }
         // two launches (file order kept, exact ELL order asked for, or the merged matrix would not fit
