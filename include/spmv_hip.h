@@ -97,6 +97,8 @@ extern "C" {
                                              record is a barrier packet between back-to-back runs, ~5 us per run);
                                              spmv_hip_last_run_ns then returns SPMV_HIP_ERR_STATE.  For callers that time a
                                              whole region themselves (bench.py); the Kernel adapters keep the events */
+#define SPMV_HIP_FLAG_NO_VALUE_INDEX 0x100000u /* never build a value dictionary (spmv_hip_plan_csr_index_values is a no-op; the
+                                              context does not build one for its uploads) */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -245,9 +247,22 @@ int spmv_hip_plan_verify(spmv_hip_plan *plan, const int32_t *d_column_index, voi
  * plan_info[13] tells.  Costs 12 bytes per entry + 32 bytes per row of device memory.  Synchronises. */
 int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
                              const double *d_value, void *stream);
-/* After changing the VALUES of a matrix whose plan holds column panels (plan_info[18] == 1): copy them
- * into the panel copy again (structure unchanged; d_value may be a new array, which the plan then
- * expects).  Does nothing when the plan has no panels.  Asynchronous on `stream`. */
+/* Optional planning step for matrices with FEW DISTINCT VALUES (at most 128 different bit patterns among
+ * the stored entries: pattern / graph matrices, constant-coefficient stencils, meshes of identical
+ * elements): the plan keeps the distinct values in a table and one BYTE per entry saying which, and the
+ * default kernel then streams 1 instead of 8 bytes of value per entry, taking the double itself from the
+ * table -- the stored bits, so y is unchanged bit for bit.  Does nothing (returns 0, plan_info[20] == 0)
+ * when the matrix has more distinct values or the plan uses another kernel.  BY CALLING THIS THE CALLER
+ * PROMISES that d_value keeps its contents while the plan lives, or that
+ * spmv_hip_plan_csr_refresh_values follows every change; the promise is checked like the one for the
+ * columns (checksum on the first multiply, on every multiply with SPMV_HIP_FLAG_VERIFY_PLAN: a changed
+ * array is SPMV_HIP_ERR_STATE, not a wrong y).  spmv_hip_upload_* do this by themselves: the context
+ * owns its copy of the values.  Costs nnz bytes of device memory; synchronises `stream`. */
+int spmv_hip_plan_csr_index_values(spmv_hip_plan *plan, const double *d_value, void *stream);
+/* After changing the VALUES of a matrix whose plan holds a value dictionary (plan_info[20] > 0) or column
+ * panels (plan_info[18] == 1): bring both up to date (structure unchanged; d_value may be a new array,
+ * which the plan then expects; a dictionary is dropped if the values are no longer few).  Does nothing
+ * when the plan has neither.  The panel copy is asynchronous on `stream`, the dictionary synchronises it. */
 int spmv_hip_plan_csr_refresh_values(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
                                      const double *d_value, void *stream);
 void spmv_hip_plan_destroy(spmv_hip_plan *plan);
@@ -265,7 +280,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             ALGORITHMIC bytes of SURVEY 8(d), 12 nnz + 4 (rows + 1) + 16 rows + 8 cols, never shrink
  *        [15] stored entries in shifted tiles  [16] stored entries in 16-bit tiles
  *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels)
- *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES) */
+ *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES)
+ *        [20] size of the value dictionary (0 = none; see spmv_hip_plan_csr_index_values) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

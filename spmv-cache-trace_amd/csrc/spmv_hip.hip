@@ -60,7 +60,7 @@ namespace {
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
-    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -145,6 +145,13 @@ struct spmv_hip_plan {
     size_t meta_bytes = 0;
     // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
     long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;
+    // value dictionary (spmv_hip_plan_csr_index_values): one byte per stored entry + the distinct values
+    uint8_t * d_vidx = nullptr;
+    double * d_vtab = nullptr;            // kMaxIndexedValues doubles
+    int nvalues = 0;                      // 0 = no dictionary
+    const double * values_from = nullptr; // the value array it was made from
+    unsigned long long value_checksum = 0;
+    bool verify_values_pending = false;
     // content guard: checksum of the column array the 16-bit stream and the tile marks were derived from
     unsigned long long column_checksum = 0;
     bool verify_pending = false; // the first multiply after compress re-checks the checksum
@@ -351,6 +358,40 @@ int device_column_checksum(const int32_t * d_col, long long n, unsigned long lon
     return e == hipSuccess ? SPMV_HIP_OK : fail_hip(e, "column checksum");
 }
 
+int device_value_checksum(const double * d_val, long long n, unsigned long long * out, hipStream_t s)
+{
+    *out = 0;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    unsigned long long * d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_sum, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::value_checksum_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, d_val, d_sum);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_sum);
+    return e == hipSuccess ? SPMV_HIP_OK : fail_hip(e, "value checksum");
+}
+
+// the value dictionary belongs to ONE value array with ONE content: same rule as for the columns below
+int verify_plan_values(spmv_hip_plan * pl, const double * d_value, hipStream_t s)
+{
+    pl->verify_values_pending = false;
+    if (pl->nvalues == 0 || pl->values_from != d_value)
+        return SPMV_HIP_OK; // another array: its values are read as they are
+    unsigned long long sum = 0;
+    int rc = device_value_checksum(d_value, pl->nnz, &sum, s);
+    if (rc != SPMV_HIP_OK)
+        return rc;
+    if (sum != pl->value_checksum)
+        return fail(SPMV_HIP_ERR_STATE, "the value array changed since spmv_hip_plan_csr_index_values: call "
+                                        "spmv_hip_plan_csr_refresh_values after changing values");
+    return SPMV_HIP_OK;
+}
+
 // The plan's derived data (16-bit column stream, tile marks, patterns) belong to ONE column array.
 // Pointer identity alone cannot tell a new matrix that an allocator placed at the old address, so
 // the contents are checked: on the first multiply after compress, on every multiply with
@@ -402,7 +443,9 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         }
         if (uniform)
             pl->uniform_rows += rows;
-        bytes += 8 * entries + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+        // with a value dictionary the stream tiles of the default kernel read one byte per entry
+        const long long val_bytes = (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
+        bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
     pl->streamed_bytes = bytes;
     return SPMV_HIP_OK;
@@ -665,6 +708,10 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_patterns);
     if (pl->d_blocks)
         (void) hipFree(pl->d_blocks);
+    if (pl->d_vidx)
+        (void) hipFree(pl->d_vidx);
+    if (pl->d_vtab)
+        (void) hipFree(pl->d_vtab);
     if (pl->inner)
         spmv_hip_plan_destroy(pl->inner);
     if (pl->d_vrow_ptr)
@@ -926,11 +973,112 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     return SPMV_HIP_OK;
 }
 
+static void drop_value_dictionary(spmv_hip_plan * pl)
+{
+    if (pl->d_vidx) (void) hipFree(pl->d_vidx);
+    if (pl->d_vtab) (void) hipFree(pl->d_vtab);
+    pl->d_vidx = nullptr;
+    pl->d_vtab = nullptr;
+    pl->nvalues = 0;
+    pl->values_from = nullptr;
+    pl->verify_values_pending = false;
+}
+
+int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t before = (pl->d_vidx ? (size_t) pl->nnz + 64 + spmv::kMaxIndexedValues * sizeof(double) : 0);
+    drop_value_dictionary(pl);
+    pl->meta_bytes -= std::min(pl->meta_bytes, before);
+    // only the default kernel reads the dictionary (row-owned wave tiles with 16-bit-capable plans, x below 4 GiB)
+    // (not with column panels, block windows or a majority of x-window tiles: those launches have their own variants)
+    const bool other_variant = pl->inner || pl->d_blocks
+        || (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles);
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
+        || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
+        || (pl->flags & (SPMV_HIP_FLAG_NO_VALUE_INDEX | SPMV_HIP_FLAG_XCD_REMAP)))
+        return pl->inner ? SPMV_HIP_OK : plan_account(pl, pl->d_col16 != nullptr);
+    if (!d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    unsigned long long * d_keys = nullptr;
+    int * d_state = nullptr;
+    std::vector<unsigned long long> keys((size_t) spmv::kDictSlots, spmv::kDictEmpty);
+    int state[2] = {0, 0};
+    hipError_t e = hipMalloc((void **) &d_keys, keys.size() * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_state, sizeof(state));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_keys, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(state), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::value_dict_insert_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 8)), dim3(256), 0, s,
+                           (long long) pl->nnz, d_value, d_keys, d_state, spmv::kMaxIndexedValues);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int rc = SPMV_HIP_OK;
+    if (e == hipSuccess && state[1] == 0 && state[0] >= 1 && state[0] <= spmv::kMaxIndexedValues) {
+        // few enough distinct values: sort the bit patterns, index every entry
+        std::vector<unsigned long long> table;
+        for (unsigned long long k : keys)
+            if (k != spmv::kDictEmpty)
+                table.push_back(k);
+        std::sort(table.begin(), table.end());
+        std::vector<double> values((size_t) spmv::kMaxIndexedValues, 0.0);
+        for (size_t i = 0; i < table.size(); ++i)
+            std::memcpy(&values[i], &table[i], sizeof(double));
+        unsigned long long * d_table = nullptr;
+        e = hipMalloc((void **) &d_table, (size_t) spmv::kMaxIndexedValues * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vtab, (size_t) spmv::kMaxIndexedValues * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vidx, (size_t) pl->nnz + 64);
+        if (e == hipSuccess) e = hipMemsetAsync(pl->d_vidx, 0, (size_t) pl->nnz + 64, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(pl->d_vtab, values.data(), values.size() * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(state), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::value_index_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 16)), dim3(256), 0, s,
+                               (long long) pl->nnz, d_value, d_table, (int) table.size(), pl->d_vidx, d_state);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (d_table) (void) hipFree(d_table);
+        if (e == hipSuccess && state[1] == 0) {
+            pl->nvalues = (int) table.size();
+            pl->values_from = d_value;
+            rc = device_value_checksum(d_value, pl->nnz, &pl->value_checksum, s);
+            pl->verify_values_pending = true;
+            pl->meta_bytes += (size_t) pl->nnz + 64 + spmv::kMaxIndexedValues * sizeof(double);
+        } else {
+            drop_value_dictionary(pl); // the values changed between the two passes, or a HIP error
+        }
+    }
+    if (d_keys) (void) hipFree(d_keys);
+    if (d_state) (void) hipFree(d_state);
+    if (e != hipSuccess) {
+        drop_value_dictionary(pl);
+        return fail_hip(e, "value dictionary");
+    }
+    if (rc != SPMV_HIP_OK) {
+        drop_value_dictionary(pl);
+        return rc;
+    }
+    return plan_account(pl, pl->d_col16 != nullptr);
+}
+
 int spmv_hip_plan_csr_refresh_values(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
                                      const double * d_value, void * stream)
 {
     if (!pl)
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->nvalues > 0 || pl->d_vidx) {
+        // the dictionary is rebuilt from the new values (and dropped if they are no longer few)
+        int rc = spmv_hip_plan_csr_index_values(pl, d_value, stream);
+        if (rc != SPMV_HIP_OK)
+            return rc;
+    }
     if (!pl->inner)
         return SPMV_HIP_OK; // no snapshot: the multiply reads the caller's values
     if (!d_row_ptr || !d_column_index || !d_value)
@@ -950,12 +1098,12 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[20] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[21] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
-                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0};
-    for (int i = 0; i < n && i < 20; ++i)
+                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues};
+    for (int i = 0; i < n && i < 21; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }
@@ -994,6 +1142,11 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
     }
     if (pl->verify_pending || (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN)) {
         int rc = verify_plan(const_cast<spmv_hip_plan *>(pl), j, s);
+        if (rc != SPMV_HIP_OK)
+            return rc;
+    }
+    if (pl->verify_values_pending || (pl->nvalues > 0 && (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN))) {
+        int rc = verify_plan_values(const_cast<spmv_hip_plan *>(pl), a, s);
         if (rc != SPMV_HIP_OK)
             return rc;
     }
@@ -1076,6 +1229,11 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
 #endif
             else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
+            } else if (c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a) {
+                // the default kernel with the value dictionary: one byte per entry instead of eight
+                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                   spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
             }
@@ -1383,6 +1541,8 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
         // scattered columns and an x that does not fit one XCD's L2: column panels (the context owns
         // the arrays, so the snapshot of the values cannot go stale)
         if ((rc = spmv_hip_plan_csr_repack(c->plan, c->d_ptr, c->d_col, c->d_val, c->stream)) != 0) return rc;
+        // the context owns the device copy of the values, so a value dictionary cannot go stale
+        if ((rc = spmv_hip_plan_csr_index_values(c->plan, c->d_val, c->stream)) != 0) return rc;
     }
     c->format = 1;
     return SPMV_HIP_OK;
@@ -1467,6 +1627,7 @@ static int ctx_plan_device_csr(spmv_hip_ctx * c, const std::vector<int32_t> & ho
     if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
         if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
         if ((rc = spmv_hip_plan_csr_repack(c->plan, c->d_ptr, c->d_col, c->d_val, c->stream)) != 0) return rc;
+        if ((rc = spmv_hip_plan_csr_index_values(c->plan, c->d_val, c->stream)) != 0) return rc;
     }
     return SPMV_HIP_OK;
 }
@@ -1575,8 +1736,10 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
             free_ctx_matrix(c);
             return fail(SPMV_HIP_ERR_INVALID, "column index out of range");
         }
-        if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION))
+        if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
             if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
+            if ((rc = spmv_hip_plan_csr_index_values(c->plan, c->d_val, c->stream)) != 0) return rc;
+        }
     } else if (n > 0) {
         int32_t * t_col = nullptr;
         double * t_val = nullptr;

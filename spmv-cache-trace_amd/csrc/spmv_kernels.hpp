@@ -330,30 +330,69 @@ __device__ __forceinline__ double tile_row_sum(const double * prod, int s, int e
     return group_sum<L>(z);
 }
 
+// Where a tile's values come from.  VI = false: the value array (two 16-byte loads per lane and quad).
+// VI = true (the plan holds a value dictionary: the matrix has at most kMaxIndexedValues distinct values --
+// a pattern / graph matrix, a constant-coefficient stencil, a mesh of identical elements): one BYTE per
+// entry from the plan's index stream (one dword per lane and quad) and the value itself out of a table
+// in LDS.  The doubles are the stored ones bit for bit; the tile streams 1 instead of 8 bytes per entry.
+constexpr int kMaxIndexedValues = 128;
+
+template <int QUADS, bool VI>
+struct TileValues {
+    v2d va[QUADS], vb[QUADS];
+    unsigned vi[VI ? QUADS : 1];
+
+    // at / vit already point at the tile's 4-aligned first entry
+    __device__ __forceinline__ void load(const double * __restrict__ at, const uint8_t * __restrict__ vit, int last, int lane)
+    {
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            int o = 256 * q + 4 * lane;
+            o = o < last ? o : last; // lanes past the tile's end re-read its last quad
+            if (VI) {
+                vi[q] = *reinterpret_cast<const unsigned *>(vit + o);
+            } else {
+                va[q] = *reinterpret_cast<const v2d *>(at + o);
+                vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void resolve(const double * vtab)
+    {
+        if (VI) {
+#pragma unroll
+            for (int q = 0; q < QUADS; ++q) {
+                va[q] = v2d{vtab[vi[q] & 0x7Fu], vtab[(vi[q] >> 8) & 0x7Fu]};
+                vb[q] = v2d{vtab[(vi[q] >> 16) & 0x7Fu], vtab[(vi[q] >> 24) & 0x7Fu]};
+            }
+        }
+    }
+};
+
 // Products of one quad-set with 32-bit column indices.
-template <int QUADS, bool X32>
+template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_wide(
     double * prod, const int32_t * __restrict__ jt, const double * __restrict__ at,
-    const double * __restrict__ x, int last, int lane)
+    const double * __restrict__ x, int last, int lane, const uint8_t * __restrict__ vit = nullptr, const double * vtab = nullptr)
 {
     v4i c[QUADS];
-    v2d va[QUADS], vb[QUADS];
+    TileValues<QUADS, VI> vals;
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         int o = 256 * q + 4 * lane;
         o = o < last ? o : last; // lanes past the tile's end re-read its last quad
         c[q] = *reinterpret_cast<const v4i *>(jt + o);
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
     }
+    vals.load(at, vit, last, lane);
+    vals.resolve(vtab);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         const int o = 256 * q + 4 * lane;
         if (o <= last) {
-            const double q0 = va[q].x * gather_x<X32>(x, c[q].x);
-            const double q1 = va[q].y * gather_x<X32>(x, c[q].y);
-            const double q2 = vb[q].x * gather_x<X32>(x, c[q].z);
-            const double q3 = vb[q].y * gather_x<X32>(x, c[q].w);
+            const double q0 = vals.va[q].x * gather_x<X32>(x, c[q].x);
+            const double q1 = vals.va[q].y * gather_x<X32>(x, c[q].y);
+            const double q2 = vals.vb[q].x * gather_x<X32>(x, c[q].z);
+            const double q3 = vals.vb[q].y * gather_x<X32>(x, c[q].w);
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
             dst[0] = v2d{q0, q1};
             dst[1] = v2d{q2, q3};
@@ -363,22 +402,23 @@ __device__ __forceinline__ void tile_products_wide(
 
 // The same with 16-bit column offsets from the tile's base: xt = x + base (scalar), limit =
 // last valid offset from the base (cols - 1 - base).
-template <int QUADS, int ABL>
+template <int QUADS, int ABL, bool VI = false>
 __device__ __forceinline__ void tile_products_narrow(
     double * prod, const uint16_t * __restrict__ jt, const double * __restrict__ at,
-    const double * __restrict__ xt, unsigned limit, int last, int lane)
+    const double * __restrict__ xt, unsigned limit, int last, int lane, const uint8_t * __restrict__ vit = nullptr,
+    const double * vtab = nullptr)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     v2u c[QUADS];
-    v2d va[QUADS], vb[QUADS];
+    TileValues<QUADS, VI> vals;
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         int o = 256 * q + 4 * lane;
         o = o < last ? o : last;
         c[q] = *reinterpret_cast<const v2u *>(jt + o); // four 16-bit offsets
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
     }
+    vals.load(at, vit, last, lane);
+    vals.resolve(vtab);
     const char * xb = reinterpret_cast<const char *>(xt);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -389,10 +429,10 @@ __device__ __forceinline__ void tile_products_narrow(
             if (ABL & 1) { // timing experiment only: every lane gathers the same four x entries
                 c0 &= 1; c1 &= 1; c2 &= 1; c3 &= 1;
             }
-            const double q0 = va[q].x * *reinterpret_cast<const double *>(xb + (c0 << 3));
-            const double q1 = va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
-            const double q2 = vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
-            const double q3 = vb[q].y * *reinterpret_cast<const double *>(xb + (c3 << 3));
+            const double q0 = vals.va[q].x * *reinterpret_cast<const double *>(xb + (c0 << 3));
+            const double q1 = vals.va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
+            const double q2 = vals.vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
+            const double q3 = vals.vb[q].y * *reinterpret_cast<const double *>(xb + (c3 << 3));
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
             dst[0] = v2d{q0, q1};
             dst[1] = v2d{q2, q3};
@@ -409,28 +449,23 @@ __device__ __forceinline__ void tile_products_narrow(
 // while t * len < 2^22 (t < 1024, len <= 512), with t * magic < 2^32.
 constexpr int kShiftedMaxLen = 128;
 
-template <int QUADS, bool X32>
+template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_shifted(
     double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
     const double * __restrict__ at, const double * __restrict__ x, unsigned limit, int last, int lane,
-    int len, int lead)
+    int len, int lead, const uint8_t * __restrict__ vit = nullptr, const double * vtab = nullptr)
 {
     static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
-    v2d va[QUADS], vb[QUADS];
+    TileValues<QUADS, VI> vals;
     // first_row: the tile's own first row in the column array (base 0), or its pattern's columns
     // relative to the first row index (base = that index; cache-resident, no per-tile read)
     for (int i = lane; i < len; i += kWave)
         tab[i] = (uint32_t) (first_row[i] + first_row_base);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last;
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-    }
+    vals.load(at, vit, last, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    vals.resolve(vtab);
     const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -446,10 +481,10 @@ __device__ __forceinline__ void tile_products_shifted(
                 const unsigned r = (t * magic) >> 22;
                 c[i] = min(tab[t - r * (unsigned) len] + r, limit);
             }
-            const double q0 = va[q].x * gather_x<X32>(x, (int) c[0]);
-            const double q1 = va[q].y * gather_x<X32>(x, (int) c[1]);
-            const double q2 = vb[q].x * gather_x<X32>(x, (int) c[2]);
-            const double q3 = vb[q].y * gather_x<X32>(x, (int) c[3]);
+            const double q0 = vals.va[q].x * gather_x<X32>(x, (int) c[0]);
+            const double q1 = vals.va[q].y * gather_x<X32>(x, (int) c[1]);
+            const double q2 = vals.vb[q].x * gather_x<X32>(x, (int) c[2]);
+            const double q3 = vals.vb[q].y * gather_x<X32>(x, (int) c[3]);
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
             dst[0] = v2d{q0, q1};
             dst[1] = v2d{q2, q3};
@@ -615,12 +650,16 @@ struct PanelInfo {
     int rows;     // rows of the matrix (= virtual rows per panel)
 };
 
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false>
+// VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
+// <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
+// only workgroup barrier of this kernel, passed by every wave before any of them can leave).
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
-    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo)
+    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
+    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr)
 {
     // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
     // different ones (a partitioned multiply whose previous result is still being gathered); every
@@ -629,6 +668,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
+    __shared__ double vtab[VI ? kMaxIndexedValues : 1];                 // VI variant: the value dictionary
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
@@ -643,13 +683,23 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         y = y_arg - (size_t) pk * (size_t) pinfo.rows; // virtual row v of panel pk is row v - pk * rows
     } else {
         w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
-        if (w >= ntiles)
-            return; // whole wave leaves; no workgroup barrier anywhere in this kernel
+        if (!VI && w >= ntiles)
+            return; // whole wave leaves; no workgroup barrier in the kernels without a value dictionary
     }
     double * prod = prod_all[wave];
 
-    const int4 d0 = desc[w];
-    const int4 d1 = desc[w + 1];
+    // (VI: waves past the last tile read its descriptor and leave after the table barrier)
+    const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
+    const int4 d0 = desc[wd];
+    const int4 d1 = desc[wd + 1];
+    if (VI) {
+        // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
+        if (threadIdx.x < kMaxIndexedValues)
+            vtab[threadIdx.x] = vtable[threadIdx.x];
+        __syncthreads();
+        if (w >= ntiles)
+            return;
+    }
     const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
@@ -725,14 +775,14 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         }
         else if (C16 && (meta & kTileMetaShifted)) {
             const bool pattern = (meta & kTileMetaPattern) != 0;
-            tile_products_shifted<QUADS, X32>(prod, first_row_all[C16 ? wave : 0],
+            tile_products_shifted<QUADS, X32, VI>(prod, first_row_all[C16 ? wave : 0],
                                               pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
-                                              a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb);
+                                              a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb, vidx + kb, vtab);
         }
         else if (C16 && (meta & kTileMetaNarrow))
-            tile_products_narrow<QUADS, ABL>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
+            tile_products_narrow<QUADS, ABL, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);
         else
-            tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
+            tile_products_wide<QUADS, X32, VI>(prod, j + kb, a + kb, x, last, lane, vidx + kb, vtab);
         // same-wave LDS operations execute in order; the fences only pin the compiler
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2002,6 +2052,91 @@ __global__ __launch_bounds__(256) void hybrid_merge_kernel(
         out_col[dst] = coo_col[k];
         out_val[dst] = coo_val[k];
     }
+}
+
+// Value dictionary, plan time.  value_dict_insert_kernel: every distinct bit pattern among the n values goes
+// into an open-addressing table of kDictSlots 64-bit keys (kDictEmpty = free); state[0] counts the distinct
+// values, state[1] is raised when there are more than `limit` (or a value equals the free marker) and
+// everybody stops.  Almost every probe ends on its first load: a matrix that qualifies has few values.
+constexpr int kDictSlots = 1024;
+constexpr unsigned long long kDictEmpty = 0x7FF8DEADBEEF0001ull; // a NaN payload nobody stores
+
+__global__ __launch_bounds__(256) void value_dict_insert_kernel(
+    long long n, const double * __restrict__ a, unsigned long long * __restrict__ keys, int * __restrict__ state, int limit)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        if ((k & 0xFFF) == 0 && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return;
+        const unsigned long long key = (unsigned long long) __double_as_longlong(a[k]);
+        if (key == kDictEmpty) {
+            atomicOr(state + 1, 1);
+            return;
+        }
+        unsigned long long h = key * 0x9E3779B97F4A7C15ull;
+        unsigned slot = (unsigned) (h >> 54) & (kDictSlots - 1);
+        for (int probe = 0; probe < kDictSlots; ++probe, slot = (slot + 1) & (kDictSlots - 1)) {
+            unsigned long long cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == key)
+                break;
+            if (cur == kDictEmpty) {
+                cur = atomicCAS(keys + slot, kDictEmpty, key);
+                if (cur == kDictEmpty) {
+                    if (atomicAdd(state, 1) + 1 > limit)
+                        atomicOr(state + 1, 1);
+                    break;
+                }
+                if (cur == key)
+                    break;
+            }
+        }
+    }
+}
+
+// value_index_kernel: idx[k] = position of a[k] in the dictionary `table` (nvalues bit patterns, ascending as
+// unsigned 64-bit integers); state[1] is raised if a value is not in it (the array changed under the plan).
+__global__ __launch_bounds__(256) void value_index_kernel(
+    long long n, const double * __restrict__ a, const unsigned long long * __restrict__ table, int nvalues,
+    uint8_t * __restrict__ idx, int * __restrict__ state)
+{
+    __shared__ unsigned long long t[kMaxIndexedValues];
+    if (threadIdx.x < kMaxIndexedValues)
+        t[threadIdx.x] = threadIdx.x < (unsigned) nvalues ? table[threadIdx.x] : ~0ull;
+    __syncthreads();
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        const unsigned long long key = (unsigned long long) __double_as_longlong(a[k]);
+        int lo = 0, hi = nvalues - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (t[lo] != key)
+            atomicOr(state + 1, 1);
+        idx[k] = (uint8_t) lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void value_checksum_kernel(
+    long long n, const double * __restrict__ a, unsigned long long * __restrict__ out)
+{
+    const long long stride = (long long) gridDim.x * 256;
+    unsigned long long h = 0;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        unsigned long long t = (unsigned long long) k * 0x9E3779B97F4A7C15ull ^ (unsigned long long) __double_as_longlong(a[k]);
+        t ^= t >> 29;
+        t *= 0xBF58476D1CE4E5B9ull;
+        t ^= t >> 32;
+        h += t;
+    }
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1)
+        h += __shfl_xor(h, d);
+    if ((int) __lane_id() == 0)
+        atomicAdd(out, h);
 }
 
 __global__ __launch_bounds__(256) void column_checksum_kernel(

@@ -27,6 +27,7 @@ FLAG_NO_COLUMN_PANELS = 0x1000
 FLAG_VERIFY_PLAN = 0x8000
 FLAG_NO_BALANCED_TILES = 0x40000
 FLAG_NO_RUN_EVENTS = 0x80000
+FLAG_NO_VALUE_INDEX = 0x100000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -62,6 +63,7 @@ SIGNATURES = {
     "spmv_hip_plan_verify": (C.c_int, [_vp, _vp, _vp]),
     "spmv_hip_plan_csr_repack": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_plan_csr_refresh_values": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_plan_csr_index_values": (C.c_int, [_vp, _vp, _vp]),
     "spmv_hip_plan_destroy": (None, [_vp]),
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -288,11 +290,11 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(20, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 20))
+        out = np.zeros(21, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 21))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
-                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced"]
+                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):
@@ -315,6 +317,11 @@ class CsrPlan:
     def verify(self, d_col, stream=0):
         """Raises SpmvHipError (ERR_STATE) if d_col no longer has the contents the plan was compressed from."""
         check(self.lib.spmv_hip_plan_verify(self.h, d_col, stream))
+
+    def index_values(self, d_val, stream=0):
+        """Value dictionary for matrices with at most 128 distinct values (a no-op otherwise).  The caller keeps
+        d_val unchanged while the plan lives, or calls refresh_values after changing it."""
+        check(self.lib.spmv_hip_plan_csr_index_values(self.h, d_val, stream))
 
     def refresh_values(self, d_row_ptr, d_col, d_val, stream=0):
         """Re-copy the values into the plan's column-panel copy (no-op without panels)."""

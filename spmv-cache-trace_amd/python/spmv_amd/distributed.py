@@ -100,6 +100,8 @@ class DistributedCsrSpmv:
             # column panels keep a snapshot of the values: this object holds the tensors it was taken
             # from (self._keep) for as long as the plan lives, so it cannot go stale
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            # ... and so does the value dictionary of a matrix with few distinct values (same lifetime argument)
+            plan.index_values(tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
         # The launch itself is one foreign call with everything resolved beforehand (device addresses, the
         # stream, the plan handle): a rank-local multiply of a partitioned matrix lasts 20-30 us, and ten

@@ -189,3 +189,133 @@ def test_hybrid_upload_is_one_fused_multiply(oracle):
         ctx.set_y(y0)
         ctx.run(2)
         assert_close(ctx.get_y(), want, scale, what="hybrid two launches")
+
+
+def test_value_dictionary_bit_identical_and_guarded(oracle):
+    """spmv_hip_plan_csr_index_values: matrices with at most 128 distinct values stream one byte per entry and take
+    the double from a table.  Same bits as without; -0.0 / 0.0 and NaN payloads stay distinct; 129 values -> no
+    dictionary; a changed value array is found (ERR_STATE) unless refresh_values follows the change; the context
+    API builds the dictionary by itself for CSR, COO, ELLPACK and hybrid uploads."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(77)
+
+    def run(rows, cols, p, c, v, x, y0, index=True, flags=0):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+        tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        if index:
+            plan.index_values(tv.data_ptr(), stream)
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return ty.cpu().numpy(), plan.info(), (plan, tp, tc, tv, tx)
+
+    special = np.array([0.0, -0.0, 1.0, -1.0, 4.0, 1e-300, -2.5, np.inf, 3.0, 0.5])
+    for name, gen, nvals in (("poisson", lambda: synth.poisson2d(200), 2),
+                             ("band, 10 special values", lambda: synth.banded(30000, [-700, -300, -1, 0, 1, 500], seed=2), 10),
+                             ("random columns, 128 values", lambda: synth.random_uniform(20000, 20000, 6, seed=5), 128),
+                             ("random columns, 129 values", lambda: synth.random_uniform(20000, 20000, 6, seed=6), 129)):
+        rows, cols, p, c, v = gen()
+        if name != "poisson":
+            pool = special if nvals == 10 else rng.uniform(-1, 1, size=nvals)
+            v = pool[rng.integers(0, len(pool), size=len(v))]
+            v[:len(pool)] = pool  # every value occurs
+        x = synth.x_vector(cols, seed=3)
+        if nvals == 10:
+            x = np.abs(x) + 0.5  # inf * x stays inf: no NaN from inf - inf in a row with one infinite entry ... mostly
+        y0 = synth.x_vector(rows, seed=4)
+        got, info, keep = run(rows, cols, p, c, v, x, y0)
+        ref, info0, _ = run(rows, cols, p, c, v, x, y0, index=False)
+        assert info["indexed_values"] == (nvals if nvals <= 128 else 0), (name, info)
+        assert info0["indexed_values"] == 0
+        if nvals <= 128:
+            assert info["streamed_bytes"] < info0["streamed_bytes"]
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), name  # NaN-safe bit comparison
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) or name.startswith("random"), name
+        plan, tp, tc, tv, tx = keep
+        if nvals == 2:
+            # values changed in place without telling the plan: found on request (VERIFY_PLAN) ...
+            plan2 = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_VERIFY_PLAN)
+            plan2.compress(tc.data_ptr(), stream)
+            plan2.index_values(tv.data_ptr(), stream)
+            ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+            plan2.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            tv[5] = 7.25
+            with pytest.raises(capi.SpmvHipError) as e:
+                plan2.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            assert e.value.code == capi.ERR_STATE
+            # ... and brought up to date by refresh_values (three values now)
+            plan2.refresh_values(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+            assert plan2.info()["indexed_values"] == 3
+            ty.zero_()
+            plan2.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            torch.cuda.synchronize()
+            v2 = v.copy()
+            v2[5] = 7.25
+            assert_bitexact(ty.cpu().numpy(), oracle.csr_spmv(rows, p, c, v2, x, num_threads=4), "after refresh_values")
+            plan2.close()
+        plan.close()
+    # the context API: dictionary for every format, same y as the oracle
+    rows, cols, p, c, v = synth.poisson2d(150)
+    x = synth.x_vector(cols, seed=9)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    with capi.Context(0) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.run()
+        assert_bitexact(ctx.get_y(), want, "ctx csr with dictionary")
+        assert ctx.info()["streamed_bytes"] < 6 * len(v) + 24 * rows
+        ctx.upload_coo(rows, cols, i - 1, j - 1, a)
+        ctx.set_x(x)
+        ctx.run()
+        assert_bitexact(ctx.get_y(), want, "ctx coo with dictionary")
+        rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
+        ctx.upload_ell(rows, cols, L, ec, ev)
+        ctx.set_x(x)
+        ctx.run()
+        assert_bitexact(ctx.get_y(), oracle.ell_spmv(rows, L, ec, ev, x), "ctx ell with dictionary (padding zeros are values too)")
+    with capi.Context(0, flags=capi.FLAG_NO_VALUE_INDEX) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        assert ctx.info()["streamed_bytes"] > 8 * len(v)
+
+
+def test_value_dictionary_on_short_row_stencils_bit_identical(oracle):
+    """Shifted tiles with a value dictionary on stencils and bands whose tiles have 33 ... 128 rows, at the matrix
+    boundaries, with 64- and 128-row tiles, with and without x windows: the oracle's bits every time."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    cases = [("poisson 5-pt 300^2", lambda: synth.poisson2d(300)), ("poisson 5-pt 67^2", lambda: synth.poisson2d(67)),
+             ("tridiagonal", lambda: synth.banded(50000, [-1, 0, 1], seed=1)), ("diagonal", lambda: synth.banded(30000, [0], seed=2)),
+             ("7-point 40^3", lambda: synth.banded(64000, [-1600, -40, -1, 0, 1, 40, 1600], seed=3)),
+             ("8 diagonals", lambda: synth.banded(40000, [-900, -500, -200, -1, 0, 1, 300, 800], seed=4)),
+             ("9 diagonals (not staged)", lambda: synth.banded(40000, [-900, -500, -200, -1, 0, 1, 300, 800, 1100], seed=5)),
+             ("upper bidiagonal, x ends with the last run", lambda: synth.banded(20000, [0, 1], seed=6))]
+    vals = np.array([-1.0, 4.0, 0.5, -0.25, 2.0, 1e-3, -7.0])
+    rng = np.random.default_rng(5)
+    for name, gen in cases:
+        rows, cols, p, c, v = gen()
+        v = vals[rng.integers(0, len(vals), size=len(v))]
+        x = synth.x_vector(cols, seed=3)
+        y0 = synth.x_vector(rows, seed=4)
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+        tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+        out = {}
+        for flags in (capi.FLAG_ROWS128, capi.FLAG_ROWS64, capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW):
+            plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+            plan.compress(tc.data_ptr(), stream)
+            plan.index_values(tv.data_ptr(), stream)
+            ty = torch.from_numpy(y0.copy()).to(dev)
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            torch.cuda.synchronize()
+            out[flags] = (ty.cpu().numpy(), plan.info())
+            plan.close()
+        for flags, (got, info) in out.items():
+            assert_bitexact(got, want, "%s flags %x (dictionary %d)" % (name, flags, info["indexed_values"]))
+        assert out[capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW][1]["indexed_values"] == len(vals), name

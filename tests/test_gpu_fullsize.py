@@ -33,6 +33,7 @@ def _plan_multiply(A, x, compress=True, flags=0, runs=1, y0=None):
     if compress:
         plan.compress(tc.data_ptr(), stream)
         plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
     ty = torch.zeros(A.rows, dtype=torch.float64, device=dev) if y0 is None else torch.from_numpy(y0).to(dev)
     for _ in range(runs):
         plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
@@ -55,8 +56,9 @@ def test_poisson4096_compressed_plan_whole_vector_bitexact(oracle):
     assert info["shifted_tiles"] > 0.9 * info["row_blocks"], info
     assert info["narrow_tiles"] == info["row_blocks"] and info["panel_tiles"] == 0
     assert info["shifted_entries"] > 0.9 * A.stored
-    # the tile classes stream less than the algorithmic bytes (8 instead of 12 B per entry, no row_ptr)
-    assert info["streamed_bytes"] < 0.8 * synth.csr_bytes(A.rows, A.cols, A.stored)
+    assert info["indexed_values"] == 2  # the stencil's two values, -1 and 4: one byte per entry instead of eight
+    # the tile classes stream less than the algorithmic bytes (1 instead of 12 B per entry, no row_ptr)
+    assert info["streamed_bytes"] < 0.4 * synth.csr_bytes(A.rows, A.cols, A.stored)
     want = oracle.csr_spmv(A.rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS)
     assert_bitexact(y, want, "poisson 4096^2, compressed plan")
     # and twice more on top (y += A x accumulates)
