@@ -598,7 +598,8 @@ def main():
                            "workgroups": info["workgroups"], "tiles": info["row_blocks"],
                            "tiles_with_16bit_columns": info["narrow_tiles"], "uniform_tiles": info["uniform_tiles"],
                            "shifted_tiles": info["shifted_tiles"], "tiles_with_x_window": info["xwin_tiles"],
-                           "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"]})
+                           "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"],
+                           "balanced_tiles": bool(info["balanced"]), "value_dictionary_size": info["indexed_values"]})
         else:
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],
@@ -620,6 +621,8 @@ def main():
             roofline["share_of_entries_not_reading_column_index"] = round(info["shifted_entries"] / local_nnz, 4)
             roofline["share_of_entries_with_16bit_columns"] = round(info["narrow_entries"] / local_nnz, 4)
             roofline["share_of_rows_not_reading_row_ptr"] = round(info["uniform_rows"] / max(1, local_rows), 4)
+            # > 0: the matrix has that many distinct values and the kernel streams ONE byte per entry instead of eight
+            roofline["value_dictionary_size"] = info["indexed_values"]
         out = {
             "metric": "spmv_%s_gflops" % fmt, "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

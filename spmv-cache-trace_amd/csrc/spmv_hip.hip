@@ -998,7 +998,7 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
         || (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles);
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
         || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
-        || (pl->flags & (SPMV_HIP_FLAG_NO_VALUE_INDEX | SPMV_HIP_FLAG_XCD_REMAP)))
+        || (pl->flags & SPMV_HIP_FLAG_NO_VALUE_INDEX))
         return pl->inner ? SPMV_HIP_OK : plan_account(pl, pl->d_col16 != nullptr);
     if (!d_value)
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
@@ -1229,11 +1229,16 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
 #endif
             else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
-            } else if (c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a) {
+            } else if (c16 && x32 && pl->nvalues > 0 && pl->values_from == a) {
                 // the default kernel with the value dictionary: one byte per entry instead of eight
-                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
-                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
-                                   spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
+                if (xcd)
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, true, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
+                else
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
             }
