@@ -465,13 +465,14 @@ __device__ __forceinline__ void tile_products_shifted(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    vals.resolve(vtab);
     const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
+    // the x gathers depend on the descriptor and the first row only: all of them are issued before anything
+    // waits for the value stream (with a value dictionary the table look-ups below need the index loads back)
+    double xg[QUADS][4];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         const int o = 256 * q + 4 * lane;
         if (o <= last) {
-            unsigned c[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // entries in front of the tile (they share its first quad) are multiplied and never
@@ -479,15 +480,18 @@ __device__ __forceinline__ void tile_products_shifted(
                 const int ti = o + i - lead;
                 const unsigned t = ti > 0 ? (unsigned) ti : 0u;
                 const unsigned r = (t * magic) >> 22;
-                c[i] = min(tab[t - r * (unsigned) len] + r, limit);
+                xg[q][i] = gather_x<X32>(x, (int) min(tab[t - r * (unsigned) len] + r, limit));
             }
-            const double q0 = vals.va[q].x * gather_x<X32>(x, (int) c[0]);
-            const double q1 = vals.va[q].y * gather_x<X32>(x, (int) c[1]);
-            const double q2 = vals.vb[q].x * gather_x<X32>(x, (int) c[2]);
-            const double q3 = vals.vb[q].y * gather_x<X32>(x, (int) c[3]);
+        }
+    }
+    vals.resolve(vtab);
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
             v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
+            dst[0] = v2d{vals.va[q].x * xg[q][0], vals.va[q].y * xg[q][1]};
+            dst[1] = v2d{vals.vb[q].x * xg[q][2], vals.vb[q].y * xg[q][3]};
         }
     }
 }
@@ -653,6 +657,10 @@ struct PanelInfo {
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
+#ifndef SPMV_VI_TPW
+#define SPMV_VI_TPW 4
+#endif
+constexpr int kValueIndexTilesPerWave = SPMV_VI_TPW; // tiles one wave of the value-dictionary kernel works through
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
@@ -665,6 +673,10 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     // different ones (a partitioned multiply whose previous result is still being gathered); every
     // row is read and written by the same lane, so the in-place case needs no ordering.
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
+    // tiles per wave: with a value dictionary the launch is bound by the latency of a tile's dependent round
+    // trips (descriptor -> streams -> x), and taking four consecutive tiles per wave removes the first of them
+    // from three tiles out of four
+    constexpr int TPW = (VI && !XCD) ? kValueIndexTilesPerWave : 1;
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             return;
         y = y_arg - (size_t) pk * (size_t) pinfo.rows; // virtual row v of panel pk is row v - pk * rows
     } else {
-        w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
+        w = ((XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave) * TPW;
         if (!VI && w >= ntiles)
             return; // whole wave leaves; no workgroup barrier in the kernels without a value dictionary
     }
@@ -690,8 +702,16 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 
     // (VI: waves past the last tile read its descriptor and leave after the table barrier)
     const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
-    const int4 d0 = desc[wd];
-    const int4 d1 = desc[wd + 1];
+    int4 d0s = make_int4(0, 0, 0, 0), d1s = d0s, dd = d0s;
+    if (TPW == 1) {
+        d0s = desc[wd];
+        d1s = desc[wd + 1];
+    } else {
+        // TPW consecutive tiles per wave: lane t holds the descriptor of tile w + t (one vector load for all of
+        // them), so only the first tile of a wave waits for a descriptor round trip
+        const int wl = w + (lane < TPW ? lane : TPW); // lanes past TPW repeat the last one: 80 bytes, one request
+        dd = desc[wl < ntiles ? wl : ntiles];
+    }
     if (VI) {
         // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
         if (threadIdx.x < kMaxIndexedValues)
@@ -700,12 +720,23 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         if (w >= ntiles)
             return;
     }
+#pragma unroll 1
+    for (int t = 0; t < TPW; ++t) {
+    if (TPW > 1 && w + t >= ntiles)
+        break;
+    int4 d0 = d0s, d1 = d1s;
+    if (TPW > 1) {
+        d0 = make_int4(__builtin_amdgcn_readlane(dd.x, t), __builtin_amdgcn_readlane(dd.y, t), __builtin_amdgcn_readlane(dd.z, t),
+                       __builtin_amdgcn_readlane(dd.w, t));
+        d1.x = __builtin_amdgcn_readlane(dd.x, t + 1);
+        d1.y = __builtin_amdgcn_readlane(dd.y, t + 1);
+    }
     const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
     const int meta = __builtin_amdgcn_readfirstlane(d0.z);
     if (C16 && (meta & kTileMetaBlockWin))
-        return; // done by csr_blockwin_kernel (second launch of the same multiply)
+        continue; // done by csr_blockwin_kernel (second launch of the same multiply)
     const int maxlen = meta & 0xFFFF;
     const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
     const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
@@ -752,10 +783,10 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (!PANELS)
                 yvB = yin_t[rowB];
         }
+        const int last = (k1 - 1 - kb) & ~3;
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
-        const int last = (k1 - 1 - kb) & ~3;
         if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
             tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0],
                                       reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]),
@@ -884,6 +915,11 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 y[r0] = y_in[r0] + z;
         }
     }
+    // the next tile of this wave reuses the LDS slices: its writes come after this tile's reads (one wave, in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } // tiles of this wave
 }
 
 // ---------------------------------------------------------------------------------
