@@ -99,6 +99,10 @@ extern "C" {
                                              whole region themselves (bench.py); the Kernel adapters keep the events */
 #define SPMV_HIP_FLAG_NO_VALUE_INDEX 0x100000u /* never build a value dictionary (spmv_hip_plan_csr_index_values is a no-op; the
                                               context does not build one for its uploads) */
+#define SPMV_HIP_FLAG_PEER_GATHER 0x200000u /* spmv_hip_create_multi: gather the y slots with remote stores instead of RCCL: after
+                                             its multiply every device runs one kernel that writes its slot into the
+                                             other devices' y over xGMI (peer access must be available between all
+                                             devices; librccl.so is then never loaded).  Same result, bit for bit. */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -133,7 +137,12 @@ void spmv_hip_destroy(spmv_hip_ctx *ctx);
  * Only CSR can be uploaded (the other upload_* return SPMV_HIP_ERR_STATE), spmv_hip_set_stream is
  * refused.  librccl.so is loaded at run time, and only when num_gpus > 1 (or SPMV_HIP_FORCE_RCCL=1
  * is set, which runs the collective with one device too); num_gpus = 1 is an ordinary context with
- * the same calling sequence. */
+ * the same calling sequence.
+ * With SPMV_HIP_FLAG_PEER_GATHER the gather is done without RCCL: every device pushes its slot into the other
+ * devices' y with one kernel of remote stores (one copy per xGMI link); y is complete on every device after
+ * spmv_hip_sync.  Under that flag the environment variable SPMV_HIP_SHARE_DEVICES=1 lets num_gpus exceed the
+ * number of visible devices (part g then runs on device g mod visible): a rehearsal of the G-way partition,
+ * slots and gather on a smaller machine -- the arithmetic is the same, the timing means nothing. */
 int spmv_hip_create_multi(spmv_hip_ctx **ctx, int num_gpus, unsigned flags);
 
 /* Enqueue everything this context does from now on on the caller's `stream` (a hipStream_t on the

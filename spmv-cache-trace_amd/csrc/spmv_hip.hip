@@ -60,7 +60,8 @@ namespace {
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
-    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX
+    SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
+    SPMV_HIP_FLAG_PEER_GATHER
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -191,6 +192,7 @@ struct spmv_hip_ctx {
     std::vector<double *> yfull;
     std::vector<hipEvent_t> ev_gather; // recorded after the all-gather on each part's stream
     int32_t chunk = 0;
+    bool peer_gather = false; // SPMV_HIP_FLAG_PEER_GATHER: slots are pushed to the other devices by a kernel, no RCCL
     void * rccl_lib = nullptr;
     std::vector<ncclComm_t> comms;
     ncclResult_t (*p_all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -2172,6 +2174,9 @@ int multi_set_x(spmv_hip_ctx * c, const double * x)
 
 int multi_set_y(spmv_hip_ctx * c, const double * y)
 {
+    int rc0 = multi_sync(c); // a peer's push of an earlier run may still be writing into the vectors replaced here
+    if (rc0 != 0)
+        return rc0;
     for (size_t g = 0; g < c->parts.size(); ++g) { // every device gets the whole y, as after a gather
         spmv_hip_ctx * part = c->parts[g];
         HIP_TRY(hipSetDevice(part->device));
@@ -2184,11 +2189,91 @@ int multi_set_y(spmv_hip_ctx * c, const double * y)
 
 int multi_get_y(spmv_hip_ctx * c, double * y)
 {
+    if (c->peer_gather) { // device 0's y is complete once every OTHER device's push has finished
+        int rc0 = multi_sync(c);
+        if (rc0 != 0)
+            return rc0;
+    }
     spmv_hip_ctx * part = c->parts[0];
     HIP_TRY(hipSetDevice(part->device));
     if (c->rows > 0)
         HIP_TRY(hipMemcpyAsync(y, c->yfull[0], (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, part->stream));
     HIP_TRY(hipStreamSynchronize(part->stream));
+    return SPMV_HIP_OK;
+}
+
+// SPMV_HIP_FLAG_PEER_GATHER: the all-gather as remote stores.  Device g reads its slot once and writes it into
+// slot g of up to kPeerFanout other devices' y (coalesced stores that leave over the xGMI link to each peer: on a
+// fully connected node all seven links of the device carry one copy each, which is what a direct all-gather
+// over point-to-point links amounts to).  One launch per device and run; nothing is received by a kernel --
+// the stores of the peers land in memory this device does not touch until the streams have been synchronised.
+constexpr int kPeerFanout = 8;
+struct PeerTargets {
+    double * dst[kPeerFanout];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void peer_push_kernel(const double * __restrict__ src, PeerTargets t, long long n)
+{
+    // a slot starts at g * chunk doubles: 8-byte aligned only, hence one double per lane (a wave still writes
+    // 512 contiguous bytes per store instruction)
+    const long long stride = (long long) gridDim.x * 256;
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double v = src[i];
+#pragma unroll
+        for (int k = 0; k < kPeerFanout; ++k)
+            if (k < t.n)
+                t.dst[k][i] = v;
+    }
+}
+
+int multi_peer_gather(spmv_hip_ctx * c)
+{
+    const int G = (int) c->parts.size();
+    const size_t chunk = (size_t) c->chunk;
+    const long long pairs = (long long) chunk;
+    if (pairs == 0)
+        return SPMV_HIP_OK;
+    for (int g = 0; g < G; ++g) {
+        spmv_hip_ctx * part = c->parts[(size_t) g];
+        HIP_TRY(hipSetDevice(part->device));
+        const unsigned blocks = (unsigned) std::min<long long>((pairs + 255) / 256, 8ll * cu_count());
+        for (int h0 = 0; h0 < G; h0 += kPeerFanout) {
+            PeerTargets t;
+            t.n = 0;
+            for (int h = h0; h < G && h < h0 + kPeerFanout; ++h)
+                if (h != g)
+                    t.dst[t.n++] = c->yfull[(size_t) h] + (size_t) g * chunk;
+            for (int k = t.n; k < kPeerFanout; ++k)
+                t.dst[k] = nullptr;
+            if (t.n > 0)
+                hipLaunchKernelGGL(peer_push_kernel, dim3(blocks), dim3(256), 0, part->stream,
+                                   c->yfull[(size_t) g] + (size_t) g * chunk, t, pairs);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return SPMV_HIP_OK;
+}
+
+int multi_enable_peers(spmv_hip_ctx * c)
+{
+    const int G = (int) c->parts.size();
+    for (int g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(c->parts[(size_t) g]->device));
+        for (int h = 0; h < G; ++h) {
+            const int dg = c->parts[(size_t) g]->device, dh = c->parts[(size_t) h]->device;
+            if (dg == dh)
+                continue;
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, dg, dh));
+            if (!can)
+                return fail(SPMV_HIP_ERR_STATE, "SPMV_HIP_FLAG_PEER_GATHER: a device cannot access a peer's memory");
+            const hipError_t e = hipDeviceEnablePeerAccess(dh, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                return fail_hip(e, "hipDeviceEnablePeerAccess");
+            (void) hipGetLastError();
+        }
+    }
     return SPMV_HIP_OK;
 }
 
@@ -2200,7 +2285,11 @@ int multi_run(spmv_hip_ctx * c)
         if (rc != 0)
             return rc;
     }
-    if (!c->comms.empty()) {
+    if (c->peer_gather) {
+        int rc = multi_peer_gather(c);
+        if (rc != 0)
+            return rc;
+    } else if (!c->comms.empty()) {
         // the one collective of the path: every device sends its slot and receives the others', in place
         ncclResult_t r = c->p_group_start();
         if (r != ncclSuccess)
@@ -2265,20 +2354,25 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
         (void) hipGetLastError();
         return fail(SPMV_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     }
-    if (num_gpus < 1 || num_gpus > n)
-        return fail(SPMV_HIP_ERR_INVALID, "num_gpus must be between 1 and the number of visible devices");
     if (flags & ~kKnownFlags)
         return fail(SPMV_HIP_ERR_INVALID, "unknown flag bits");
+    // SPMV_HIP_SHARE_DEVICES=1 (rehearsals on fewer devices than parts): part g runs on device g mod visible.
+    // Only with the peer gather -- RCCL refuses two ranks on one device.
+    const char * share_env = std::getenv("SPMV_HIP_SHARE_DEVICES");
+    const bool share = share_env && share_env[0] == '1' && (flags & SPMV_HIP_FLAG_PEER_GATHER);
+    if (num_gpus < 1 || (num_gpus > n && !share) || num_gpus > 64)
+        return fail(SPMV_HIP_ERR_INVALID, "num_gpus must be between 1 and the number of visible devices");
     spmv_hip_ctx * c = new (std::nothrow) spmv_hip_ctx;
     if (!c)
         return fail(SPMV_HIP_ERR_ALLOC, "ctx allocation failed");
     c->multi = true;
     c->flags = flags;
+    c->peer_gather = (flags & SPMV_HIP_FLAG_PEER_GATHER) != 0;
     c->yfull.assign((size_t) num_gpus, nullptr);
     int rc = SPMV_HIP_OK;
     for (int g = 0; g < num_gpus && rc == SPMV_HIP_OK; ++g) {
         spmv_hip_ctx * part = nullptr;
-        rc = spmv_hip_create(&part, g, flags);
+        rc = spmv_hip_create(&part, g % n, flags);
         if (rc == SPMV_HIP_OK) {
             c->parts.push_back(part);
             hipEvent_t ev = nullptr;
@@ -2288,7 +2382,9 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
         }
     }
     const char * force = std::getenv("SPMV_HIP_FORCE_RCCL");
-    if (rc == SPMV_HIP_OK && (num_gpus > 1 || (force && force[0] == '1')))
+    if (rc == SPMV_HIP_OK && c->peer_gather)
+        rc = multi_enable_peers(c);
+    else if (rc == SPMV_HIP_OK && (num_gpus > 1 || (force && force[0] == '1')))
         rc = multi_load_rccl(c, num_gpus);
     if (rc != SPMV_HIP_OK) {
         std::string const keep = g_last_error;

@@ -77,6 +77,7 @@ enum Key
     key_expand_symmetric,
     key_matrix_cache,
     key_exact_order,
+    key_peer_gather,
     key_threads,
     key_check,
     key_synthetic,
@@ -160,6 +161,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case key_expand_symmetric: a.spmv.expand_symmetric = true; break;
     case key_matrix_cache: setenv("SPMV_MATRIX_CACHE", arg, 1); break;
     case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
+    case key_peer_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PEER_GATHER; break;
     case key_threads:
         if (!parse_count(arg, n) || n < 1 || n > 4096)
             argp_error(state, "threads: expected a positive integer");
@@ -273,6 +275,8 @@ int main(int argc, char ** argv)
         {"gpus", key_gpus, "G", 0,
          "hip-csr only: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
          "x replicated, one RCCL all-gather of y per run", 3},
+        {"peer-gather", key_peer_gather, nullptr, 0,
+         "with --gpus: gather y by remote stores over xGMI (one kernel per device) instead of RCCL", 3},
         {"csr-algorithm", key_csr_algorithm, "NAME", 0, "auto, scalar, vector, adaptive or wavetile", 3},
         {"lanes-per-row", key_lanes, "L", 0, "lanes per row of the vector algorithm (2..64, power of two)", 3},
         {"exact-order", key_exact_order, nullptr, 0, "sum every row left to right like the CPU loop (bit-exact)", 3},

@@ -337,3 +337,54 @@ def test_cli_synthetic_full_size_gpus_and_check():
                         "--check"], env=dict(os.environ, SPMV_DEVICE="hip"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout)["kernel"]["name"] == "hip-coo-spmv"
+    # --gpus 4 --peer-gather, the four row blocks rehearsed on this box's one device: the G > 1 flow end to end
+    r = subprocess.run([hostlib.CLI, "--synthetic", "kkt:30", "--spmv-format", "hip-csr", "--gpus", "4", "--peer-gather", "--threads", "1",
+                        "--profile", "3", "--x", "uniform", "--check"], env=dict(os.environ, SPMV_HIP_SHARE_DEVICES="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["kernel"]["device"]["gpus"] == 4 and d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts):
+    """The G > 1 flow of spmv_hip_create_multi -- ceil(rows / G) row blocks (src/matrix/csr-matrix.cpp:77-95), one
+    plan per block, y slots, the gather, set_y / get_y -- with every part on this box's one device
+    (SPMV_HIP_SHARE_DEVICES=1) and the gather done by the peer-push kernel (SPMV_HIP_FLAG_PEER_GATHER; RCCL cannot put
+    two ranks on a device).  Rows are not a multiple of G, the last block is short, one block is empty of entries."""
+    import os
+    rows, cols, p, c, v = synth.powerlaw(30011, 30011, seed=13)
+    # rows of the second block hold nothing: a part without entries
+    chunk = -(-rows // parts)
+    lens = np.diff(p).astype(np.int64)
+    if parts >= 3:
+        keep = np.ones(len(c), dtype=bool)
+        keep[p[chunk]:p[2 * chunk]] = False
+        lens[chunk:2 * chunk] = 0
+        c, v = c[keep], v[keep]
+        p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = synth.x_vector(cols, seed=5)
+    y0 = synth.x_vector(rows, seed=6)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=3)
+    scale = 3 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
+    try:
+        with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER) as ctx:
+            ctx.upload_csr(rows, cols, p, c, v)
+            ctx.set_x(x)
+            ctx.set_y(y0)
+            ctx.run(3)
+            assert_close(ctx.get_y(), want, scale, what="G=%d on one device" % parts)
+            info = ctx.info()
+            assert info["devices"] == parts and info["rows"] == rows and info["stored"] == len(c)
+            k_ns, g_ns = ctx.last_run_times()
+            assert k_ns > 0
+            # a second y replaces the first on every part; the next run starts from it everywhere
+            ctx.set_y(np.zeros(rows))
+            ctx.run()
+            assert_close(ctx.get_y(), oracle.csr_spmv(rows, p, c, v, x, num_threads=4), scale, what="after set_y")
+        with pytest.raises(capi.SpmvHipError) as e:  # sharing devices is a rehearsal of the peer gather only
+            capi.Context(num_gpus=capi.device_count() + 1)
+        assert e.value.code == capi.ERR_INVALID
+    finally:
+        os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
