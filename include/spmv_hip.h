@@ -103,6 +103,11 @@ extern "C" {
                                              its multiply every device runs one kernel that writes its slot into the
                                              other devices' y over xGMI (peer access must be available between all
                                              devices; librccl.so is then never loaded).  Same result, bit for bit. */
+#define SPMV_HIP_FLAG_BALANCE_ENTRIES 0x400000u /* spmv_hip_create_multi: cut the rows where the stored entries divide evenly
+                                             (boundary g = first row whose row_ptr reaches g * nnz / G) instead of
+                                             the reference's ceil(rows / G) rows per device; y slots are as long as
+                                             the longest block.  For matrices whose row lengths differ between the
+                                             top and the bottom (a KKT system's two row populations). */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;

@@ -61,7 +61,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
-    SPMV_HIP_FLAG_PEER_GATHER
+    SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -191,7 +191,9 @@ struct spmv_hip_ctx {
     std::vector<spmv_hip_ctx *> parts;
     std::vector<double *> yfull;
     std::vector<hipEvent_t> ev_gather; // recorded after the all-gather on each part's stream
-    int32_t chunk = 0;
+    int32_t chunk = 0;              // doubles per y slot: the longest row block
+    std::vector<int32_t> row_begin; // G + 1 block boundaries; block g sits at yfull[.] + g * chunk
+    bool packed = true;             // every block but the last fills its slot: yfull IS y (the static rule)
     bool peer_gather = false; // SPMV_HIP_FLAG_PEER_GATHER: slots are pushed to the other devices by a kernel, no RCCL
     void * rccl_lib = nullptr;
     std::vector<ncclComm_t> comms;
@@ -2115,6 +2117,8 @@ void multi_free_matrix(spmv_hip_ctx * c)
     c->format = 0;
     c->rows = c->cols = c->nnz = 0;
     c->chunk = 0;
+    c->row_begin.clear();
+    c->packed = true;
     c->timed = false;
 }
 
@@ -2127,8 +2131,32 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
         return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
     multi_free_matrix(c);
     const int G = (int) c->parts.size();
-    const int32_t chunk = std::max<int32_t>(1, (int32_t) (((long long) rows + G - 1) / G)); // ceil(rows / G): the reference's rule
-    c->chunk = chunk;
+    // block boundaries: the reference's static rule, chunk = ceil(rows / G) rows per device -- or, with
+    // SPMV_HIP_FLAG_BALANCE_ENTRIES, cuts on row boundaries at equal shares of the stored entries (SURVEY 8e:
+    // boundary g = the first row whose row_ptr reaches g * nnz / G), for matrices whose rows differ in length
+    c->row_begin.assign((size_t) G + 1, 0);
+    if (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) {
+        for (int g = 1; g < G; ++g) {
+            const int32_t target = (int32_t) (((long long) nnz * g) / G);
+            const int32_t r = (int32_t) (std::lower_bound(row_ptr, row_ptr + rows + 1, target) - row_ptr);
+            c->row_begin[(size_t) g] = std::max(c->row_begin[(size_t) g - 1], std::min(r, rows));
+        }
+    } else {
+        const long long per = std::max<long long>(1, ((long long) rows + G - 1) / G);
+        for (int g = 1; g < G; ++g)
+            c->row_begin[(size_t) g] = (int32_t) std::min<long long>(rows, g * per);
+    }
+    c->row_begin[(size_t) G] = rows;
+    int32_t chunk = 1;
+    for (int g = 0; g < G; ++g)
+        chunk = std::max(chunk, c->row_begin[(size_t) g + 1] - c->row_begin[(size_t) g]);
+    c->chunk = chunk; // slots are equally long (the all-gather wants equal counts); shorter blocks leave padding
+    c->packed = true;
+    for (int g = 0; g < G; ++g) {
+        const int32_t b = c->row_begin[(size_t) g], e = c->row_begin[(size_t) g + 1];
+        if (e > b && (b != (long long) g * chunk || (e - b != chunk && e != rows)))
+            c->packed = false;
+    }
     std::vector<int32_t> local_ptr;
     for (int g = 0; g < G; ++g) {
         spmv_hip_ctx * part = c->parts[(size_t) g];
@@ -2137,8 +2165,7 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
         const size_t ybytes = (size_t) chunk * (size_t) G * sizeof(double) + 64;
         HIP_TRY(hipMalloc((void **) &c->yfull[(size_t) g], ybytes));
         HIP_TRY(hipMemsetAsync(c->yfull[(size_t) g], 0, ybytes, part->stream));
-        const int32_t b = (int32_t) std::min<long long>(rows, (long long) g * chunk);
-        const int32_t e = (int32_t) std::min<long long>(rows, (long long) (g + 1) * chunk);
+        const int32_t b = c->row_begin[(size_t) g], e = c->row_begin[(size_t) g + 1];
         local_ptr.resize((size_t) (e - b) + 1);
         for (int32_t r = b; r <= e; ++r)
             local_ptr[(size_t) (r - b)] = row_ptr[r] - row_ptr[b];
@@ -2180,8 +2207,14 @@ int multi_set_y(spmv_hip_ctx * c, const double * y)
     for (size_t g = 0; g < c->parts.size(); ++g) { // every device gets the whole y, as after a gather
         spmv_hip_ctx * part = c->parts[g];
         HIP_TRY(hipSetDevice(part->device));
-        if (c->rows > 0)
+        if (c->rows > 0 && c->packed)
             HIP_TRY(hipMemcpyAsync(c->yfull[g], y, (size_t) c->rows * sizeof(double), hipMemcpyHostToDevice, part->stream));
+        for (size_t h = 0; h < c->parts.size() && !c->packed; ++h) { // block by block into the slots
+            const int32_t b = c->row_begin[h], e = c->row_begin[h + 1];
+            if (e > b)
+                HIP_TRY(hipMemcpyAsync(c->yfull[g] + h * (size_t) c->chunk, y + b, (size_t) (e - b) * sizeof(double), hipMemcpyHostToDevice,
+                                       part->stream));
+        }
         HIP_TRY(hipStreamSynchronize(part->stream));
     }
     return SPMV_HIP_OK;
@@ -2196,8 +2229,14 @@ int multi_get_y(spmv_hip_ctx * c, double * y)
     }
     spmv_hip_ctx * part = c->parts[0];
     HIP_TRY(hipSetDevice(part->device));
-    if (c->rows > 0)
+    if (c->rows > 0 && c->packed)
         HIP_TRY(hipMemcpyAsync(y, c->yfull[0], (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, part->stream));
+    for (size_t h = 0; h < c->parts.size() && !c->packed; ++h) {
+        const int32_t b = c->row_begin[h], e = c->row_begin[h + 1];
+        if (e > b)
+            HIP_TRY(hipMemcpyAsync(y + b, c->yfull[0] + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost,
+                                   part->stream));
+    }
     HIP_TRY(hipStreamSynchronize(part->stream));
     return SPMV_HIP_OK;
 }

@@ -78,6 +78,7 @@ enum Key
     key_matrix_cache,
     key_exact_order,
     key_peer_gather,
+    key_balance_entries,
     key_threads,
     key_check,
     key_synthetic,
@@ -162,6 +163,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case key_matrix_cache: setenv("SPMV_MATRIX_CACHE", arg, 1); break;
     case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
     case key_peer_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PEER_GATHER; break;
+    case key_balance_entries: a.spmv.hip_flags |= SPMV_HIP_FLAG_BALANCE_ENTRIES; break;
     case key_threads:
         if (!parse_count(arg, n) || n < 1 || n > 4096)
             argp_error(state, "threads: expected a positive integer");
@@ -275,6 +277,8 @@ int main(int argc, char ** argv)
         {"gpus", key_gpus, "G", 0,
          "hip-csr only: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
          "x replicated, one RCCL all-gather of y per run", 3},
+        {"balance-entries", key_balance_entries, nullptr, 0,
+         "with --gpus: cut the rows at equal shares of the stored entries instead of ceil(rows/G) rows per device", 3},
         {"peer-gather", key_peer_gather, nullptr, 0,
          "with --gpus: gather y by remote stores over xGMI (one kernel per device) instead of RCCL", 3},
         {"csr-algorithm", key_csr_algorithm, "NAME", 0, "auto, scalar, vector, adaptive or wavetile", 3},

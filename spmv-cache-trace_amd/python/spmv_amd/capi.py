@@ -29,6 +29,7 @@ FLAG_NO_BALANCED_TILES = 0x40000
 FLAG_NO_RUN_EVENTS = 0x80000
 FLAG_NO_VALUE_INDEX = 0x100000
 FLAG_PEER_GATHER = 0x200000
+FLAG_BALANCE_ENTRIES = 0x400000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

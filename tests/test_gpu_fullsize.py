@@ -346,12 +346,13 @@ def test_cli_synthetic_full_size_gpus_and_check():
     assert d["kernel"]["device"]["gpus"] == 4 and d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
 
 
-@pytest.mark.parametrize("parts", [2, 3, 8])
-def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts):
+@pytest.mark.parametrize("parts,balance", [(2, False), (3, False), (8, False), (3, True), (8, True)])
+def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, balance):
     """The G > 1 flow of spmv_hip_create_multi -- ceil(rows / G) row blocks (src/matrix/csr-matrix.cpp:77-95), one
     plan per block, y slots, the gather, set_y / get_y -- with every part on this box's one device
     (SPMV_HIP_SHARE_DEVICES=1) and the gather done by the peer-push kernel (SPMV_HIP_FLAG_PEER_GATHER; RCCL cannot put
-    two ranks on a device).  Rows are not a multiple of G, the last block is short, one block is empty of entries."""
+    two ranks on a device).  Rows are not a multiple of G, the last block is short, one block is empty of entries.
+    balance: SPMV_HIP_FLAG_BALANCE_ENTRIES, blocks of equal stored entries (unequal rows, padded y slots)."""
     import os
     rows, cols, p, c, v = synth.powerlaw(30011, 30011, seed=13)
     # rows of the second block hold nothing: a part without entries
@@ -369,12 +370,12 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts):
     scale = 3 * abs_products(rows, p, c, v, x) + np.abs(y0)
     os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
     try:
-        with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER) as ctx:
+        with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
             ctx.upload_csr(rows, cols, p, c, v)
             ctx.set_x(x)
             ctx.set_y(y0)
             ctx.run(3)
-            assert_close(ctx.get_y(), want, scale, what="G=%d on one device" % parts)
+            assert_close(ctx.get_y(), want, scale, what="G=%d on one device, balance=%s" % (parts, balance))
             info = ctx.info()
             assert info["devices"] == parts and info["rows"] == rows and info["stored"] == len(c)
             k_ns, g_ns = ctx.last_run_times()
