@@ -449,6 +449,9 @@ __device__ __forceinline__ void tile_products_narrow(
 // while t * len < 2^22 (t < 1024, len <= 512), with t * magic < 2^32.
 constexpr int kShiftedMaxLen = 128;
 
+#ifndef SPMV_VI_ABLATE
+#define SPMV_VI_ABLATE 0 // timing experiments only (tools/ablate.sh builds libraries with -DSPMV_VI_ABLATE=n)
+#endif
 template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_shifted(
     double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
@@ -480,7 +483,10 @@ __device__ __forceinline__ void tile_products_shifted(
                 const int ti = o + i - lead;
                 const unsigned t = ti > 0 ? (unsigned) ti : 0u;
                 const unsigned r = (t * magic) >> 22;
-                xg[q][i] = gather_x<X32>(x, (int) min(tab[t - r * (unsigned) len] + r, limit));
+                if (VI && (SPMV_VI_ABLATE & 1))
+                    xg[q][i] = gather_x<X32>(x, (int) ((tab[t - r * (unsigned) len] + r) & 15u)); // no x traffic
+                else
+                    xg[q][i] = gather_x<X32>(x, (int) min(tab[t - r * (unsigned) len] + r, limit));
             }
         }
     }
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             pe = pt[rowi + 1];
         }
         const double * yin_t = y_in + r0;
-        const double yv = PANELS ? 0.0 : yin_t[rowi]; // panels: the partial sums are added atomically
+        const double yv = (PANELS || (VI && (SPMV_VI_ABLATE & 2))) ? 0.0 : yin_t[rowi]; // panels: the partial sums are added atomically
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
         const bool second = nrows > kWave; // wave-uniform; implies one lane per row
         int psB = 0, peB = 0;
@@ -780,7 +786,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 psB = p[r0 + rowB];
                 peB = p[r0 + rowB + 1];
             }
-            if (!PANELS)
+            if (!PANELS && !(VI && (SPMV_VI_ABLATE & 2)))
                 yvB = yin_t[rowB];
         }
         const int last = (k1 - 1 - kb) & ~3;
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         const int s = ps - kb;
         const int e_row = pe - kb;
         double z;
-        if (ABL & 2) {
+        if ((ABL & 2) || (VI && (SPMV_VI_ABLATE & 4))) {
             z = prod[s];
         } else if (lanes_log2 == 0) { // short rows: one lane per row, the reference's order
             z = tile_row_sum<1>(prod, s, e_row, 0, maxlen);
@@ -837,15 +843,15 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
             }
         }
-        if (sub < nrows && part == 0) {
+        if (sub < nrows && part == 0 && !(VI && (SPMV_VI_ABLATE & 8) && lane > 0)) {
             if (PANELS)
                 unsafeAtomicAdd(yt + sub, z);
             else
                 yt[sub] = yv + z;
         }
         if (second) {
-            const double zB = (ABL & 2) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
-            if (lane + kWave < nrows) {
+            const double zB = ((ABL & 2) || (VI && (SPMV_VI_ABLATE & 4))) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
+            if (lane + kWave < nrows && !(VI && (SPMV_VI_ABLATE & 8))) {
                 if (PANELS)
                     unsafeAtomicAdd(yt + lane + kWave, zB);
                 else

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(PKG_ROOT, "libspmv_hip.so")
 EXPERIMENTS_LIB_PATH = os.path.join(PKG_ROOT, "libspmv_hip_experiments.so")
 if os.environ.get("SPMV_HIP_EXPERIMENTS") == "1":
     LIB_PATH = EXPERIMENTS_LIB_PATH
+elif os.environ.get("SPMV_HIP_EXPERIMENTS", "").endswith(".so"):  # an ablation build of tools/ablate.sh
+    LIB_PATH = os.path.abspath(os.environ["SPMV_HIP_EXPERIMENTS"])
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
 
 OK = 0
