@@ -502,6 +502,77 @@ __device__ __forceinline__ void tile_products_shifted(
     }
 }
 
+// A shifted tile whose rows are all equally long (the interior of a stencil), under a value dictionary: ONE LANE
+// PER ROW.  Row r of the tile has the columns first_row[pos] + r, so for a given pos the lanes of a wave read
+// x[first_row[pos] + lane]: 512 contiguous bytes, 8 accesses of the vector L1 -- where the entry-major layout of
+// tile_products_shifted (lane = four consecutive entries) lands the 64 lanes of every gather on all the
+// diagonals at once, ~35 different 64-byte pieces per instruction.  The counters of the value-dictionary launch
+// (71 M L1 accesses in 143 us: 0.85 per clock and CU, profiles/r02_prof_poisson_csr_vi_summary.md) say that this
+// look-up rate, not memory, was what it ran at.  first_row sits one entry per lane in a register and is
+// broadcast with v_readlane (len <= 64); the tile's index bytes go through the wave's LDS slice (two coalesced
+// dwords per lane in, the row's bytes out); the doubles come from the table and are added left to right from
+// +0.0: the reference's order, bit for bit.  Lanes own a second row 64 further on when the tile has more than 64.
+template <bool X32>
+__device__ __forceinline__ void tile_rows_uniform_indexed(
+    double * prod, const int32_t * __restrict__ first_row, int first_row_base,
+    const uint8_t * __restrict__ vit, const double * vtab, const double * __restrict__ x, int last, int lane,
+    int len, int lead, int nrows, bool second, double & zA, double & zB)
+{
+    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
+    unsigned * vw = reinterpret_cast<unsigned *>(prod);
+    unsigned vi[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int o = 256 * q + 4 * lane;
+        o = o < last ? o : last; // lanes past the tile's end re-read its last dword (and park it where nobody looks)
+        vi[q] = *reinterpret_cast<const unsigned *>(vit + o);
+    }
+    const int rowA = lane < nrows ? lane : nrows - 1;
+    const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
+    zA = 0.0;
+    zB = 0.0;
+    constexpr int CH = 5; // positions per round: a 5-point row in one go
+    double xa[CH], xb[CH];
+    // first round of gathers: they depend on first_row only and leave before the index bytes are back
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (i < len) { // wave-uniform
+            const int c = __builtin_amdgcn_readlane(fr, i);
+            xa[i] = gather_x<X32>(x, (SPMV_VI_ABLATE & 1) ? ((c + rowA) & 15) : c + rowA);
+            if (second)
+                xb[i] = gather_x<X32>(x, (SPMV_VI_ABLATE & 1) ? ((c + rowB) & 15) : c + rowB);
+        }
+    }
+    vw[lane] = vi[0];
+    vw[64 + lane] = vi[1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t * vA = reinterpret_cast<const uint8_t *>(prod) + lead + rowA * len;
+    const uint8_t * vB = reinterpret_cast<const uint8_t *>(prod) + lead + rowB * len;
+    for (int p0 = 0; p0 < len; p0 += CH) {
+        if (p0 > 0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (p0 + i < len) {
+                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
+                    xa[i] = gather_x<X32>(x, c + rowA);
+                    if (second)
+                        xb[i] = gather_x<X32>(x, c + rowB);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (p0 + i < len) {
+                zA += vtab[vA[p0 + i] & 0x7Fu] * xa[i];
+                if (second)
+                    zB += vtab[vB[p0 + i] & 0x7Fu] * xb[i];
+            }
+        }
+    }
+}
+
 // x staged through LDS (kernel variant XW > 0, tiles marked kTileMetaXWin): the tile's column
 // range [base, base + 64 * chunks) is read once with coalesced loads into the wave's window and the
 // products take x from there (ds_read_b64) instead of gathering it through the vector L1.  All
@@ -664,11 +735,14 @@ struct PanelInfo {
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
 #ifndef SPMV_VI_TPW
-#define SPMV_VI_TPW 4
+#define SPMV_VI_TPW 1
 #endif
 constexpr int kValueIndexTilesPerWave = SPMV_VI_TPW; // tiles one wave of the value-dictionary kernel works through
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
-__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
+#ifndef SPMV_VI_WAVES
+#define SPMV_VI_WAVES 8
+#endif
+__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_VI_WAVES : 8) : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
@@ -772,7 +846,10 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             pe = pt[rowi + 1];
         }
         const double * yin_t = y_in + r0;
-        const double yv = (PANELS || (VI && (SPMV_VI_ABLATE & 2))) ? 0.0 : yin_t[rowi]; // panels: the partial sums are added atomically
+        // (value-dictionary variant: y is read once and written once per launch -- non-temporal, to keep it out of
+        // the way of x in the caches: 143 -> 139 us)
+        const double yv = (PANELS || (VI && (SPMV_VI_ABLATE & 2))) ? 0.0 // panels: the partial sums are added atomically
+            : (VI ? __builtin_nontemporal_load(yin_t + rowi) : yin_t[rowi]);
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
         const bool second = nrows > kWave; // wave-uniform; implies one lane per row
         int psB = 0, peB = 0;
@@ -787,9 +864,25 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 peB = p[r0 + rowB + 1];
             }
             if (!PANELS && !(VI && (SPMV_VI_ABLATE & 2)))
-                yvB = yin_t[rowB];
+                yvB = VI ? __builtin_nontemporal_load(yin_t + rowB) : yin_t[rowB];
         }
         const int last = (k1 - 1 - kb) & ~3;
+        if (VI && C16 && TILE == 512 && !PANELS && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
+            && lanes_log2 == 0 && maxlen <= kWave) {
+            // equally long shifted rows under a value dictionary: a lane per row, nothing parked in LDS
+            const bool pattern = (meta & kTileMetaPattern) != 0;
+            double zA, zB;
+            tile_rows_uniform_indexed<X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
+                                           vidx + kb, vtab, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
+            if (lane < nrows && !((SPMV_VI_ABLATE & 8) && lane > 0))
+                __builtin_nontemporal_store(yv + zA, yt + lane);
+            if (second && lane + kWave < nrows && !(SPMV_VI_ABLATE & 8))
+                __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            continue;
+        }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
@@ -846,6 +939,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         if (sub < nrows && part == 0 && !(VI && (SPMV_VI_ABLATE & 8) && lane > 0)) {
             if (PANELS)
                 unsafeAtomicAdd(yt + sub, z);
+            else if (VI)
+                __builtin_nontemporal_store(yv + z, yt + sub);
             else
                 yt[sub] = yv + z;
         }
@@ -854,6 +949,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (lane + kWave < nrows && !(VI && (SPMV_VI_ABLATE & 8))) {
                 if (PANELS)
                     unsafeAtomicAdd(yt + lane + kWave, zB);
+                else if (VI)
+                    __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
                 else
                     yt[lane + kWave] = yvB + zB;
             }

@@ -296,7 +296,10 @@ def test_value_dictionary_on_short_row_stencils_bit_identical(oracle):
              ("7-point 40^3", lambda: synth.banded(64000, [-1600, -40, -1, 0, 1, 40, 1600], seed=3)),
              ("8 diagonals", lambda: synth.banded(40000, [-900, -500, -200, -1, 0, 1, 300, 800], seed=4)),
              ("9 diagonals (not staged)", lambda: synth.banded(40000, [-900, -500, -200, -1, 0, 1, 300, 800, 1100], seed=5)),
-             ("upper bidiagonal, x ends with the last run", lambda: synth.banded(20000, [0, 1], seed=6))]
+             ("upper bidiagonal, x ends with the last run", lambda: synth.banded(20000, [0, 1], seed=6)),
+             # one lane per row (EXACT_ORDER below) with rows longer than one round of gathers, and longer than a wave
+             ("27 diagonals", lambda: synth.banded(30000, sorted(set(int(o) for o in np.linspace(-1300, 1300, 27))), seed=7)),
+             ("70 diagonals", lambda: synth.banded(20000, list(range(-35, 35)), seed=8))]
     vals = np.array([-1.0, 4.0, 0.5, -0.25, 2.0, 1e-3, -7.0])
     rng = np.random.default_rng(5)
     for name, gen in cases:
@@ -307,7 +310,8 @@ def test_value_dictionary_on_short_row_stencils_bit_identical(oracle):
         want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
         tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
         out = {}
-        for flags in (capi.FLAG_ROWS128, capi.FLAG_ROWS64, capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW):
+        for flags in (capi.FLAG_ROWS128, capi.FLAG_ROWS64, capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW,
+                      capi.FLAG_EXACT_ORDER | capi.FLAG_NO_X_WINDOW):
             plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
             plan.compress(tc.data_ptr(), stream)
             plan.index_values(tv.data_ptr(), stream)

@@ -7,13 +7,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 if [ "$1" = build ]; then
     mkdir -p tools/ablate
-    for n in 1 2 4 8 15; do
+    for n in ${ABLATE_MASKS:-1 2 4 8 15}; do
         (cd spmv-cache-trace_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics \
             -I../include -DSPMV_HIP_EXPERIMENTS -DSPMV_VI_ABLATE=$n -shared csrc/spmv_hip.hip csrc/coo_sort.hip -o ../tools/ablate/ablate_$n.so) &
     done
     wait
 else
-    for n in 0 1 2 4 8 15; do
+    for n in 0 ${ABLATE_MASKS:-1 2 4 8 15}; do
         if [ $n = 0 ]; then export SPMV_HIP_EXPERIMENTS=0; else export SPMV_HIP_EXPERIMENTS=tools/ablate/ablate_$n.so; fi
         python3 bench.py --steps 100 --warmup 10 --no-reference-protocol --no-cpu-baseline "${@:2}" > gpurun_out/ablate_$n.log 2> gpurun_out/ablate_$n.err
         echo "ablate mask $n: $(python3 tools/jline.py gpurun_out/ablate_$n.log roofline.kernel_us)"
