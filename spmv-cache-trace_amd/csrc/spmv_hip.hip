@@ -1239,10 +1239,10 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, true, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
                                        pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
-                else // four consecutive tiles per wave, sixteen per workgroup
-                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3((unsigned) ((pl->ntiles + 4 * spmv::kValueIndexTilesPerWave - 1) / (4 * spmv::kValueIndexTilesPerWave))),
-                                       dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact,
-                                       pl->d_patterns, spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
+                else
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
             }

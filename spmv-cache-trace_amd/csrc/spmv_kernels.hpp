@@ -734,10 +734,6 @@ struct PanelInfo {
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
-#ifndef SPMV_VI_TPW
-#define SPMV_VI_TPW 1
-#endif
-constexpr int kValueIndexTilesPerWave = SPMV_VI_TPW; // tiles one wave of the value-dictionary kernel works through
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
 #ifndef SPMV_VI_WAVES
 #define SPMV_VI_WAVES 8
@@ -753,10 +749,6 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
     // different ones (a partitioned multiply whose previous result is still being gathered); every
     // row is read and written by the same lane, so the in-place case needs no ordering.
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
-    // tiles per wave: with a value dictionary the launch is bound by the latency of a tile's dependent round
-    // trips (descriptor -> streams -> x), and taking four consecutive tiles per wave removes the first of them
-    // from three tiles out of four
-    constexpr int TPW = (VI && !XCD) ? kValueIndexTilesPerWave : 1;
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
@@ -774,7 +766,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
             return;
         y = y_arg - (size_t) pk * (size_t) pinfo.rows; // virtual row v of panel pk is row v - pk * rows
     } else {
-        w = ((XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave) * TPW;
+        w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
         if (!VI && w >= ntiles)
             return; // whole wave leaves; no workgroup barrier in the kernels without a value dictionary
     }
@@ -782,16 +774,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
 
     // (VI: waves past the last tile read its descriptor and leave after the table barrier)
     const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
-    int4 d0s = make_int4(0, 0, 0, 0), d1s = d0s, dd = d0s;
-    if (TPW == 1) {
-        d0s = desc[wd];
-        d1s = desc[wd + 1];
-    } else {
-        // TPW consecutive tiles per wave: lane t holds the descriptor of tile w + t (one vector load for all of
-        // them), so only the first tile of a wave waits for a descriptor round trip
-        const int wl = w + (lane < TPW ? lane : TPW); // lanes past TPW repeat the last one: 80 bytes, one request
-        dd = desc[wl < ntiles ? wl : ntiles];
-    }
+    const int4 d0 = desc[wd];
+    const int4 d1 = desc[wd + 1];
     if (VI) {
         // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
         if (threadIdx.x < kMaxIndexedValues)
@@ -800,23 +784,12 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
         if (w >= ntiles)
             return;
     }
-#pragma unroll 1
-    for (int t = 0; t < TPW; ++t) {
-    if (TPW > 1 && w + t >= ntiles)
-        break;
-    int4 d0 = d0s, d1 = d1s;
-    if (TPW > 1) {
-        d0 = make_int4(__builtin_amdgcn_readlane(dd.x, t), __builtin_amdgcn_readlane(dd.y, t), __builtin_amdgcn_readlane(dd.z, t),
-                       __builtin_amdgcn_readlane(dd.w, t));
-        d1.x = __builtin_amdgcn_readlane(dd.x, t + 1);
-        d1.y = __builtin_amdgcn_readlane(dd.y, t + 1);
-    }
     const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
     const int meta = __builtin_amdgcn_readfirstlane(d0.z);
     if (C16 && (meta & kTileMetaBlockWin))
-        continue; // done by csr_blockwin_kernel (second launch of the same multiply)
+        return; // done by csr_blockwin_kernel (second launch of the same multiply)
     const int maxlen = meta & 0xFFFF;
     const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
     const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
@@ -878,10 +851,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
                 __builtin_nontemporal_store(yv + zA, yt + lane);
             if (second && lane + kWave < nrows && !(SPMV_VI_ABLATE & 8))
                 __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            continue;
+            return;
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
@@ -1018,11 +988,6 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_V
                 y[r0] = y_in[r0] + z;
         }
     }
-    // the next tile of this wave reuses the LDS slices: its writes come after this tile's reads (one wave, in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } // tiles of this wave
 }
 
 // ---------------------------------------------------------------------------------

@@ -321,5 +321,10 @@ def test_value_dictionary_on_short_row_stencils_bit_identical(oracle):
             out[flags] = (ty.cpu().numpy(), plan.info())
             plan.close()
         for flags, (got, info) in out.items():
-            assert_bitexact(got, want, "%s flags %x (dictionary %d)" % (name, flags, info["indexed_values"]))
+            what = "%s flags %x (dictionary %d)" % (name, flags, info["indexed_values"])
+            if "diagonals" in name and int(name.split()[0]) > 16 and not (flags & capi.FLAG_EXACT_ORDER):
+                # rows of more than 16 entries are summed by several lanes unless EXACT_ORDER asks for the reference's order
+                assert_close(got, want, abs_products(rows, p, c, v, x) + np.abs(y0), what=what)
+            else:
+                assert_bitexact(got, want, what)
         assert out[capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW][1]["indexed_values"] == len(vals), name
