@@ -735,10 +735,7 @@ struct PanelInfo {
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
-#ifndef SPMV_VI_WAVES
-#define SPMV_VI_WAVES 8
-#endif
-__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? (VI && !XCD ? SPMV_VI_WAVES : 8) : 4)) void csr_wavetile_kernel(
+__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
