@@ -6,6 +6,7 @@
 
 #include "spmv_hip.h"
 
+#include <chrono>
 #include <ostream>
 #include <sstream>
 #include <system_error>
@@ -386,8 +387,12 @@ protected:
           << ", \"streamed_bytes_per_run\": " << info[15] << ", \"gpus\": " << info[16]
           << ", \"last_run_device_ns\": " << device_ns;
         if (info[16] > 1 || options.num_gpus > 0)
-            o << ", \"last_run_all_gather_ns\": " << gather_ns
-              << ", \"partition\": \"rows/" << info[16] << " static chunks, x replicated, 1 in-place all-gather(y) per run\"";
+            o << ", \"last_run_all_gather_ns\": " << gather_ns << ", \"partition\": \""
+              << ((options.hip_flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) ? "row blocks of equal stored entries over " : "static chunks of ceil(rows/G) rows over ")
+              << info[16] << " devices, x replicated, 1 in-place all-gather(y) per run ("
+              << ((options.hip_flags & SPMV_HIP_FLAG_PEER_GATHER) ? "remote stores over xGMI" : "RCCL") << ")\"";
+        if (init_load_seconds > 0.0 || init_upload_seconds > 0.0)
+            o << ", \"init_seconds\": {\"load_and_convert\": " << init_load_seconds << ", \"upload_and_plan\": " << init_upload_seconds << "}";
         o << "}";
         return o;
     }
@@ -397,6 +402,7 @@ protected:
     spmv_hip_ctx * ctx = nullptr;
     aligned_vector<double> x, y;
     std::uint64_t device_ns = 0, gather_ns = 0;
+    double init_load_seconds = 0.0, init_upload_seconds = 0.0; // wall time of Kernel::init: file -> host arrays -> device + plan
     std::string prepare_error;
 };
 
@@ -406,14 +412,18 @@ public:
     using hip_kernel_base::hip_kernel_base;
     void init(TraceConfig const &, std::ostream & o, bool verbose) override
     {
+        auto const t0 = std::chrono::steady_clock::now();
         guarded_init(matrix_path, [&] {
             A = load_csr(matrix_path, options, o, verbose);
             x.assign((std::size_t) A.columns, 1.0);
             y.assign((std::size_t) A.rows, 0.0);
         });
+        auto const t1 = std::chrono::steady_clock::now();
         create_context();
         check(spmv_hip_upload_csr(ctx, A.rows, A.columns, A.row_ptr[(std::size_t) A.rows], A.row_ptr.data(),
                                   A.column_index.data(), A.value.data()), "upload_csr");
+        init_load_seconds = std::chrono::duration<double>(t1 - t0).count();
+        init_upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     }
     std::string name() const override { return "hip-csr-spmv"; }
     std::ostream & print(std::ostream & o) const override

@@ -9,6 +9,7 @@
 // counters are outside this engine and are refused with a message.
 #include "kernels/spmv-kernels.hpp"
 #include "kernels/triad-kernel.hpp"
+#include "matrix/matrix-market.hpp"
 #include "profile-kernel.hpp"
 #include "trace-config.hpp"
 #include "util/json-ostreambuf.hpp"
@@ -42,6 +43,7 @@ struct Arguments
     bool hip = false;
     std::size_t triad_entries = 0;
     std::string matrix_path;
+    std::string write_mtx; // --write-mtx: write the loaded (or generated) matrix to this file and stop
     std::string trace_config;
     int threads = 0;
     int profile = 0;
@@ -81,6 +83,7 @@ enum Key
     key_balance_entries,
     key_threads,
     key_check,
+    key_write_mtx,
     key_synthetic,
     key_x,
     key_gpus,
@@ -100,6 +103,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     long long n = 0;
     switch (key) {
     case key_matrix: a.matrix_path = arg; break;
+    case key_write_mtx: a.write_mtx = arg; break;
     case key_trace_config: a.trace_config = arg; break;
     case key_profile:
         if (!parse_count(arg, n) || n > 1000000000)
@@ -188,7 +192,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case ARGP_KEY_END:
         if (a.list_perf_events)
             break;
-        if (a.trace_config.empty() && a.threads == 0)
+        if (a.trace_config.empty() && a.threads == 0 && a.write_mtx.empty())
             argp_error(state, "Please specify --trace-config");
         break;
     default: return ARGP_ERR_UNKNOWN;
@@ -246,6 +250,9 @@ int main(int argc, char ** argv)
         {"flush-caches", key_flush_caches, nullptr, 0, "Flush CPU caches between each profiling run", 0},
         {"list-perf-events", key_list_perf_events, nullptr, 0, "Not available (libpfm4 is not part of this build)", 0},
         {"verbose", key_verbose, nullptr, 0, "be more verbose", 0},
+        {"write-mtx", key_write_mtx, "PATH", 0,
+         "Write the matrix (--matrix / --synthetic / --csr ...) to PATH as a Matrix Market file (.gz: compressed) that reads "
+         "back bit for bit, and stop: files of the generated stand-ins, or a file re-written in plain form", 2},
         {"check", key_check, nullptr, 0,
          "After profiling, compare y with the CPU CSR kernel run the same number of times; adds \"parity\"", 0},
 
@@ -300,6 +307,25 @@ int main(int argc, char ** argv)
         std::cerr << "Please re-build with libpfm enabled\n"; // the reference's NO_LIBPFM message
         return EXIT_FAILURE;
     }
+    if (!args.write_mtx.empty()) {
+        if (args.matrix_path.empty()) {
+            std::cerr << "--write-mtx needs a matrix (--matrix PATH, --synthetic SPEC or --csr/--coo/--ell PATH)\n";
+            return EXIT_FAILURE;
+        }
+        try {
+            matrix_market::Matrix m = matrix_market::load_matrix(args.matrix_path, std::cerr, args.verbose);
+            if (args.spmv.expand_symmetric)
+                m = matrix_market::expand_symmetry(m);
+            matrix_market::write_matrix(args.write_mtx, m);
+            std::cout << "{\"written\": \"" << args.write_mtx << "\", \"rows\": " << m.rows() << ", \"columns\": " << m.columns()
+                      << ", \"entries\": " << m.num_entries() << "}\n";
+            return EXIT_SUCCESS;
+        } catch (std::exception const & e) {
+            std::cerr << e.what() << "\n";
+            return EXIT_FAILURE;
+        }
+    }
+
     if (args.kernel_type == KernelType::none) {
         std::cerr << "Please choose a kernel: --spmv-format FMT --matrix PATH, --csr/--coo/--ell PATH or --triad N\n";
         return EXIT_FAILURE;

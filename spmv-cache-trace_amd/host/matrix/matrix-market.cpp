@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <charconv>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -790,6 +791,93 @@ std::ostream & operator<<(std::ostream & o, Matrix const & m)
         o << '\n';
     }
     return o;
+}
+
+void write_matrix(std::string const & path, Matrix const & m)
+{
+    static char const * const fields[] = {"real", "complex", "integer", "pattern"};
+    static char const * const syms[] = {"general", "symmetric", "skew-symmetric", "hermitian"};
+    std::string head = std::string("%%MatrixMarket matrix ") + (m.format() == Format::coordinate ? "coordinate" : "array") + ' '
+        + fields[(int) m.field()] + ' ' + syms[(int) m.symmetry()] + '\n';
+    for (auto const & c : m.comments())
+        head += c + '\n';
+    head += std::to_string(m.rows()) + ' ' + std::to_string(m.columns()) + ' ' + std::to_string(m.num_entries()) + '\n';
+    if (m.format() != Format::coordinate)
+        throw matrix::matrix_error("write_matrix: only coordinate matrices are written");
+    auto const & ri = m.row_indices();
+    auto const & ci = m.column_indices();
+    auto const a = m.values_real();
+    bool const complex = m.field() == Field::complex, pattern = m.field() == Field::pattern, integer = m.field() == Field::integer;
+    std::size_t const n = ri.size();
+    // one text block per chunk of entries, formatted in parallel, written in order
+    std::size_t const chunk = 1u << 20;
+    std::size_t const nchunks = (n + chunk - 1) / chunk;
+    bool const gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    std::FILE * f = nullptr;
+    gzFile g = nullptr;
+    if (gz)
+        g = gzopen(path.c_str(), "wb1");
+    else
+        f = std::fopen(path.c_str(), "wb");
+    if (!f && !g)
+        throw matrix::matrix_error(path + ": cannot open for writing");
+    auto put = [&](char const * data, std::size_t len) {
+        bool ok = true;
+        if (gz) {
+            for (std::size_t off = 0; ok && off < len;) {
+                unsigned const part = (unsigned) std::min<std::size_t>(len - off, 1u << 30);
+                ok = gzwrite(g, data + off, part) == (int) part;
+                off += part;
+            }
+        } else {
+            ok = std::fwrite(data, 1, len, f) == len;
+        }
+        if (!ok) {
+            if (f) std::fclose(f);
+            if (g) gzclose(g);
+            throw matrix::matrix_error(path + ": write failed");
+        }
+    };
+    put(head.data(), head.size());
+    int const group = 16; // chunks formatted side by side before they are written
+    std::vector<std::string> text((std::size_t) group);
+    for (std::size_t c0 = 0; c0 < nchunks; c0 += group) {
+        std::size_t const c1 = std::min(nchunks, c0 + group);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long c = (long long) c0; c < (long long) c1; ++c) {
+            std::string & out = text[(std::size_t) c - c0];
+            out.clear();
+            out.reserve(chunk * 40);
+            char buf[96];
+            std::size_t const k1 = std::min(n, ((std::size_t) c + 1) * chunk);
+            for (std::size_t k = (std::size_t) c * chunk; k < k1; ++k) {
+                char * q = buf;
+                q = std::to_chars(q, buf + sizeof(buf), (long long) ri[k]).ptr;
+                *q++ = ' ';
+                q = std::to_chars(q, buf + sizeof(buf), (long long) ci[k]).ptr;
+                if (!pattern) {
+                    *q++ = ' ';
+                    if (integer)
+                        q = std::to_chars(q, buf + sizeof(buf), (long long) a[k]).ptr;
+                    else
+                        q = std::to_chars(q, buf + sizeof(buf), (double) a[k]).ptr;
+                    if (complex) {
+                        *q++ = ' ';
+                        q = std::to_chars(q, buf + sizeof(buf), (double) m.values_imag()[k]).ptr;
+                    }
+                }
+                *q++ = '\n';
+                out.append(buf, (std::size_t) (q - buf));
+            }
+        }
+        for (std::size_t c = c0; c < c1; ++c)
+            put(text[c - c0].data(), text[c - c0].size());
+    }
+    bool ok = true;
+    if (f) ok = std::fclose(f) == 0;
+    if (g) ok = gzclose(g) == Z_OK;
+    if (!ok)
+        throw matrix::matrix_error(path + ": close failed");
 }
 
 } // namespace matrix_market

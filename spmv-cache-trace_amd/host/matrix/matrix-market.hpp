@@ -123,4 +123,9 @@ Matrix expand_symmetry(Matrix const & m);
 
 std::ostream & operator<<(std::ostream & o, Matrix const & m);
 
+// EXTENSION: the matrix as a Matrix Market file that load_matrix reads back bit for bit -- values in their
+// shortest decimal form that round-trips (std::to_chars), entries formatted by all OpenMP threads.  `.gz`
+// paths are compressed with zlib.  Used by `--write-mtx` (files of the generated stand-ins at full size).
+void write_matrix(std::string const & path, Matrix const & m);
+
 } // namespace matrix_market
