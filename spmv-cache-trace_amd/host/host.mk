@@ -11,7 +11,7 @@
 
 HOST_CXXFLAGS := -std=c++17 -O3 -fopenmp -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter \
                  -D__HIP_PLATFORM_AMD__ $(INC) -I$(ROCM)/include -Ihost
-HOST_SRCS := host/util/json-value.cpp host/trace-config.cpp host/matrix/matrix-market.cpp host/matrix/matrix-cache.cpp \
+HOST_SRCS := host/util/json-value.cpp host/util/cpu-budget.cpp host/trace-config.cpp host/matrix/matrix-market.cpp host/matrix/matrix-cache.cpp \
              host/matrix/csr-matrix.cpp host/matrix/coo-matrix.cpp host/matrix/ell-matrix.cpp \
              host/matrix/hybrid-matrix.cpp host/matrix/matrix-reorder.cpp host/matrix/synthetic.cpp \
              host/kernels/spmv-kernels.cpp host/kernels/triad-kernel.cpp host/profile-kernel.cpp \

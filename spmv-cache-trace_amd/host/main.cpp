@@ -12,6 +12,7 @@
 #include "matrix/matrix-market.hpp"
 #include "profile-kernel.hpp"
 #include "trace-config.hpp"
+#include "util/cpu-budget.hpp"
 #include "util/json-ostreambuf.hpp"
 
 #include "spmv_hip.h"
@@ -169,9 +170,9 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case key_peer_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PEER_GATHER; break;
     case key_balance_entries: a.spmv.hip_flags |= SPMV_HIP_FLAG_BALANCE_ENTRIES; break;
     case key_threads:
-        if (!parse_count(arg, n) || n < 1 || n > 4096)
-            argp_error(state, "threads: expected a positive integer");
-        a.threads = (int) n;
+        if (!parse_count(arg, n) || n < 0 || n > 4096)
+            argp_error(state, "threads: expected a positive integer, or 0 for the cores this process may use");
+        a.threads = n == 0 ? cpu_budget() : (int) n; // 0: affinity mask capped by the cgroup quota
         break;
     case key_check: a.check = true; break;
     case key_gpus:
@@ -244,7 +245,7 @@ int main(int argc, char ** argv)
         {"matrix", key_matrix, "PATH", 0, "Read matrix from file in Matrix Market format.", 0},
         {"trace-config", key_trace_config, "PATH", 0,
          "Read cache parameters and thread affinities from a configuration file in JSON format.", 0},
-        {"threads", key_threads, "T", 0, "Use a generated configuration with T threads instead of --trace-config", 0},
+        {"threads", key_threads, "T", 0, "Use a generated configuration with T threads instead of --trace-config (0: the cores this process may use -- affinity mask capped by the cgroup quota)", 0},
         {"profile", key_profile, "N", 0, "Time N runs of the kernel", 0},
         {"warmup", key_warmup, nullptr, 0, "Accepted for compatibility (profiling always warms up once)", 0},
         {"flush-caches", key_flush_caches, nullptr, 0, "Flush CPU caches between each profiling run", 0},

@@ -12,14 +12,14 @@ OUT=$ROOT/gpurun_out/$TAG.log
 DIR=$(mktemp -d /tmp/ingest.XXXXXX)
 trap 'rm -rf "$DIR"' EXIT
 {
-echo "# $SPEC on $(nproc) host cores, $(df -h /tmp | tail -1 | awk '{print $4}') free in /tmp"
+echo "# $SPEC, $(nproc) CPUs visible (the CLI takes its cgroup share: --threads 0), $(df -h /tmp | tail -1 | awk '{print $4}') free in /tmp"
 t0=$(date +%s.%N)
 "$CLI" --matrix "$SPEC" --write-mtx "$DIR/m.mtx" || exit 1
 t1=$(date +%s.%N)
 ls -l "$DIR/m.mtx" | awk '{printf "file: %.1f MB\n", $5 / 1e6}'
 echo "generated + written in $(python3 -c "print(round($t1 - $t0, 2))") s"
 t2=$(date +%s.%N)
-"$CLI" --threads "$(nproc)" --csr "$DIR/m.mtx" --device hip --profile 10 --x uniform --check > "$DIR/run.json" || { cat "$DIR/run.json" | tail -5; exit 1; }
+"$CLI" --threads 0 --csr "$DIR/m.mtx" --device hip --profile 10 --x uniform --check > "$DIR/run.json" || { cat "$DIR/run.json" | tail -5; exit 1; }
 t3=$(date +%s.%N)
 echo "CLI from the file, whole process: $(python3 -c "print(round($t3 - $t2, 2))") s"
 python3 - "$DIR/run.json" "$DIR/m.mtx" <<'PY'
