@@ -328,3 +328,42 @@ def test_value_dictionary_on_short_row_stencils_bit_identical(oracle):
             else:
                 assert_bitexact(got, want, what)
         assert out[capi.FLAG_ROWS128 | capi.FLAG_NO_X_WINDOW][1]["indexed_values"] == len(vals), name
+
+
+def test_lane_per_row_stencil_tiles_fuzz(oracle):
+    """The one-lane-per-row path of the value-dictionary kernel (uniform shifted tiles): bands of 1 ... 64 diagonals at
+    random offsets, so that tiles have anything from 8 to 128 rows, start at any of the four positions inside an
+    aligned quad, end ragged, and come with and without a shared pattern; rows of up to 16 entries take it by
+    default, longer ones under EXACT_ORDER.  y must equal the oracle's bit for bit every time."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(2024)
+    vals = np.array([1.0, -1.0, 4.0, 0.5, -0.125, 3.0, 1e-8, -2.0e5])
+    took_path = 0
+    for case in range(24):
+        ndiag = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 11, 13, 16, 17, 23, 32, 47, 63, 64]))
+        rows = int(rng.integers(2500, 9000))
+        reach = int(rng.integers(ndiag, max(ndiag + 1, rows // 3)))
+        offs = np.sort(rng.choice(np.arange(-reach, reach + 1), size=ndiag, replace=False)).tolist()
+        r, cols, p, c, v = synth.banded(rows, offs, seed=case)
+        v = vals[rng.integers(0, len(vals), size=len(v))]
+        x = synth.x_vector(cols, seed=case + 100)
+        y0 = synth.x_vector(r, seed=case + 200)
+        want = oracle.csr_spmv(r, p, c, v, x, y=y0, num_threads=2)
+        tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+        for flags in ((capi.FLAG_EXACT_ORDER | capi.FLAG_NO_X_WINDOW), capi.FLAG_NO_X_WINDOW, 0):
+            if ndiag > 16 and not (flags & capi.FLAG_EXACT_ORDER):
+                continue  # several lanes per row: another path, another summation order
+            plan = capi.CsrPlan(r, cols, p, capi.CSR_AUTO, 0, flags)
+            plan.compress(tc.data_ptr(), stream)
+            plan.index_values(tv.data_ptr(), stream)
+            info = plan.info()
+            ty = torch.from_numpy(y0.copy()).to(dev)
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert_bitexact(ty.cpu().numpy(), want, "case %d: %d diagonals, %d rows, flags %x, %r" % (case, ndiag, r, flags, info))
+            if info["indexed_values"] > 0 and info["shifted_tiles"] > 0 and info["uniform_tiles"] > 0:
+                took_path += 1
+            plan.close()
+    assert took_path >= 20  # the cases did exercise dictionary + shifted + uniform tiles
