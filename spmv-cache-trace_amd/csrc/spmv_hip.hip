@@ -1412,6 +1412,9 @@ namespace {
 void multi_free_matrix(spmv_hip_ctx * c);
 int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_ptr,
                      const int32_t * column_index, const double * value);
+int multi_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length, const int32_t * column_index, const double * value);
+int multi_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_index, const int32_t * column_index,
+                     const double * value);
 int multi_set_x(spmv_hip_ctx * c, const double * x);
 int multi_set_y(spmv_hip_ctx * c, const double * y);
 int multi_get_y(spmv_hip_ctx * c, double * y);
@@ -1647,7 +1650,7 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->multi)
-        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
+        return multi_upload_coo(c, rows, cols, nnz, row_index, column_index, value);
     if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
     bool row_sorted = true;
@@ -1701,7 +1704,7 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->multi)
-        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
+        return multi_upload_ell(c, rows, cols, row_length, column_index, value);
     if (rows < 0 || cols < 0 || row_length < 0)
         return fail(SPMV_HIP_ERR_INVALID, "bad ELL arguments");
     int32_t n;
@@ -1795,7 +1798,7 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->multi)
-        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR (the row partition of src/matrix/csr-matrix.cpp:77-95)");
+        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR, COO or ELLPACK (row blocks: src/matrix/csr-matrix.cpp:77-95)");
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
     // the ELL part is uploaded (validated) exactly like a plain ELLPACK matrix ...
@@ -2122,27 +2125,23 @@ void multi_free_matrix(spmv_hip_ctx * c)
     c->timed = false;
 }
 
-int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_ptr,
-                     const int32_t * column_index, const double * value)
+// Row blocks of a multi-GPU context and each device's copy of y.  row_ptr (rows + 1 entries, any base) gives the
+// stored entries in front of every row: the reference's static rule needs only `rows`, SPMV_HIP_FLAG_BALANCE_ENTRIES
+// cuts where the entries divide evenly (boundary g = the first row whose row_ptr reaches g * nnz / G).
+int multi_layout(spmv_hip_ctx * c, int32_t rows, const long long * entries_before_row /* rows + 1, or null */)
 {
-    if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!column_index || !value)))
-        return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
-    if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
-        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
     multi_free_matrix(c);
     const int G = (int) c->parts.size();
-    // block boundaries: the reference's static rule, chunk = ceil(rows / G) rows per device -- or, with
-    // SPMV_HIP_FLAG_BALANCE_ENTRIES, cuts on row boundaries at equal shares of the stored entries (SURVEY 8e:
-    // boundary g = the first row whose row_ptr reaches g * nnz / G), for matrices whose rows differ in length
     c->row_begin.assign((size_t) G + 1, 0);
-    if (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) {
+    if ((c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) && entries_before_row) {
+        const long long nnz = entries_before_row[rows] - entries_before_row[0];
         for (int g = 1; g < G; ++g) {
-            const int32_t target = (int32_t) (((long long) nnz * g) / G);
-            const int32_t r = (int32_t) (std::lower_bound(row_ptr, row_ptr + rows + 1, target) - row_ptr);
+            const long long target = entries_before_row[0] + (nnz * g) / G;
+            const int32_t r = (int32_t) (std::lower_bound(entries_before_row, entries_before_row + rows + 1, target) - entries_before_row);
             c->row_begin[(size_t) g] = std::max(c->row_begin[(size_t) g - 1], std::min(r, rows));
         }
     } else {
-        const long long per = std::max<long long>(1, ((long long) rows + G - 1) / G);
+        const long long per = std::max<long long>(1, ((long long) rows + G - 1) / G); // ceil(rows / G): src/matrix/csr-matrix.cpp:77-95
         for (int g = 1; g < G; ++g)
             c->row_begin[(size_t) g] = (int32_t) std::min<long long>(rows, g * per);
     }
@@ -2157,7 +2156,6 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
         if (e > b && (b != (long long) g * chunk || (e - b != chunk && e != rows)))
             c->packed = false;
     }
-    std::vector<int32_t> local_ptr;
     for (int g = 0; g < G; ++g) {
         spmv_hip_ctx * part = c->parts[(size_t) g];
         HIP_TRY(hipSetDevice(part->device));
@@ -2165,27 +2163,133 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
         const size_t ybytes = (size_t) chunk * (size_t) G * sizeof(double) + 64;
         HIP_TRY(hipMalloc((void **) &c->yfull[(size_t) g], ybytes));
         HIP_TRY(hipMemsetAsync(c->yfull[(size_t) g], 0, ybytes, part->stream));
-        const int32_t b = c->row_begin[(size_t) g], e = c->row_begin[(size_t) g + 1];
-        local_ptr.resize((size_t) (e - b) + 1);
-        for (int32_t r = b; r <= e; ++r)
-            local_ptr[(size_t) (r - b)] = row_ptr[r] - row_ptr[b];
         part->y_borrowed = true;
         part->borrowed_y = c->yfull[(size_t) g] + (size_t) g * (size_t) chunk;
         part->csr_algorithm = c->csr_algorithm;
         part->csr_lanes = c->csr_lanes;
-        int rc = spmv_hip_upload_csr(part, e - b, cols, row_ptr[e] - row_ptr[b], local_ptr.data(),
-                                     column_index ? column_index + row_ptr[b] : nullptr, value ? value + row_ptr[b] : nullptr);
-        if (rc != 0) {
-            std::string const keep = g_last_error;
-            multi_free_matrix(c);
-            g_last_error = keep;
-            return rc;
-        }
+    }
+    return SPMV_HIP_OK;
+}
+
+int multi_upload_failed(spmv_hip_ctx * c, int rc)
+{
+    std::string const keep = g_last_error;
+    multi_free_matrix(c);
+    g_last_error = keep;
+    return rc;
+}
+
+int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_ptr,
+                     const int32_t * column_index, const double * value)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad CSR arguments");
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
+        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[rows] must equal nnz");
+    std::vector<long long> before;
+    if (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES)
+        before.assign(row_ptr, row_ptr + rows + 1);
+    int rc = multi_layout(c, rows, before.empty() ? nullptr : before.data());
+    if (rc != 0)
+        return multi_upload_failed(c, rc);
+    std::vector<int32_t> local_ptr;
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        const int32_t b = c->row_begin[g], e = c->row_begin[g + 1];
+        local_ptr.resize((size_t) (e - b) + 1);
+        for (int32_t r = b; r <= e; ++r)
+            local_ptr[(size_t) (r - b)] = row_ptr[r] - row_ptr[b];
+        rc = spmv_hip_upload_csr(c->parts[g], e - b, cols, row_ptr[e] - row_ptr[b], local_ptr.data(),
+                                 column_index ? column_index + row_ptr[b] : nullptr, value ? value + row_ptr[b] : nullptr);
+        if (rc != 0)
+            return multi_upload_failed(c, rc);
     }
     c->rows = rows;
     c->cols = cols;
     c->nnz = nnz;
     c->format = 1;
+    return SPMV_HIP_OK;
+}
+
+// ELLPACK across the devices ("ELL: row range"): every row has row_length slots, so the blocks of the
+// static rule are also the blocks of equal entries; device g gets rows [b, e) of the row-major arrays as they are.
+int multi_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length, const int32_t * column_index, const double * value)
+{
+    if (rows < 0 || cols < 0 || row_length < 0 || ((long long) rows * row_length > 0 && (!column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad ELL arguments");
+    if ((long long) rows * row_length > INT32_MAX)
+        return fail(SPMV_HIP_ERR_OVERFLOW, "Integer overflow when computing number of non-zeros");
+    int rc = multi_layout(c, rows, nullptr);
+    if (rc != 0)
+        return multi_upload_failed(c, rc);
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        const int32_t b = c->row_begin[g], e = c->row_begin[g + 1];
+        const size_t off = (size_t) b * (size_t) row_length;
+        rc = spmv_hip_upload_ell(c->parts[g], e - b, cols, row_length, column_index ? column_index + off : nullptr, value ? value + off : nullptr);
+        if (rc != 0)
+            return multi_upload_failed(c, rc);
+    }
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = (int32_t) ((long long) rows * row_length);
+    c->format = 3;
+    return SPMV_HIP_OK;
+}
+
+// COO across the devices ("split the row-sorted stream at row boundaries"): the triplets may come in any
+// order (file order: src/matrix/coo-matrix.cpp:220-243); they are dealt to the row blocks by a stable counting pass --
+// every device gets its rows' triplets in their original relative order, row indices rebased to the block -- and
+// each device then treats its share like any COO upload (sorted by row on the device, multiplied as row-major tiles).
+int multi_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_index, const int32_t * column_index,
+                     const double * value)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_index || !column_index || !value)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad COO arguments");
+    for (int32_t k = 0; k < nnz; ++k)
+        if (row_index[k] < 0 || row_index[k] >= rows)
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+    std::vector<long long> before;
+    if (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) { // entries in front of every row, from a histogram of the row indices
+        before.assign((size_t) rows + 1, 0);
+        for (int32_t k = 0; k < nnz; ++k)
+            ++before[(size_t) row_index[k] + 1];
+        for (int32_t r = 0; r < rows; ++r)
+            before[(size_t) r + 1] += before[(size_t) r];
+    }
+    int rc = multi_layout(c, rows, before.empty() ? nullptr : before.data());
+    if (rc != 0)
+        return multi_upload_failed(c, rc);
+    const size_t G = c->parts.size();
+    // block of a row: binary search over the G + 1 boundaries (blocks may be empty)
+    auto block_of = [&](int32_t r) {
+        return (size_t) (std::upper_bound(c->row_begin.begin() + 1, c->row_begin.end(), r) - (c->row_begin.begin() + 1));
+    };
+    std::vector<size_t> start(G + 1, 0);
+    for (int32_t k = 0; k < nnz; ++k)
+        ++start[block_of(row_index[k]) + 1];
+    for (size_t g = 0; g < G; ++g)
+        start[g + 1] += start[g];
+    std::vector<int32_t> ri((size_t) nnz), ci((size_t) nnz);
+    std::vector<double> va((size_t) nnz);
+    std::vector<size_t> fill(start.begin(), start.end() - 1);
+    for (int32_t k = 0; k < nnz; ++k) {
+        const size_t g = block_of(row_index[k]);
+        const size_t at = fill[g]++;
+        ri[at] = row_index[k] - c->row_begin[g];
+        ci[at] = column_index[k];
+        va[at] = value[k];
+    }
+    for (size_t g = 0; g < G; ++g) {
+        const int32_t b = c->row_begin[g], e = c->row_begin[g + 1];
+        const size_t off = start[g], cnt = start[g + 1] - start[g];
+        rc = spmv_hip_upload_coo(c->parts[g], e - b, cols, (int32_t) cnt, cnt ? ri.data() + off : nullptr, cnt ? ci.data() + off : nullptr,
+                                 cnt ? va.data() + off : nullptr);
+        if (rc != 0)
+            return multi_upload_failed(c, rc);
+    }
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = nnz;
+    c->format = 2;
     return SPMV_HIP_OK;
 }
 

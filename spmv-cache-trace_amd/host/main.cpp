@@ -283,7 +283,7 @@ int main(int argc, char ** argv)
          "variable SPMV_DEVICE=hip changes the default, so that --csr/--coo/--ell PATH run on the GPU", 3},
         {"gpu", key_gpu, "INDEX", 0, "HIP device index (default 0)", 3},
         {"gpus", key_gpus, "G", 0,
-         "hip-csr only: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
+         "hip-csr, hip-coo, hip-ell: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
          "x replicated, one RCCL all-gather of y per run", 3},
         {"balance-entries", key_balance_entries, nullptr, 0,
          "with --gpus: cut the rows at equal shares of the stored entries instead of ceil(rows/G) rows per device", 3},

@@ -304,10 +304,11 @@ def test_multi_gpu_context_with_one_device(oracle):
                 k_ns, g_ns = ctx.last_run_times()
                 assert k_ns > 0 and g_ns < 5_000_000
                 i, j, a = synth.csr_to_coordinate(rows, p, c, v)
-                with pytest.raises(capi.SpmvHipError) as e:  # only CSR is partitioned
-                    ctx.upload_coo(rows, cols, i - 1, j - 1, a)
-                assert e.value.code == capi.ERR_STATE
-                ctx.upload_csr(rows, cols, p, c, v)  # a second upload replaces the first
+                ctx.upload_coo(rows, cols, i - 1, j - 1, a)  # a second upload (another format) replaces the first
+                ctx.set_x(x)
+                ctx.run()
+                assert_close(ctx.get_y(), oracle.csr_spmv(rows, p, c, v, x, num_threads=4), scale, what="COO in a multi ctx")
+                ctx.upload_csr(rows, cols, p, c, v)
                 ctx.set_x(x)
                 ctx.run()
                 assert_close(ctx.get_y(), oracle.csr_spmv(rows, p, c, v, x, num_threads=4), scale, what="re-upload")
@@ -387,5 +388,57 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
         with pytest.raises(capi.SpmvHipError) as e:  # sharing devices is a rehearsal of the peer gather only
             capi.Context(num_gpus=capi.device_count() + 1)
         assert e.value.code == capi.ERR_INVALID
+    finally:
+        os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
+
+
+@pytest.mark.parametrize("fmt,parts,balance", [("coo", 3, False), ("coo", 8, True), ("ell", 2, False), ("ell", 5, False)])
+def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
+    """COO and ELLPACK through spmv_hip_create_multi (SURVEY 8e: "COO: split the row-sorted stream at row boundaries;
+    ELL: row range"), rehearsed with every block on this box's one device: the triplets come shuffled, are dealt to
+    the blocks of their rows and rebased; the ELLPACK arrays are cut by rows.  y against the oracle on the whole
+    matrix, two accumulating runs from a given y."""
+    import os
+    rng = np.random.default_rng(5)
+    if fmt == "coo":
+        rows, cols, p, c, v = synth.powerlaw(20011, 20011, seed=21)
+        i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+        perm = rng.permutation(len(a))
+        i, j, a = i[perm] - 1, j[perm] - 1, a[perm]
+    else:
+        rows, cols, p, c, v = synth.banded(15013, [-700, -3, -1, 0, 1, 2, 900], seed=22)
+    x = synth.x_vector(cols, seed=5)
+    y0 = synth.x_vector(rows, seed=6)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
+    scale = 2 * abs_products(rows, p, c, v, x) + np.abs(y0)
+    os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
+    try:
+        with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
+            if fmt == "coo":
+                ctx.upload_coo(rows, cols, i, j, a)
+            else:
+                # row-major ELLPACK like ell_matrix::from_matrix_market (src/matrix/ell-matrix.cpp:190-238): zero
+                # padding whose column repeats the row's last real one
+                lens = np.diff(p)
+                L = int(lens.max())
+                ec = np.zeros((rows, L), dtype=np.int32)
+                ev = np.zeros((rows, L), dtype=np.float64)
+                slot = np.arange(len(c)) - np.repeat(p[:-1], lens)
+                rix = np.repeat(np.arange(rows), lens)
+                ec[rix, slot] = c
+                ev[rix, slot] = v
+                last = np.where(lens > 0, c[np.maximum(p[1:] - 1, 0)], 0)
+                pad = np.arange(L)[None, :] >= lens[:, None]
+                ec[pad] = np.broadcast_to(last[:, None], (rows, L))[pad]
+                ctx.upload_ell(rows, cols, L, ec.ravel(), ev.ravel())
+            ctx.set_x(x)
+            ctx.set_y(y0)
+            ctx.run(2)
+            assert_close(ctx.get_y(), want, scale, what="%s over %d blocks" % (fmt, parts))
+            info = ctx.info()
+            assert info["devices"] == parts and info["format"] == (2 if fmt == "coo" else 3) and info["rows"] == rows
+            with pytest.raises(capi.SpmvHipError) as e:  # a bad row index is refused before anything is dealt
+                ctx.upload_coo(rows, cols, np.array([rows], dtype=np.int32), np.array([0], dtype=np.int32), np.array([1.0]))
+            assert e.value.code == capi.ERR_INVALID
     finally:
         os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
