@@ -2166,8 +2166,11 @@ __global__ __launch_bounds__(256) void value_dict_insert_kernel(
     long long n, const double * __restrict__ a, unsigned long long * __restrict__ keys, int * __restrict__ state, int limit)
 {
     const long long stride = (long long) gridDim.x * 256;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        if ((k & 0xFFF) == 0 && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    int round = 0;
+    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride, ++round) {
+        // a matrix with more distinct values than the dictionary holds is found out within the first few thousand
+        // entries: every thread looks at the verdict every eighth round and leaves
+        if ((round & 7) == 0 && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             return;
         const unsigned long long key = (unsigned long long) __double_as_longlong(a[k]);
         if (key == kDictEmpty) {
