@@ -573,6 +573,70 @@ __device__ __forceinline__ void tile_rows_uniform_indexed(
     }
 }
 
+// The same lane-per-row scheme with the values themselves (no dictionary): the tile's values are loaded as ever --
+// two coalesced 16-byte loads per lane and quad -- and parked in the wave's LDS slice where the products used to
+// go; a lane then reads its row's values back (the access pattern the row sums had) and multiplies them with x
+// read 512 contiguous bytes at a time.  Same bits as the reference's loop.
+template <int QUADS, bool X32>
+__device__ __forceinline__ void tile_rows_uniform_values(
+    double * prod, const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
+    const double * __restrict__ x, int last, int lane, int len, int lead, int nrows, bool second, double & zA, double & zB)
+{
+    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
+    TileValues<QUADS, false> vals;
+    vals.load(at, nullptr, last, lane);
+    const int rowA = lane < nrows ? lane : nrows - 1;
+    const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
+    zA = 0.0;
+    zB = 0.0;
+    constexpr int CH = 5;
+    double xa[CH], xb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (i < len) { // wave-uniform
+            const int c = __builtin_amdgcn_readlane(fr, i);
+            xa[i] = gather_x<X32>(x, c + rowA);
+            if (second)
+                xb[i] = gather_x<X32>(x, c + rowB);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+        const int o = 256 * q + 4 * lane;
+        if (o <= last) {
+            v2d * dst = reinterpret_cast<v2d *>(prod + o);
+            dst[0] = vals.va[q];
+            dst[1] = vals.vb[q];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double * vA = prod + lead + rowA * len;
+    const double * vB = prod + lead + rowB * len;
+    for (int p0 = 0; p0 < len; p0 += CH) {
+        if (p0 > 0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (p0 + i < len) {
+                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
+                    xa[i] = gather_x<X32>(x, c + rowA);
+                    if (second)
+                        xb[i] = gather_x<X32>(x, c + rowB);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (p0 + i < len) {
+                zA += vA[p0 + i] * xa[i];
+                if (second)
+                    zB += vB[p0 + i] * xb[i];
+            }
+        }
+    }
+}
+
 // x staged through LDS (kernel variant XW > 0, tiles marked kTileMetaXWin): the tile's column
 // range [base, base + 64 * chunks) is read once with coalesced loads into the wave's window and the
 // products take x from there (ds_read_b64) instead of gathering it through the vector L1.  All
@@ -848,6 +912,18 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 __builtin_nontemporal_store(yv + zA, yt + lane);
             if (second && lane + kWave < nrows && !(SPMV_VI_ABLATE & 8))
                 __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
+            return;
+        }
+        if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
+            && lanes_log2 == 0 && maxlen <= kWave) {
+            const bool pattern = (meta & kTileMetaPattern) != 0;
+            double zA, zB;
+            tile_rows_uniform_values<QUADS, X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
+                                                 a + kb, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
+            if (lane < nrows)
+                yt[lane] = yv + zA;
+            if (second && lane + kWave < nrows)
+                yt[lane + kWave] = yvB + zB;
             return;
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries

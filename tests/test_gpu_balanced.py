@@ -355,15 +355,18 @@ def test_lane_per_row_stencil_tiles_fuzz(oracle):
         for flags in ((capi.FLAG_EXACT_ORDER | capi.FLAG_NO_X_WINDOW), capi.FLAG_NO_X_WINDOW, 0):
             if ndiag > 16 and not (flags & capi.FLAG_EXACT_ORDER):
                 continue  # several lanes per row: another path, another summation order
-            plan = capi.CsrPlan(r, cols, p, capi.CSR_AUTO, 0, flags)
-            plan.compress(tc.data_ptr(), stream)
-            plan.index_values(tv.data_ptr(), stream)
-            info = plan.info()
-            ty = torch.from_numpy(y0.copy()).to(dev)
-            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
-            torch.cuda.synchronize()
-            assert_bitexact(ty.cpu().numpy(), want, "case %d: %d diagonals, %d rows, flags %x, %r" % (case, ndiag, r, flags, info))
-            if info["indexed_values"] > 0 and info["shifted_tiles"] > 0 and info["uniform_tiles"] > 0:
-                took_path += 1
-            plan.close()
+            for index in (True, False):  # with the dictionary, and the same scheme on the 8-byte values
+                plan = capi.CsrPlan(r, cols, p, capi.CSR_AUTO, 0, flags)
+                plan.compress(tc.data_ptr(), stream)
+                if index:
+                    plan.index_values(tv.data_ptr(), stream)
+                info = plan.info()
+                ty = torch.from_numpy(y0.copy()).to(dev)
+                plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+                torch.cuda.synchronize()
+                assert_bitexact(ty.cpu().numpy(), want, "case %d: %d diagonals, %d rows, flags %x, dictionary %s, %r" % (
+                    case, ndiag, r, flags, index, info))
+                if index and info["indexed_values"] > 0 and info["shifted_tiles"] > 0 and info["uniform_tiles"] > 0:
+                    took_path += 1
+                plan.close()
     assert took_path >= 20  # the cases did exercise dictionary + shifted + uniform tiles
