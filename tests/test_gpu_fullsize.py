@@ -442,3 +442,37 @@ def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
             assert e.value.code == capi.ERR_INVALID
     finally:
         os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
+
+
+def test_bench_on_a_matrix_market_file(tmp_path):
+    """bench.py --matrix FILE: what a box that has the SuiteSparse files runs.  A symmetric file (the 1138_bus
+    stand-in) packed the way SuiteSparse ships (NAME.tar.gz holding NAME/NAME.mtx), stored triangle only and with
+    --expand-symmetric, CSR and COO: one JSON line each, named after the file, parity against the CPU kernel."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import tarfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "bus_like"
+    member = tmp_path / name
+    member.mkdir()
+    shutil.copy(os.path.join(root, "tests", "golden", "bus1138_like.mtx"), member / (name + ".mtx"))
+    archive = tmp_path / (name + ".tar.gz")
+    with tarfile.open(archive, "w:gz") as t:
+        t.add(member, arcname=name)
+    stored = None
+    for extra, fmt in (([], "csr"), (["--expand-symmetric"], "csr"), (["--expand-symmetric"], "coo")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--matrix", str(archive), "--format", fmt, "--steps", "3",
+                            "--warmup", "1", "--cpu-seconds", "0.2", "--no-reference-protocol"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["config"]["workload"].startswith(name + ".tar.gz") and d["config"]["rows"] == 1138
+        assert d["parity"]["pass"] is True and d["roofline"]["kernel_us"] > 0 and d["cpu_baseline"]["value"] > 0
+        assert d["config"]["symmetric_file_expanded"] is bool(extra)
+        if not extra:
+            stored = d["config"]["nnz"]
+            assert stored == 2596  # the reference multiplies what the file stores (SURVEY section 0.2)
+        else:
+            assert d["config"]["nnz"] == 2 * stored - 1138  # mirrored off-diagonal entries
