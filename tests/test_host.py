@@ -653,3 +653,19 @@ def test_cli_check_gate_fails_on_non_finite_values(tmp_path):
     r = subprocess.run([hostlib.CLI, "--matrix", str(path), "--spmv-format", "ell", "--threads", "2", "--profile", "3", "--check", "--x", "uniform"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0 and json.loads(r.stdout)["parity"]["pass"] is True
+
+
+def test_cli_check_and_the_reference_coo_workspace_recurrence(tmp_path):
+    """The reference's multi-threaded COO kernel never clears its per-thread workspaces (coo-matrix.cpp:248-285), so
+    after k runs y is not k * A x; the CPU COO / hybrid kernels reproduce that, and --check then gives no verdict
+    (with the reason) instead of a misleading failure.  One thread: an ordinary verdict."""
+    spec = "synthetic:webbase:3000,9000,100,75"
+    for fmt in ("coo", "hybrid"):
+        r = subprocess.run([hostlib.CLI, "--matrix", spec, "--spmv-format", fmt, "--threads", "2", "--profile", "2", "--check"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        p = json.loads(r.stdout)["parity"]
+        assert p["pass"] is None and "workspace" in p["skipped"]
+        r = subprocess.run([hostlib.CLI, "--matrix", spec, "--spmv-format", fmt, "--threads", "1", "--profile", "2", "--check"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and json.loads(r.stdout)["parity"]["pass"] is True, r.stderr
