@@ -456,7 +456,8 @@ def test_cli_cpu_formats_and_readme_spellings(fmt, name):
     assert doc["parity"]["pass"] is True
     if fmt == "coo":
         rc, out, err = hostlib.run_cli("-c", TC2, "--spmv-format", fmt, "--matrix", BUS, "-p", 3, "--check")
-        assert rc == 1 and "parity check failed" in err  # the recurrence, faithfully reproduced
+        # the recurrence is reproduced (tests/test_oracle.py compares it with the reference library run by run): no verdict
+        assert rc == 0 and json.loads(out)["parity"]["pass"] is None and "workspace" in json.loads(out)["parity"]["skipped"]
         doc["kernel"] = json.loads(out)["kernel"]
     if fmt in ("csr", "coo", "ell"):
         rc, out2, err = hostlib.run_cli("-c", TC2, "--" + fmt, BUS, "--profile=3")  # README.md:81,124
