@@ -163,7 +163,7 @@ def host_cores():
     return n
 
 
-def pmc_traffic(kernel_name, workload, algorithmic_bytes):
+def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_summary.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 + WRITE_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
@@ -177,6 +177,9 @@ def pmc_traffic(kernel_name, workload, algorithmic_bytes):
             d = json.load(open(f))
             rl = (d.get("bench_line") or {}).get("roofline", {})
             if rl.get("algorithmic_bytes_per_launch") != algorithmic_bytes:
+                continue
+            # the same tile classes too (a plan with and one without a value dictionary run different kernel variants)
+            if streamed_bytes is not None and rl.get("streamed_bytes_per_launch") not in (None, streamed_bytes):
                 continue
             for k in d["kernels"]:
                 if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k and d.get("sequence", 0) > seq:
@@ -654,7 +657,7 @@ def main():
             out["gather_check"] = gather_check
             if not gather_check["pass"]:
                 code, message = 1, "bench.py: gathered y does not match the owning rank's rows"
-        tr = pmc_traffic(kernel_name, wname, int(local_bytes))
+        tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"))
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = "profiles/" + tr[1] + " (rocprofv3 PMC of an earlier run of this workload, not of this process)"
