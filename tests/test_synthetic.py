@@ -134,3 +134,18 @@ def test_write_mtx_reads_back_bit_for_bit(tmp_path, spec, suffix):
     assert code != 0
     code, out, err = hostlib.run_cli("--matrix", spec, "--write-mtx", str(tmp_path / "no" / "such" / "dir.mtx"))
     assert code != 0 and "cannot open" in err
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo", "ell", "hybrid"])
+def test_matrix_arrays_are_page_aligned(fmt):
+    """The reference keeps every matrix array in 4096-byte aligned storage (src/util/aligned-allocator.hpp; its tests
+    ask for 64: test/test_ell-matrix.cpp:97-102, test/test_hybrid-matrix.cpp:123-130).  The device upload relies on
+    at least 16 (16-byte vector loads of the tiles)."""
+    m = hostapi.load("synthetic:webbase:5000,15000,200,75" if fmt != "ell" else "synthetic:poisson2d:40", fmt)
+    names = [n for n in ("row_ptr", "row_index", "column_index", "value", "coo_row_index", "coo_column_index", "coo_value") if hasattr(m, n)]
+    assert len(names) >= 2
+    for n in names:
+        a = getattr(m, n)
+        if len(a):
+            assert a.ctypes.data % 4096 == 0, (fmt, n)
+    m.close()
