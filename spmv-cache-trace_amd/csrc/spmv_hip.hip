@@ -1238,11 +1238,11 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
                 if (xcd)
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, true, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
                                        pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
-                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues);
                 else
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
                                        pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
-                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab);
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);
             }

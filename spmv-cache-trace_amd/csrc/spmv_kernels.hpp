@@ -337,6 +337,16 @@ __device__ __forceinline__ double tile_row_sum(const double * prod, int s, int e
 // in LDS.  The doubles are the stored ones bit for bit; the tile streams 1 instead of 8 bytes per entry.
 constexpr int kMaxIndexedValues = 128;
 
+// Where an index byte finds its double: the dictionary in LDS -- or, for a dictionary of one or two values (a
+// pattern or graph matrix; the 5-point stencil's -1 and 4), two scalar registers and a select: no table, no look-up,
+// and no workgroup barrier at the start of the kernel.
+struct ValueLookup {
+    const double * tab;
+    bool tiny;
+    double t0, t1;
+    __device__ __forceinline__ double operator[](unsigned b) const { return tiny ? (b ? t1 : t0) : tab[b]; }
+};
+
 template <int QUADS, bool VI>
 struct TileValues {
     v2d va[QUADS], vb[QUADS];
@@ -357,7 +367,7 @@ struct TileValues {
             }
         }
     }
-    __device__ __forceinline__ void resolve(const double * vtab)
+    __device__ __forceinline__ void resolve(ValueLookup vtab)
     {
         if (VI) {
 #pragma unroll
@@ -373,7 +383,7 @@ struct TileValues {
 template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_wide(
     double * prod, const int32_t * __restrict__ jt, const double * __restrict__ at,
-    const double * __restrict__ x, int last, int lane, const uint8_t * __restrict__ vit = nullptr, const double * vtab = nullptr)
+    const double * __restrict__ x, int last, int lane, const uint8_t * __restrict__ vit = nullptr, ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
 {
     v4i c[QUADS];
     TileValues<QUADS, VI> vals;
@@ -406,7 +416,7 @@ template <int QUADS, int ABL, bool VI = false>
 __device__ __forceinline__ void tile_products_narrow(
     double * prod, const uint16_t * __restrict__ jt, const double * __restrict__ at,
     const double * __restrict__ xt, unsigned limit, int last, int lane, const uint8_t * __restrict__ vit = nullptr,
-    const double * vtab = nullptr)
+    ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     v2u c[QUADS];
@@ -456,7 +466,7 @@ template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_shifted(
     double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
     const double * __restrict__ at, const double * __restrict__ x, unsigned limit, int last, int lane,
-    int len, int lead, const uint8_t * __restrict__ vit = nullptr, const double * vtab = nullptr)
+    int len, int lead, const uint8_t * __restrict__ vit = nullptr, ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
 {
     static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
     TileValues<QUADS, VI> vals;
@@ -515,7 +525,7 @@ __device__ __forceinline__ void tile_products_shifted(
 template <bool X32>
 __device__ __forceinline__ void tile_rows_uniform_indexed(
     double * prod, const int32_t * __restrict__ first_row, int first_row_base,
-    const uint8_t * __restrict__ vit, const double * vtab, const double * __restrict__ x, int last, int lane,
+    const uint8_t * __restrict__ vit, ValueLookup vtab, const double * __restrict__ x, int last, int lane,
     int len, int lead, int nrows, bool second, double & zA, double & zB)
 {
     const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
     int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
-    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr)
+    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0)
 {
     // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
     // different ones (a partitioned multiply whose previous result is still being gathered); every
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
-    __shared__ double vtab[VI ? kMaxIndexedValues : 1];                 // VI variant: the value dictionary
+    __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
@@ -837,11 +847,18 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
     const int4 d0 = desc[wd];
     const int4 d1 = desc[wd + 1];
+    ValueLookup vtab{vtab_lds, false, 0.0, 0.0};
     if (VI) {
-        // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
-        if (threadIdx.x < kMaxIndexedValues)
-            vtab[threadIdx.x] = vtable[threadIdx.x];
-        __syncthreads();
+        vtab.tiny = nvalues <= 2; // kernel-uniform
+        if (vtab.tiny) {
+            vtab.t0 = vtable[0]; // scalar loads (the table is padded to kMaxIndexedValues entries)
+            vtab.t1 = vtable[1];
+        } else {
+            // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
+            if (threadIdx.x < kMaxIndexedValues)
+                vtab_lds[threadIdx.x] = vtable[threadIdx.x];
+            __syncthreads();
+        }
         if (w >= ntiles)
             return;
     }
