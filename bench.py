@@ -52,9 +52,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="poisson2d",
-                    choices=["poisson2d", "queen", "kkt", "webbase", "powerlaw", "stencil27", "random"],
+                    choices=["poisson2d", "queen", "kkt", "webbase", "powerlaw", "banded", "random24", "stencil27", "random"],
                     help="poisson2d = BASELINE configs[1]; queen / kkt / webbase = generated stand-ins of configs[2..4] "
-                         "at full size; powerlaw = webbase with uniformly scattered columns; stencil27 / random: round-1 stand-ins")
+                         "at full size; powerlaw = webbase with uniformly scattered columns; banded / random24 = north_star's synthetic banded / "
+                         "random CSR of ~100 M entries (SURVEY 8d S-banded, S-random); stencil27 / random: round-1 numpy stand-ins")
     ap.add_argument("--matrix", default=None, help="Matrix Market file (.mtx, .gz, .tgz, .tar.gz) or synthetic:<spec>; overrides --workload")
     ap.add_argument("--expand-symmetric", action="store_true",
                     help="mirror the entries of a symmetric file (EXTENSION; the reference multiplies the stored triangle)")
@@ -106,6 +107,10 @@ def workload_spec(args):
         return "synthetic:webbase", "webbase-like power law, 75% host-local links (webbase-1M-like)"
     if args.workload == "powerlaw":
         return "synthetic:powerlaw", "power-law rows, uniformly scattered columns"
+    if args.workload == "banded":  # north_star: "synthetic banded ... CSR of stated nnz": 4 M rows x 27 diagonals = 108 M entries
+        return "synthetic:banded:4000000,13", "banded-4M-27diagonals"
+    if args.workload == "random24":  # ... and random: 4 M rows x 24 uniform columns = 96 M entries (host generator)
+        return "synthetic:random:4000000,24,3", "random-4M-24perrow (host generator)"
     return None, {"stencil27": "stencil27-253^3", "random": "random-4M-24perrow"}[args.workload]
 
 

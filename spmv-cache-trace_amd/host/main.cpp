@@ -268,7 +268,7 @@ int main(int argc, char ** argv)
         {"ell", key_ell, "PATH", 0, "same as --spmv-format ell --matrix PATH", 2},
         {"synthetic", key_synthetic, "SPEC", 0,
          "EXTENSION: generate the matrix instead of reading it: poisson2d:<n>, queen[:gx,gy,gz], kkt[:<n>], "
-         "webbase[:N,Z,maxrow,locality%], powerlaw[:N,Z,maxrow] (same as --matrix synthetic:SPEC)", 2},
+         "webbase[:N,Z,maxrow,locality%], powerlaw[:N,Z,maxrow], banded:N,b[,seed], random:N,k[,seed] (same as --matrix synthetic:SPEC)", 2},
         {"x", key_x, "ones|uniform", 0,
          "EXTENSION: the vector multiplied: all ones like the reference (default), or uniform(-1,1) hashes", 2},
         {"expand-symmetric", key_expand_symmetric, nullptr, 0,

@@ -397,6 +397,51 @@ csr_matrix::Matrix webbase(long long N, long long Z, long long maxrow, int local
     return build(N, N, rb, re, len, fill);
 }
 
+// ---- banded: SURVEY 8d "S-banded(N, b, seed)": N rows, the 2b + 1 diagonals -b .. +b, values U(-1, 1) ----------------
+csr_matrix::Matrix banded(long long N, long long b, std::uint64_t seed, long long rb, long long re, long long * total)
+{
+    if (N < 1 || b < 0 || 2 * b + 1 > 4096)
+        throw matrix::matrix_error("synthetic:banded:<N>,<b>[,seed]: N >= 1, 0 <= b <= 2047");
+    if (total) *total = N;
+    if (re < 0) re = N;
+    auto len = [=](long long r) { return std::min(N - 1, r + b) - std::max(0LL, r - b) + 1; };
+    auto fill = [=](long long r, index_type * c, double * v) {
+        long long const lo = std::max(0LL, r - b), hi = std::min(N - 1, r + b);
+        for (long long q = lo; q <= hi; ++q) {
+            *c++ = (index_type) q;
+            *v++ = u11(h2(seed * 0x9E3779B97F4A7C15ull + (std::uint64_t) r, (std::uint64_t) q));
+        }
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
+// ---- random: SURVEY 8d "S-random(N, k, seed)": k distinct uniform columns per row, ascending, values U(-1, 1) --------
+csr_matrix::Matrix random_columns(long long N, long long k, std::uint64_t seed, long long rb, long long re, long long * total)
+{
+    if (N < 1 || k < 1 || k > 1024 || k > N)
+        throw matrix::matrix_error("synthetic:random:<N>,<k>[,seed]: N >= 1, 1 <= k <= min(N, 1024)");
+    if (total) *total = N;
+    if (re < 0) re = N;
+    auto len = [=](long long) { return k; };
+    auto fill = [=](long long r, index_type * c, double * v) {
+        // k distinct columns: draw, sort, and push duplicates up to the next free column (wrapping keeps them in range)
+        std::uint64_t const hr = seed * 0xD1B54A32D192ED03ull + (std::uint64_t) r;
+        for (long long i = 0; i < k; ++i)
+            c[i] = (index_type) (h2(hr, (std::uint64_t) i) % (std::uint64_t) N);
+        std::sort(c, c + k);
+        for (long long i = 1; i < k; ++i)
+            if (c[i] <= c[i - 1])
+                c[i] = c[i - 1] + 1;
+        if (c[k - 1] >= N) { // ran over the edge: the last columns of the matrix, still distinct and ascending
+            for (long long i = k - 1, q = N - 1; i >= 0 && c[i] > q; --i, --q)
+                c[i] = (index_type) q;
+        }
+        for (long long i = 0; i < k; ++i)
+            v[i] = u11(h2(hr, (std::uint64_t) (1u << 20) + (std::uint64_t) i));
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
 } // namespace
 
 bool is_spec(std::string const & path) { return path.compare(0, 10, "synthetic:") == 0; }
@@ -445,9 +490,15 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
         int const loc = web ? (v.size() > 3 ? (int) v[3] : 75) : 0;
         check_range(N);
         A = webbase(N, Z, maxrow, loc, web ? 4 : 1, rb, re, &tot);
+    } else if (family == "banded" || family == "random") {
+        if (v.size() < 2 || v.size() > 3)
+            throw matrix::matrix_error("synthetic:" + family + ":<N>,<" + (family == "banded" ? "b" : "k") + ">[,seed]");
+        check_range(v[0]);
+        std::uint64_t const seed = v.size() > 2 ? (std::uint64_t) v[2] : 1;
+        A = family == "banded" ? banded(v[0], v[1], seed, rb, re, &tot) : random_columns(v[0], v[1], seed, rb, re, &tot);
     } else {
         throw matrix::matrix_error("unknown synthetic matrix family '" + family +
-                                   "' (poisson2d, queen, kkt, webbase, powerlaw)");
+                                   "' (poisson2d, queen, kkt, webbase, powerlaw, banded, random)");
     }
     if (total)
         *total = tot;

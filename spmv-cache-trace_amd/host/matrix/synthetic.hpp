@@ -22,6 +22,8 @@
 //                                    cent of a row's links inside its host block, the rest to
 //                                    power-law-popular pages; default 1000005,3105536,4700,75
 //   synthetic:powerlaw[:N,Z,maxrow]  the same with locality 0: uniformly scattered columns (worst case)
+//   synthetic:banded:N,b[,seed]      SURVEY 8d S-banded: N rows, the 2b + 1 diagonals -b .. +b, values U(-1,1)
+//   synthetic:random:N,k[,seed]      SURVEY 8d S-random: k distinct uniform columns per row, ascending, values U(-1,1)
 //
 // What these are NOT: the SuiteSparse matrices themselves.  They reproduce size, row-length
 // populations, symmetry of structure and the kind of column locality of their namesakes

@@ -149,3 +149,28 @@ def test_matrix_arrays_are_page_aligned(fmt):
         if len(a):
             assert a.ctypes.data % 4096 == 0, (fmt, n)
     m.close()
+
+
+def test_banded_and_random_families():
+    """SURVEY 8d's S-banded(N, b, seed) and S-random(N, k, seed): shapes, ascending distinct columns, values in (-1, 1),
+    the same arrays whatever the row range, different seeds different matrices."""
+    b = hostapi.load("synthetic:banded:5000,13", "csr")
+    p, c = np.asarray(b.row_ptr), np.asarray(b.column_index)
+    lens = np.diff(p)
+    assert b.rows == b.cols == 5000 and lens.max() == 27 and lens[0] == 14 and lens[-1] == 14 and lens[2500] == 27
+    assert np.array_equal(c[p[2500]:p[2501]], np.arange(2500 - 13, 2500 + 14))
+    r = hostapi.load("synthetic:random:4000,24,3", "csr")
+    p, c, v = np.asarray(r.row_ptr), np.asarray(r.column_index), np.asarray(r.value)
+    assert np.all(np.diff(p) == 24) and c.min() >= 0 and c.max() < 4000 and np.all(np.abs(v) < 1)
+    cc = c.reshape(4000, 24)
+    assert np.all(np.diff(cc, axis=1) > 0)  # distinct, ascending
+    assert len(np.unique(cc[:, 0])) > 100   # and not all the same
+    part = hostapi.load_csr_rows("synthetic:random:4000,24,3", 1000, 1500)
+    assert np.array_equal(np.asarray(part.column_index), c[p[1000]:p[1500]]) and np.array_equal(np.asarray(part.value), v[p[1000]:p[1500]])
+    other = hostapi.load("synthetic:random:4000,24,4", "csr")
+    assert not np.array_equal(np.asarray(other.column_index), c)
+    tiny = hostapi.load("synthetic:random:30,30", "csr")  # k = N: every row holds every column
+    assert np.array_equal(np.asarray(tiny.column_index).reshape(30, 30), np.tile(np.arange(30), (30, 1)))
+    for bad in ("synthetic:banded:10", "synthetic:random:10,11", "synthetic:banded:10,3000"):
+        with pytest.raises(hostapi.HostError):
+            hostapi.load(bad, "csr")
