@@ -55,6 +55,37 @@ def main():
                 else:
                     assert_close(got, want, scale, what=what)
                 checked += 1
+        if seed % 5 == 0:
+            # the context API on the same matrix: shuffled COO triplets, ELLPACK where it fits, three row blocks of equal
+            # entries rehearsed on this one device (peer-store gather)
+            want2 = oracle.csr_spmv(rows, p, c, v0, x, y=y0.copy(), num_threads=1, runs=2)
+            scale2 = 2 * abs_products(rows, p, c, v0, x) + np.abs(y0)
+            i, j, a = synth.csr_to_coordinate(rows, p, c, v0)
+            perm = rng.permutation(len(a))
+            with capi.Context() as ctx:
+                ctx.upload_coo(rows, cols, i[perm] - 1, j[perm] - 1, a[perm])
+                ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
+                assert_close(ctx.get_y(), want2, scale2, what="seed %d COO" % seed)
+            lens = np.diff(p)
+            L = int(lens.max())
+            if rows * L < 40_000_000 and lens[0] > 0:
+                ec = np.zeros((rows, L), dtype=np.int32); ev = np.zeros((rows, L), dtype=np.float64)
+                slot = np.arange(len(c)) - np.repeat(p[:-1], lens); rix = np.repeat(np.arange(rows), lens)
+                ec[rix, slot] = c; ev[rix, slot] = v0
+                last = np.where(lens > 0, c[np.maximum(p[1:] - 1, 0)], 0)
+                pad = np.arange(L)[None, :] >= lens[:, None]
+                ec[pad] = np.broadcast_to(last[:, None], (rows, L))[pad]
+                with capi.Context() as ctx:
+                    ctx.upload_ell(rows, cols, L, ec.ravel(), ev.ravel())
+                    ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
+                    assert_bitexact(ctx.get_y(), want2, "seed %d ELLPACK L=%d" % (seed, L))
+            os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
+            with capi.Context(num_gpus=3, flags=capi.FLAG_PEER_GATHER | capi.FLAG_BALANCE_ENTRIES) as ctx:
+                ctx.upload_csr(rows, cols, p, c, v0)
+                ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
+                assert_close(ctx.get_y(), want2, scale2, what="seed %d three blocks" % seed)
+            os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
+            checked += 3
         if (seed - first) % 10 == 9:
             print("seeds %d..%d ok (%d multiplies checked)" % (first, seed, checked), flush=True)
     print("soak ok: %d multiplies" % checked)
