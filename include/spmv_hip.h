@@ -202,6 +202,11 @@ int spmv_hip_run(spmv_hip_ctx *ctx);
 /* Block until the stream is idle: must precede the harness's closing barrier
  * (src/profile-kernel.cpp:161). */
 int spmv_hip_sync(spmv_hip_ctx *ctx);
+/* --flush-caches on the device: what flush_cache(10 x the largest cache) does for the CPU between two timed runs
+ * (src/profile-kernel.cpp:181-192, :264).  Streams through a scratch buffer of four times the 256 MB Infinity Cache
+ * (allocated on first use) on every device of the context and waits, so that the next run finds neither its
+ * matrix nor its vectors in the L2 or the Infinity Cache.  Not part of a run; never timed. */
+int spmv_hip_flush_caches(spmv_hip_ctx *ctx);
 /* Device time of the last spmv_hip_run (hipEvent pair), valid after a sync. */
 int spmv_hip_last_run_ns(spmv_hip_ctx *ctx, uint64_t *kernel_ns);
 /* The same with the collective apart: kernel_ns = the slowest device's multiply, gather_ns

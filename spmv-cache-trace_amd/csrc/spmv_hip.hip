@@ -181,6 +181,7 @@ struct spmv_hip_ctx {
     int coo_panel_blocks = 0;
     bool ell_as_tiles = false; // ELLPACK runs as uniform CSR tiles (row-major, in place)
     bool as_csr = false;       // COO / hybrid were turned into one row-major matrix on the device: run = the CSR plan
+    double * d_flush = nullptr; // scratch of spmv_hip_flush_caches (4 x the Infinity Cache), allocated on first use
     bool y_borrowed = false;   // d_y points into memory owned by a multi-GPU front context
     double * borrowed_y = nullptr;
     // ---- multi-GPU front (spmv_hip_create_multi): parts[g] is an ordinary context on device g that holds
@@ -1482,6 +1483,7 @@ void spmv_hip_destroy(spmv_hip_ctx * c)
     if (c->own_stream)
         (void) hipStreamSynchronize(c->stream);
     free_ctx_matrix(c);
+    if (c->d_flush) (void) hipFree(c->d_flush);
     if (c->ev0) (void) hipEventDestroy(c->ev0);
     if (c->ev1) (void) hipEventDestroy(c->ev1);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
@@ -1989,6 +1991,31 @@ int spmv_hip_sync(spmv_hip_ctx * c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->multi)
         return multi_sync(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_flush_caches(spmv_hip_ctx * c)
+{
+    if (!c)
+        return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
+    if (c->multi) {
+        for (spmv_hip_ctx * part : c->parts) {
+            int rc = spmv_hip_flush_caches(part);
+            if (rc != 0)
+                return rc;
+        }
+        return SPMV_HIP_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n = 1LL << 27; // 2^27 doubles = 1 GiB: four times the 256 MB Infinity Cache
+    if (!c->d_flush)
+        HIP_TRY(hipMalloc((void **) &c->d_flush, (size_t) n * sizeof(double)));
+    // a = b + q * c over the halves of the scratch: reads 512 MiB, writes 512 MiB (values are irrelevant)
+    const long long n2 = n / 4; // 16-byte elements per array, two arrays read from the upper half
+    hipLaunchKernelGGL((spmv::triad_flat_kernel<kBlock, false>), dim3((unsigned) ((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, n2,
+                       c->d_flush, c->d_flush + n / 2, c->d_flush + n / 2, 0.0);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SPMV_HIP_OK;
 }

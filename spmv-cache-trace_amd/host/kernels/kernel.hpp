@@ -54,6 +54,9 @@ public:
     // Not pure: a Kernel written against the reference's header (src/kernels/kernel.hpp:18-45)
     // compiles against this one unchanged; it simply cannot take part in --check.
     virtual std::vector<double> result() const { throw kernel_error(name() + ": result() is not implemented"); }
+    // --flush-caches: what the kernel has to add to the harness's flush of the CPU caches (a device kernel evicts the
+    // device's caches); called by one thread between two timed runs, never inside the timed window.
+    virtual void flush_caches() {}
     // Replace x (default: all ones, src/kernels/csr-spmv.cpp:35) before prepare().
     virtual void set_x(std::vector<double> const &) { throw kernel_error(name() + ": set_x() is not implemented"); }
 };

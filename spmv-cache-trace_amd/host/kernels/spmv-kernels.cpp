@@ -333,6 +333,7 @@ public:
 
     MemoryReferenceString memory_reference_string(TraceConfig const &, int, int) const override { no_reference_string(); }
     std::uint64_t last_device_ns() const override { return device_ns; }
+    void flush_caches() override { check(spmv_hip_flush_caches(ctx), "flush_caches"); }
 
     std::vector<double> result() const override
     {

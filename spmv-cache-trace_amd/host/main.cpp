@@ -248,7 +248,7 @@ int main(int argc, char ** argv)
         {"threads", key_threads, "T", 0, "Use a generated configuration with T threads instead of --trace-config (0: the cores this process may use -- affinity mask capped by the cgroup quota)", 0},
         {"profile", key_profile, "N", 0, "Time N runs of the kernel", 0},
         {"warmup", key_warmup, nullptr, 0, "Accepted for compatibility (profiling always warms up once)", 0},
-        {"flush-caches", key_flush_caches, nullptr, 0, "Flush CPU caches between each profiling run", 0},
+        {"flush-caches", key_flush_caches, nullptr, 0, "Flush CPU caches between each profiling run (hip-* kernels: the device's L2 and Infinity Cache as well)", 0},
         {"list-perf-events", key_list_perf_events, nullptr, 0, "Not available (libpfm4 is not part of this build)", 0},
         {"verbose", key_verbose, nullptr, 0, "be more verbose", 0},
         {"write-mtx", key_write_mtx, "PATH", 0,

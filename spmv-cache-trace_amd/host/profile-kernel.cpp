@@ -138,8 +138,17 @@ Profiling profile_kernel(TraceConfig const & trace_config, Kernel & kernel, bool
         for (int run = 0; run < runs; ++run) {
             if (error.failed())
                 break; // uniform: the flag was last written before the previous barrier
-            if (flush_caches)
+            if (flush_caches) {
                 flush_cache(trace_config.max_cache_size());
+#pragma omp master
+                {
+                    try {
+                        kernel.flush_caches(); // a device kernel's own caches (no-op for the CPU kernels)
+                    } catch (...) {
+                        error.capture();
+                    }
+                }
+            }
 
             profiling_clock::time_point t0, t1;
 #pragma omp barrier

@@ -59,6 +59,7 @@ SIGNATURES = {
     "spmv_hip_get_y": (C.c_int, [_vp, _f64p]),
     "spmv_hip_run": (C.c_int, [_vp]),
     "spmv_hip_sync": (C.c_int, [_vp]),
+    "spmv_hip_flush_caches": (C.c_int, [_vp]),
     "spmv_hip_last_run_ns": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "spmv_hip_last_run_times": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "spmv_hip_ctx_info": (C.c_int, [_vp, _i64p, C.c_int]),
@@ -251,6 +252,10 @@ class Context:
             check(self.lib.spmv_hip_run(self.h))
         if sync:
             check(self.lib.spmv_hip_sync(self.h))
+
+    def flush_caches(self):
+        """Evict the device's L2 and Infinity Cache (the device side of --flush-caches)."""
+        check(self.lib.spmv_hip_flush_caches(self.h))
 
     def last_run_ns(self):
         ns = C.c_uint64(0)
