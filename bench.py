@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores visible to this process")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--cold", action="store_true",
+                    help="reference_protocol: a second CLI run with --flush-caches (the device's L2 and Infinity Cache evicted before "
+                         "every timed run) next to the warm one")
     ap.add_argument("--no-reference-protocol", action="store_true",
                     help="skip the extra run of the C++ CLI that times the multiply the reference's way (sync per run)")
     ap.add_argument("--events", choices=["launch", "region"], default="region",
@@ -288,7 +291,7 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None):
             "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3)}, parity
 
 
-def reference_protocol(args, fmt, runs):
+def reference_protocol(args, fmt, runs, flush=False):
     """The same multiply timed the reference's way (src/profile-kernel.cpp:137-179): the C++ CLI
     (host/main.cpp) loads or generates the matrix itself, uploads it through the C ABI, and times
     `runs` runs each bracketed by barriers with the device idle at both ends; --check compares y
@@ -301,6 +304,8 @@ def reference_protocol(args, fmt, runs):
            "--x", "uniform", "--check"]
     if args.expand_symmetric:
         cmd.append("--expand-symmetric")
+    if flush:
+        cmd.append("--flush-caches")
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -677,6 +682,10 @@ def main():
             rp = reference_protocol(args, fmt, 10 if big else 20)
             if rp is not None:
                 out["reference_protocol"] = rp
+                if args.cold and "error" not in rp:
+                    cold = reference_protocol(args, fmt, 10, flush=True)
+                    if cold is not None:
+                        rp["flushed"] = {k: cold.get(k) for k in ("command", "execution_time_ns", "gflops_median", "device_ns_last_run", "error") if k in cold}
         print(json.dumps(out), flush=True)
     finish(code, message)
 
