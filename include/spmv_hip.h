@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_VERSION 110 /* 1.1.0 */
+#define SPMV_HIP_VERSION 120 /* 1.2.0: peer gather, entry-balanced blocks, COO / ELLPACK in multi-GPU contexts, spmv_hip_flush_caches */
 
 /* ---- error codes ---------------------------------------------------------- */
 #define SPMV_HIP_OK 0
