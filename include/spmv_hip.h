@@ -71,7 +71,7 @@ extern "C" {
 #define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
                                             exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
-                                                kernel (default only for row_length > 256; shorter rows run in place
+                                                kernel (default only for row_length > 80; shorter rows run in place
                                                 as uniform wave tiles, one lane per row) */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);

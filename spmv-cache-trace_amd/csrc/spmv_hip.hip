@@ -67,6 +67,8 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
 #endif
     ;
 
+constexpr int kEllInPlaceMaxLength = 80;
+
 bool aligned16(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kBlock = 256;
@@ -1730,9 +1732,11 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     // kernel in place, one lane per row -- the reference's order -- with no transposed copy
     // (measured against the column-major kernel: L=5 202 vs 265 us, L=27 229 vs 285, L=81 337 vs 368).
     // Longer rows take the column-major one-lane-per-row kernel, which keeps the order for any length.
-    // (rows of more than half a tile get a tile -- or, beyond 512 entries, a wave -- to themselves and
-    // are still added up by one lane: the streams, not that lane, are what the time goes into)
-    c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR);
+    // Rows of more than kEllInPlaceMaxLength entries go through the column-major kernel after all: with one lane per
+    // row (the reference's order) a tile of such rows keeps a handful of lanes busy -- measured in place / column-major,
+    // fraction of the roofline: L = 65 0.70 / 0.64, L = 93 (queen-like) 0.56 / 0.66, L = 97 0.59 / 0.65, L = 301 0.20 / 0.65,
+    // L = 601 0.39 / 0.59 (profiles/r02_ell_row_lengths.log).
+    c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR) && row_length <= kEllInPlaceMaxLength;
     if (c->ell_as_tiles) {
         std::vector<int32_t> row_ptr((size_t) rows + 1);
         for (int32_t i = 0; i <= rows; ++i)

@@ -522,6 +522,12 @@ __device__ __forceinline__ void tile_products_shifted(
 // broadcast with v_readlane (len <= 64); the tile's index bytes go through the wave's LDS slice (two coalesced
 // dwords per lane in, the row's bytes out); the doubles come from the table and are added left to right from
 // +0.0: the reference's order, bit for bit.  Lanes own a second row 64 further on when the tile has more than 64.
+// A lane per row pays while the tile has rows for at least half the wave: rows of up to 16 entries (32+ rows per 512-entry
+// tile).  Longer rows reach this test only under SPMV_HIP_FLAG_EXACT_ORDER (ELLPACK): 33 entries per row would leave
+// 15 lanes gathering in seven dependent rounds -- measured on an ELLPACK band of 33: 199 us against 157 for the
+// entry-major path.
+constexpr int kLanePerRowMaxLen = 16;
+
 template <bool X32>
 __device__ __forceinline__ void tile_rows_uniform_indexed(
     double * prod, const int32_t * __restrict__ first_row, int first_row_base,
@@ -919,7 +925,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         }
         const int last = (k1 - 1 - kb) & ~3;
         if (VI && C16 && TILE == 512 && !PANELS && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kWave) {
+            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen) {
             // equally long shifted rows under a value dictionary: a lane per row, nothing parked in LDS
             const bool pattern = (meta & kTileMetaPattern) != 0;
             double zA, zB;
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             return;
         }
         if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kWave) {
+            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen) {
             const bool pattern = (meta & kTileMetaPattern) != 0;
             double zA, zB;
             tile_rows_uniform_values<QUADS, X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
