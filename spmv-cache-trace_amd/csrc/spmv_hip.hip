@@ -184,6 +184,8 @@ struct spmv_hip_ctx {
     bool ell_as_tiles = false; // ELLPACK runs as uniform CSR tiles (row-major, in place)
     bool as_csr = false;       // COO / hybrid were turned into one row-major matrix on the device: run = the CSR plan
     double * d_flush = nullptr; // scratch of spmv_hip_flush_caches (4 x the Infinity Cache), allocated on first use
+    bool ell_in_place_any_length = false; // set by upload_hybrid around its ELLPACK upload: the parts are merged into one
+                                          // row-major matrix afterwards, which wants the row-major arrays whatever the row length
     bool y_borrowed = false;   // d_y points into memory owned by a multi-GPU front context
     double * borrowed_y = nullptr;
     // ---- multi-GPU front (spmv_hip_create_multi): parts[g] is an ordinary context on device g that holds
@@ -1736,7 +1738,7 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     // row (the reference's order) a tile of such rows keeps a handful of lanes busy -- measured in place / column-major,
     // fraction of the roofline: L = 65 0.70 / 0.64, L = 93 (queen-like) 0.56 / 0.66, L = 97 0.59 / 0.65, L = 301 0.20 / 0.65,
     // L = 601 0.39 / 0.59 (profiles/r02_ell_row_lengths.log).
-    c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR) && row_length <= kEllInPlaceMaxLength;
+    c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR) && (row_length <= kEllInPlaceMaxLength || c->ell_in_place_any_length);
     if (c->ell_as_tiles) {
         std::vector<int32_t> row_ptr((size_t) rows + 1);
         for (int32_t i = 0; i <= rows; ++i)
@@ -1808,7 +1810,9 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
     // the ELL part is uploaded (validated) exactly like a plain ELLPACK matrix ...
+    c->ell_in_place_any_length = !(c->flags & (SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_EXACT_ORDER)); // ... to be merged below
     int rc = spmv_hip_upload_ell(c, rows, cols, ell_row_length, ell_column_index, ell_value);
+    c->ell_in_place_any_length = false;
     if (rc != 0)
         return rc;
     // ... and the COO remainder rides along; should that fail, the context is left without a matrix
