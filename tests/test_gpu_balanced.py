@@ -371,3 +371,30 @@ def test_lane_per_row_stencil_tiles_fuzz(oracle):
                     took_path += 1
                 plan.close()
     assert took_path >= 20  # the cases did exercise dictionary + shifted + uniform tiles
+
+
+def test_value_dictionary_out_of_place(oracle):
+    """y_out = y_in + A x (what the partitioned multiply uses) through the lane-per-row path with a two-value dictionary
+    held in registers and with a seven-value one in the LDS table: y_out bit for bit, y_in untouched."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rows, cols, p, c, v2 = synth.poisson2d(300)
+    rng = np.random.default_rng(9)
+    v7 = np.array([-1.0, 4.0, 0.5, -0.25, 2.0, 1e-3, -7.0])[rng.integers(0, 7, size=len(v2))]
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    for v in (v2, v7):
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=2)
+        tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, 0)
+        plan.compress(tc.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        assert plan.info()["indexed_values"] == len(np.unique(v))
+        yin = torch.from_numpy(y0.copy()).to(dev)
+        yout = torch.full((rows,), np.nan, dtype=torch.float64, device=dev)
+        plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), yin.data_ptr(), yout.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_bitexact(yout.cpu().numpy(), want, "y_out, %d values" % len(np.unique(v)))
+        assert_bitexact(yin.cpu().numpy(), y0, "y_in untouched")
+        plan.close()
