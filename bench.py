@@ -19,10 +19,12 @@ static chunk rule), x is replicated, and every step ends with ONE all-gather of 
 (RCCL): total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).  `roofline` prices
-the local SpMV kernel: algorithmic bytes of one launch divided by its
-mean duration measured with HIP events on the launch stream; next to that fraction it carries
-`frac_streamed` (the bytes the chosen tile classes really stream) and `frac_of_triad` (against
-the STREAM triad measured in the same process).  `cpu_baseline` (rank 0, N = 1 only) times the
+the local SpMV kernel: the bytes its plan streams per launch divided by the launch's mean duration
+measured with HIP events on the launch stream (`frac`, never above what HBM delivered); beside it
+`frac_algorithmic` (the algorithmic bytes of BASELINE.md section 3 -- what a plain CSR kernel would
+move; above `frac` exactly where the plan found a cheaper encoding), `frac_of_triad` (against the
+STREAM triad measured in the same process) and, when the matrix has a value dictionary,
+`general_values`: the same workload timed in the same process with its values read as doubles.  `cpu_baseline` (rank 0, N = 1 only) times the
 reference's own OpenMP kernel (oracle/_ref, kind "reference") or the C oracle (kind "port") on
 the host cores; the same leg is the parity gate (whole vector, 1e-10 relative).
 """
@@ -171,28 +173,34 @@ def host_cores():
     return n
 
 
-def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None):
+def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None, build=None):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_summary.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 + WRITE_SIZE, the
-    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
-    the figure is only reported when the summary was taken on the same kernel and workload, and
-    `traffic_source` names the file it comes from."""
+    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process,
+    so the figure is only reported when the summary was taken (a) on the same kernel and workload --
+    same algorithmic and streamed bytes -- and (b) with the same device code: the summary's bench
+    line carries `build.source_sha256` (hash of csrc/ + include/spmv_hip.h) and it must equal the
+    running library's.  Returns (bytes, file name, lib hash equal too?) or None."""
     import glob
     best = None
     seq = -1
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
-            rl = (d.get("bench_line") or {}).get("roofline", {})
+            bl = d.get("bench_line") or {}
+            rl = bl.get("roofline", {})
             if rl.get("algorithmic_bytes_per_launch") != algorithmic_bytes:
                 continue
             # the same tile classes too (a plan with and one without a value dictionary run different kernel variants)
             if streamed_bytes is not None and rl.get("streamed_bytes_per_launch") not in (None, streamed_bytes):
                 continue
+            theirs = bl.get("build") or {}
+            if not build or not theirs.get("source_sha256") or theirs["source_sha256"] != build.get("source_sha256"):
+                continue  # another binary (or a summary from before the stamp existed): not evidence for this one
             for k in d["kernels"]:
                 if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k and d.get("sequence", 0) > seq:
                     seq = d.get("sequence", 0)
-                    best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+                    best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f), theirs.get("lib_sha256") == build.get("lib_sha256"))
         except (OSError, ValueError, KeyError):
             continue
     return best
@@ -537,6 +545,46 @@ def main():
     except (RuntimeError, capi.SpmvHipError):
         triad_gbs = None
 
+    # ---- the same workload with its values read as 8-byte doubles (VERDICT r02 task 2) ------------------
+    # A value dictionary (<= 128 distinct values: this Poisson operator has two) lets the default plan stream one
+    # byte per entry instead of eight, so its time says little about how the kernel does on a matrix of the same
+    # shape with arbitrary values.  Same process, same device arrays, same K and warm-up: a second plan built with
+    # SPMV_HIP_FLAG_NO_VALUE_INDEX, timed with its own event pair, checked bit for bit against the default plan.
+    general = None
+    if fmt == "csr" and world == 1 and not use_dist and info["indexed_values"] > 0:
+        tp, tc, tv, tx = op._keep
+        plan_g = capi.CsrPlan(local_rows, cols, p, algo, args.lanes, flags | capi.FLAG_NO_VALUE_INDEX)
+        plan_g.compress(tc.data_ptr(), stream)
+        plan_g.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan_g.index_values(tv.data_ptr(), stream)  # a no-op under the flag; keeps the call sequence of on_gpu
+        yg = torch.zeros(local_rows, dtype=torch.float64, device=device)
+        ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), yg.data_ptr())
+        plan_g.spmv(*ptrs, stream)
+        torch.cuda.synchronize()
+        same = bool(y_check is not None and np.array_equal(yg.cpu().numpy(), y_check))
+        for _ in range(args.warmup):
+            plan_g.spmv(*ptrs, stream)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        g0.record()
+        for _ in range(args.steps):
+            plan_g.spmv(*ptrs, stream)
+        g1.record()
+        torch.cuda.synchronize()
+        g_s = g0.elapsed_time(g1) * 1e-3 / args.steps
+        ginfo = plan_g.info()
+        general = {"flag": "SPMV_HIP_FLAG_NO_VALUE_INDEX", "kernel_us": round(g_s * 1e6, 2),
+                   "gflops": round(2.0 * local_nnz / g_s / 1e9, 1),
+                   "frac_algorithmic": round(local_bytes / g_s / 1e9 / HBM_PEAK_GBS, 4),
+                   "streamed_bytes_per_launch": int(ginfo["streamed_bytes"]),
+                   "frac": round(ginfo["streamed_bytes"] / g_s / 1e9 / HBM_PEAK_GBS, 4),
+                   "frac_of_triad": round(ginfo["streamed_bytes"] / g_s / 1e9 / triad_gbs, 4) if triad_gbs else None,
+                   "value_dictionary_size": int(ginfo["indexed_values"]),
+                   "bitexact_vs_default_plan": same if y_check is not None else None,
+                   "events": "one pair around the %d timed launches, after %d warm-up launches" % (args.steps, args.warmup)}
+        plan_g.close()
+        del yg
+
     # N > 1: the collective on its own (after the timed region, not part of `value`): a few
     # blocking all-gathers, max over ranks, so the line shows where a step's time goes.
     gather_us = None
@@ -593,6 +641,8 @@ def main():
 
     code, message = 0, None
     if rank == 0:
+        from spmv_amd import buildinfo
+        build = buildinfo.build_info(capi.LIB_PATH)
         ms_per_step = elapsed_max / args.steps * 1e3
         gflops = 2.0 * nnz * args.steps / elapsed_max / 1e9
         kern_s = kern_ms_max * 1e-3  # slowest rank's mean launch duration
@@ -617,19 +667,26 @@ def main():
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],
                            "tiles_with_16bit_columns": info["narrow_tiles"], "column_panel_tiles": info["panel_tiles"]})
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # `frac` prices what the launch really moves: the bytes the plan's tile classes stream (values 8 B or 1 index
+        # byte, columns 4 / 2 / 0 B, row_ptr where it is read, y in and out, x once, descriptors): every one of them
+        # has to come out of or go into memory once per launch, so achieved <= what the memory system delivered.  The ALGORITHMIC figure of
+        # SURVEY 8d (12 B per entry + 20 per row + 8 per column, what a plain CSR kernel would have to move) stays
+        # beside it as frac_algorithmic: it says how fast the multiply is in the reference's terms and may exceed 1
+        # exactly when the plan found a cheaper encoding.
+        roofline = {"bound": "hbm", "achieved": round(streamed_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(streamed_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "kernel": kernel_name, "kernel_us": round(kern_s * 1e6, 2),
                     "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
                     "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
-                    "algorithmic_bytes_per_launch": int(local_bytes),
-                    # companions of `frac` (which prices the ALGORITHMIC bytes of SURVEY 8d and may exceed what the
-                    # kernel moves): the bytes the chosen tile classes stream, and the triad measured in this process
+                    "bytes_per_launch": int(streamed), "bytes_are": "streamed by the plan's tile classes (compulsory traffic of this launch)",
                     "streamed_bytes_per_launch": int(streamed),
-                    "streamed_gbs": round(streamed_gbs, 1), "frac_streamed": round(streamed_gbs / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_launch": int(local_bytes),
+                    "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
                     "triad_gbs": round(triad_gbs, 1) if triad_gbs else None,
                     "frac_of_triad": round(streamed_gbs / triad_gbs, 4) if triad_gbs else None,
                     "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)}
+        if general is not None:
+            roofline["general_values"] = general
         if fmt == "csr" and local_nnz > 0:
             roofline["share_of_entries_not_reading_column_index"] = round(info["shifted_entries"] / local_nnz, 4)
             roofline["share_of_entries_with_16bit_columns"] = round(info["narrow_entries"] / local_nnz, 4)
@@ -667,10 +724,17 @@ def main():
             out["gather_check"] = gather_check
             if not gather_check["pass"]:
                 code, message = 1, "bench.py: gathered y does not match the owning rank's rows"
-        tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"))
+        out["build"] = build
+        tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build)
         if tr:
             out["roofline"]["traffic"] = tr[0]
-            out["roofline"]["traffic_source"] = "profiles/" + tr[1] + " (rocprofv3 PMC of an earlier run of this workload, not of this process)"
+            out["roofline"]["traffic_over_bytes"] = round(tr[0] / max(1, int(streamed)), 3)
+            out["roofline"]["traffic_source"] = ("profiles/%s (rocprofv3 PMC passes of the same command on the same device code: "
+                                                 "source_sha256 %s matches%s)" % (tr[1], build["source_sha256"],
+                                                                                  "" if tr[2] else "; the .so was rebuilt from it since"))
+        else:
+            out["roofline"]["traffic_source"] = ("none: no committed profiles/*_summary.json of this workload was taken with device "
+                                                 "sources %s" % build["source_sha256"])
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, fmt, rows, cols, host_arrays, x, y_check)
             if out["parity"] and not out["parity"]["pass"]:

@@ -249,7 +249,11 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  * the same while the contents are not (an allocator reusing the address for another matrix), the plan
  * keeps a 64-bit checksum of the column array: it is re-computed and compared on the first multiply
  * after this call, on every multiply with SPMV_HIP_FLAG_VERIFY_PLAN, and by spmv_hip_plan_verify;
- * a mismatch is SPMV_HIP_ERR_STATE, never a silent wrong result.  Synchronises `stream`. */
+ * a mismatch is SPMV_HIP_ERR_STATE, never a silent wrong result.  Synchronises `stream`.
+ * THE FIRST MULTIPLY after this call (and after spmv_hip_plan_csr_index_values) therefore contains one checksum
+ * pass and a hipStreamSynchronize; call spmv_hip_plan_verify beforehand to have the check outside a timed or
+ * latency-sensitive first call.  The check is skipped (left pending) while `stream` is being captured into a
+ * graph.  Two host threads may share a plan: the pending check is claimed atomically by one of them. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
 /* Content guard on demand: SPMV_HIP_OK if d_column_index is not the array the plan was compressed from
  * (nothing derived will be used) or still has the same contents; SPMV_HIP_ERR_STATE if the contents

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -154,10 +155,10 @@ struct spmv_hip_plan {
     int nvalues = 0;                      // 0 = no dictionary
     const double * values_from = nullptr; // the value array it was made from
     unsigned long long value_checksum = 0;
-    bool verify_values_pending = false;
+    mutable std::atomic<bool> verify_values_pending{false}; // claimed (exchange) by the one multiply that re-checks
     // content guard: checksum of the column array the 16-bit stream and the tile marks were derived from
     unsigned long long column_checksum = 0;
-    bool verify_pending = false; // the first multiply after compress re-checks the checksum
+    mutable std::atomic<bool> verify_pending{false}; // the first multiply after compress re-checks the checksum
 };
 
 struct spmv_hip_ctx {
@@ -386,9 +387,8 @@ int device_value_checksum(const double * d_val, long long n, unsigned long long 
 }
 
 // the value dictionary belongs to ONE value array with ONE content: same rule as for the columns below
-int verify_plan_values(spmv_hip_plan * pl, const double * d_value, hipStream_t s)
+int verify_plan_values(const spmv_hip_plan * pl, const double * d_value, hipStream_t s)
 {
-    pl->verify_values_pending = false;
     if (pl->nvalues == 0 || pl->values_from != d_value)
         return SPMV_HIP_OK; // another array: its values are read as they are
     unsigned long long sum = 0;
@@ -405,9 +405,8 @@ int verify_plan_values(spmv_hip_plan * pl, const double * d_value, hipStream_t s
 // Pointer identity alone cannot tell a new matrix that an allocator placed at the old address, so
 // the contents are checked: on the first multiply after compress, on every multiply with
 // SPMV_HIP_FLAG_VERIFY_PLAN, and on demand (spmv_hip_plan_verify).
-int verify_plan(spmv_hip_plan * pl, const int32_t * d_column_index, hipStream_t s)
+int verify_plan(const spmv_hip_plan * pl, const int32_t * d_column_index, hipStream_t s)
 {
-    pl->verify_pending = false;
     if (!pl->d_col16 || pl->compressed_from != d_column_index)
         return SPMV_HIP_OK; // another array: the plan falls back to its 32-bit path, nothing derived is used
     unsigned long long sum = 0;
@@ -882,6 +881,7 @@ int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, voi
 {
     if (!pl)
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    pl->verify_pending = false; // an explicit check stands in for the first multiply's
     return verify_plan(pl, d_column_index, static_cast<hipStream_t>(stream));
 }
 
@@ -1149,15 +1149,30 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
             y_in = y;
         }
     }
-    if (pl->verify_pending || (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN)) {
-        int rc = verify_plan(const_cast<spmv_hip_plan *>(pl), j, s);
-        if (rc != SPMV_HIP_OK)
-            return rc;
-    }
-    if (pl->verify_values_pending || (pl->nvalues > 0 && (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN))) {
-        int rc = verify_plan_values(const_cast<spmv_hip_plan *>(pl), a, s);
-        if (rc != SPMV_HIP_OK)
-            return rc;
+    // One-time content check of the first multiply after compress / index_values (and every multiply under
+    // SPMV_HIP_FLAG_VERIFY_PLAN): a checksum pass + hipStreamSynchronize, documented in spmv_hip.h.  The pending
+    // marks are atomics claimed by exchange, so two host threads sharing a plan do not both run it, and the plan is
+    // not otherwise modified here; while the stream is being captured into a graph the check is left pending
+    // (a synchronize would invalidate the capture).
+    const bool every = (pl->flags & SPMV_HIP_FLAG_VERIFY_PLAN) != 0;
+    if (every || pl->verify_pending.load(std::memory_order_relaxed) || pl->verify_values_pending.load(std::memory_order_relaxed)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+            (void) hipGetLastError();
+            cap = hipStreamCaptureStatusNone;
+        }
+        if (cap == hipStreamCaptureStatusNone) {
+            if (pl->verify_pending.exchange(false) || every) {
+                int rc = verify_plan(pl, j, s);
+                if (rc != SPMV_HIP_OK)
+                    return rc;
+            }
+            if (pl->verify_values_pending.exchange(false) || (every && pl->nvalues > 0)) {
+                int rc = verify_plan_values(pl, a, s);
+                if (rc != SPMV_HIP_OK)
+                    return rc;
+            }
+        }
     }
     switch (pl->algorithm) {
     case SPMV_HIP_CSR_SCALAR:
@@ -2479,9 +2494,11 @@ int multi_run(spmv_hip_ctx * c)
         if (r != ncclSuccess || r2 != ncclSuccess)
             return multi_fail_nccl(c, r != ncclSuccess ? r : r2, "ncclAllGather");
     }
-    for (int g = 0; g < G; ++g) {
-        HIP_TRY(hipSetDevice(c->parts[(size_t) g]->device));
-        HIP_TRY(hipEventRecord(c->ev_gather[(size_t) g], c->parts[(size_t) g]->stream));
+    if (!(c->flags & SPMV_HIP_FLAG_NO_RUN_EVENTS)) {
+        for (int g = 0; g < G; ++g) {
+            HIP_TRY(hipSetDevice(c->parts[(size_t) g]->device));
+            HIP_TRY(hipEventRecord(c->ev_gather[(size_t) g], c->parts[(size_t) g]->stream));
+        }
     }
     c->timed = true;
     return SPMV_HIP_OK;
@@ -2501,6 +2518,8 @@ int multi_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns)
 {
     if (!c->timed)
         return fail(SPMV_HIP_ERR_STATE, "no run recorded");
+    if (c->flags & SPMV_HIP_FLAG_NO_RUN_EVENTS)
+        return fail(SPMV_HIP_ERR_STATE, "the context was created with SPMV_HIP_FLAG_NO_RUN_EVENTS: no run is timed");
     float kmax = 0.f, gmax = 0.f;
     for (size_t g = 0; g < c->parts.size(); ++g) {
         spmv_hip_ctx * part = c->parts[g];

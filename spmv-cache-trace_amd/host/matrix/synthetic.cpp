@@ -79,7 +79,9 @@ csr_matrix::Matrix build(long long rows_total, long long cols, long long rb, lon
 }
 
 // ---- poisson2d: the arrays of python/spmv_amd/synth.py poisson2d(), value for value --------------
-csr_matrix::Matrix poisson2d(long long n, long long rb, long long re, long long * total)
+// hashed != 0: the "pessimistic twin" -- same structure, every coefficient perturbed by a hash of its place (a
+// variable-coefficient operator: 84 M distinct values, so no value dictionary applies)
+csr_matrix::Matrix poisson2d(long long n, long long rb, long long re, long long * total, long long hashed = 0)
 {
     if (n < 1 || n > 46340)
         throw matrix::matrix_error("synthetic:poisson2d: grid edge must be in 1..46340");
@@ -90,22 +92,32 @@ csr_matrix::Matrix poisson2d(long long n, long long rb, long long re, long long 
         long long const i = r / n, j = r % n;
         return 1 + (i > 0) + (j > 0) + (j < n - 1) + (i < n - 1);
     };
-    auto fill = [n](long long r, index_type * c, double * v) {
+    auto fill = [n, hashed](long long r, index_type * c, double * v) {
         long long const i = r / n, j = r % n;
+        double * const v0 = v;
+        index_type * const c0 = c;
         if (i > 0) { *c++ = (index_type) (r - n); *v++ = -1.0; }
         if (j > 0) { *c++ = (index_type) (r - 1); *v++ = -1.0; }
         *c++ = (index_type) r; *v++ = 4.0;
         if (j < n - 1) { *c++ = (index_type) (r + 1); *v++ = -1.0; }
         if (i < n - 1) { *c++ = (index_type) (r + n); *v++ = -1.0; }
+        if (hashed)
+            for (long long q = 0; q < v - v0; ++q)
+                v0[q] *= 1.0 + 0.25 * u11(h2(0x9015507ull + (std::uint64_t) r, (std::uint64_t) c0[q]));
     };
     return build(N, N, rb, re, len, fill);
 }
 
 // ---- kkt: [H 0 A'; 0 R C'; A C 0], unknowns ordered states, controls, multipliers ----------------
-csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * total)
+// jitter_pct > 0: the "pessimistic twin" -- that share of the 27-point links of A (and, independently, of A') ends
+// 3 cells to either side of its grid neighbour, hashed per row, so that no two rows are shifted copies of each
+// other any more (the structure is then no longer exactly symmetric: only the multiply's access pattern matters)
+csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * total, long long jitter_pct = 0)
 {
     if (n < 1 || n > 1000)
         throw matrix::matrix_error("synthetic:kkt: grid edge must be in 1..1000");
+    if (jitter_pct < 0 || jitter_pct > 100)
+        throw matrix::matrix_error("synthetic:kkt:<n>,<jitter>: jitter is a percentage");
     long long const ny = n * n * n, nu = 6 * n * n, N = 2 * ny + nu;
     if (total) *total = N;
     if (re < 0) re = N;
@@ -136,7 +148,31 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
         default: return (u * n + v) * n + (n - 1);
         }
     };
+    // moves the jittered share of the columns [lo, hi) of a row's stencil part (which lie in [base, base + ny)),
+    // keeps them ascending and distinct
+    auto jitter = [=](long long r, index_type * lo, index_type * hi, long long base) {
+        if (jitter_pct == 0 || hi - lo < 2)
+            return;
+        for (index_type * q = lo; q < hi; ++q) {
+            std::uint64_t const h = h2(0x71773Eull + (std::uint64_t) r, (std::uint64_t) (q - lo));
+            if ((long long) (h % 100) < jitter_pct) {
+                long long t = (long long) *q + ((h >> 32) & 1 ? 3 : -3);
+                t = std::max(base, std::min(base + ny - 1, t));
+                *q = (index_type) t;
+            }
+        }
+        std::sort(lo, hi);
+        for (index_type * q = lo + 1; q < hi; ++q)
+            if (*q <= q[-1])
+                *q = q[-1] + 1;
+        if ((long long) hi[-1] > base + ny - 1) {
+            hi[-1] = (index_type) (base + ny - 1);
+            for (index_type * q = hi - 2; q >= lo && *q >= q[1]; --q)
+                *q = q[1] - 1;
+        }
+    };
     auto fill = [=](long long r, index_type * col, double * val) {
+        index_type * const col0 = col;
         if (r < ny) {
             long long const a = r / n2, b = (r / n) % n, c = r % n;
             *col++ = (index_type) r;
@@ -152,6 +188,7 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
                         *col++ = (index_type) (ny + nu + s);
                         *val++ = u11(h2(seedA, (std::uint64_t) (s * 27 + (26 - code)))); // A[s][r]
                     }
+            jitter(r, col0 + 1, col, ny + nu);
         } else if (r < ny + nu) {
             long long const k = r - ny;
             *col++ = (index_type) r;
@@ -170,6 +207,7 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
                         *col++ = (index_type) ((aa * n + bb) * n + cc);
                         *val++ = u11(h2(seedA, (std::uint64_t) (s * 27 + code))); // A[s][j]
                     }
+            jitter(r, col0, col, 0);
             long long const ks[6] = {a == 0 ? 0 * n2 + b * n + c : -1, a == n - 1 ? 1 * n2 + b * n + c : -1,
                                      b == 0 ? 2 * n2 + a * n + c : -1, b == n - 1 ? 3 * n2 + a * n + c : -1,
                                      c == 0 ? 4 * n2 + a * n + b : -1, c == n - 1 ? 5 * n2 + a * n + b : -1};
@@ -184,15 +222,17 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
 }
 
 // ---- queen: 3 unknowns per node of a jittered mesh, symmetric structure, dense 3x3 blocks ------------
-csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total)
+csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total, long long jitter_nodes = 3)
 {
-    long long const nodes = gx * gy * gz;
-    if (gx < 1 || gy < 1 || gz < 1 || nodes > 700000000LL)
+    if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
         throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
+    if (jitter_nodes < 3 || jitter_nodes > 4096)
+        throw matrix::matrix_error("synthetic:queen:gx,gy,gz,<J>: a jittered link ends J nodes away, 3 <= J <= 4096");
+    long long const nodes = gx * gy * gz;
     long long const N = 3 * nodes;
     if (total) *total = N;
     if (re < 0) re = N;
-    constexpr int J = 3; // a jittered link's far end is moved by J nodes
+    long long const J = jitter_nodes; // a jittered link's far end is moved by J nodes (3 by default; more = the pessimistic twin)
     std::uint64_t const seedJ = 0x51DE, seedQ = 0x0EE2;
     // the 13 "forward" neighbour offsets (x fastest); the other 13 are their mirror images
     int fd[13][3];
@@ -218,7 +258,7 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
     // interior node has 26 distinct neighbours like a node of a hexahedral mesh
     auto jit = [=](long long m, int k) {
         std::uint64_t const h = h2(seedJ, (std::uint64_t) (m * 13 + k));
-        return (h & 1) ? 0 : ((h & 2) ? J : -J);
+        return (h & 1) ? 0LL : ((h & 2) ? J : -J);
     };
     // neighbours of node n (itself included), ascending, no duplicates; returns their number (<= 13 + 13*5 + 1)
     auto neighbours = [=](long long n, long long * out) {
@@ -230,7 +270,7 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
                 if (t >= 0 && t < nodes && t != n)
                     out[c++] = t;
             }
-            for (int j = -J; j <= J; j += J) { // links that end at n
+            for (long long j = -J; j <= J; j += J) { // links that end at n
                 long long const m = n - foff[k] - j;
                 if (m >= 0 && m < nodes && m != n && inside(m, fd[k]) && jit(m, k) == j)
                     out[c++] = m;
@@ -464,28 +504,39 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
             throw matrix::matrix_error("synthetic matrix: row range out of bounds");
     };
     csr_matrix::Matrix A;
+    // every family's parameters are bounded BEFORE a row count is formed from them (a product of two numbers
+    // parsed from the command line overflows a signed 64-bit integer long before the generator refuses them)
     if (family == "poisson2d") {
-        if (v.size() != 1)
-            throw matrix::matrix_error("synthetic:poisson2d:<n> takes one number");
+        if (v.size() < 1 || v.size() > 2)
+            throw matrix::matrix_error("synthetic:poisson2d:<n>[,<hashed values 0|1>] takes one or two numbers");
+        if (v[0] < 1 || v[0] > 46340)
+            throw matrix::matrix_error("synthetic:poisson2d: grid edge must be in 1..46340");
         check_range(v[0] * v[0]);
-        A = poisson2d(v[0], rb, re, &tot);
+        A = poisson2d(v[0], rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "kkt") {
-        if (v.size() > 1)
-            throw matrix::matrix_error("synthetic:kkt[:<n>] takes at most one number");
+        if (v.size() > 2)
+            throw matrix::matrix_error("synthetic:kkt[:<n>[,<jitter %>]] takes at most two numbers");
         long long const n = v.empty() ? 200 : v[0];
+        if (n < 1 || n > 1000)
+            throw matrix::matrix_error("synthetic:kkt: grid edge must be in 1..1000");
         check_range(2 * n * n * n + 6 * n * n);
-        A = kkt(n, rb, re, &tot);
+        A = kkt(n, rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "queen") {
-        if (!v.empty() && v.size() != 3)
-            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz] takes three numbers");
+        if (!v.empty() && v.size() != 3 && v.size() != 4)
+            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz[,J]] takes three or four numbers");
         long long const gx = v.empty() ? 110 : v[0], gy = v.empty() ? 71 : v[1], gz = v.empty() ? 177 : v[2];
+        if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
+            throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
         check_range(3 * gx * gy * gz);
-        A = queen(gx, gy, gz, rb, re, &tot);
+        A = queen(gx, gy, gz, rb, re, &tot, v.size() > 3 ? v[3] : 3);
     } else if (family == "webbase" || family == "powerlaw") {
         bool const web = family == "webbase";
         if (v.size() > (web ? 4u : 3u))
             throw matrix::matrix_error("synthetic:" + family + ": too many parameters");
-        long long const N = v.size() > 0 ? v[0] : 1000005, Z = v.size() > 1 ? v[1] : (v.empty() ? 3105536 : 3 * N);
+        long long const N = v.size() > 0 ? v[0] : 1000005;
+        if (N < 2 || N > INT32_MAX)
+            throw matrix::matrix_error("synthetic:" + family + ": need 2 <= N <= 2^31-1");
+        long long const Z = v.size() > 1 ? v[1] : (v.empty() ? 3105536 : 3 * N);
         long long const maxrow = v.size() > 2 ? v[2] : std::min(4700LL, N);
         int const loc = web ? (v.size() > 3 ? (int) v[3] : 75) : 0;
         check_range(N);

@@ -7,15 +7,19 @@
 // of the specification (counter-based hashing, no thread-count dependence): the same spec gives
 // the same arrays everywhere, bit for bit.
 //
-//   synthetic:poisson2d:<n>          5-point stencil on an n x n grid (BASELINE configs[1]: n = 4096)
-//   synthetic:queen[:gx,gy,gz]       Queen_4147-like (configs[2]): 3 unknowns per node of a gx*gy*gz
+//   synthetic:poisson2d:<n>[,1]      5-point stencil on an n x n grid (BASELINE configs[1]: n = 4096); ",1" = the
+//                                    pessimistic twin: every coefficient perturbed by a hash (84 M distinct values)
+//   synthetic:queen[:gx,gy,gz[,J]]   Queen_4147-like (configs[2]): 3 unknowns per node of a gx*gy*gz
 //                                    mesh, half of whose 26 neighbour links are moved by 3 nodes,
 //                                    symmetric structure, dense 3x3 blocks, ~81 entries per row;
-//                                    default 110,71,177 -> N = 4 147 110, ~330 M entries
-//   synthetic:kkt[:<n>]              nlpkkt200-like (configs[3]): KKT matrix [H 0 A'; 0 R C'; A C 0]
+//                                    default 110,71,177 -> N = 4 147 110, ~330 M entries; J (default 3) = how far a
+//                                    moved link ends from its grid neighbour (twin: 6)
+//   synthetic:kkt[:<n>[,<jitter %>]] nlpkkt200-like (configs[3]): KKT matrix [H 0 A'; 0 R C'; A C 0]
 //                                    of a boundary-control problem on an n^3 grid, A = 27-point
 //                                    operator; N = 2n^3 + 6n^2 (n = 200: 16 240 000), ~436 M entries,
-//                                    two row populations (28 and <= 30 entries) plus 2-entry control rows
+//                                    two row populations (28 and <= 30 entries) plus 2-entry control rows;
+//                                    jitter (default 0): that share of the stencil links is moved by 3 cells, hashed
+//                                    per row, so that no interior row is a shifted copy of its neighbour (twin: 50)
 //   synthetic:webbase[:N,Z,maxrow,locality%]
 //                                    webbase-1M-like (configs[4]): power-law row lengths (every row
 //                                    >= 1 entry, longest = maxrow, exactly Z entries), `locality` per

@@ -103,22 +103,29 @@ class DistributedCsrSpmv:
             # ... and so does the value dictionary of a matrix with few distinct values (same lifetime argument)
             plan.index_values(tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
-        # The launch itself is one foreign call with everything resolved beforehand (device addresses, the
-        # stream, the plan handle): a rank-local multiply of a partitioned matrix lasts 20-30 us, and ten
-        # attribute look-ups per step on the host would leave the launch queue empty in between.
+        # The launch itself is one foreign call with everything resolved beforehand (device addresses, the plan
+        # handle): a rank-local multiply of a partitioned matrix lasts 20-30 us, and ten attribute look-ups per
+        # step on the host would leave the launch queue empty in between.  The STREAM is looked up on every call:
+        # the collectives order themselves against torch's current stream at call time, so the multiply must be
+        # enqueued on that same stream or a gather could send a segment that is not finished
+        # (torch._C._cuda_getCurrentRawStream: one C call, no Python stream object).
         fn, handle = plan.lib.spmv_hip_csr_spmv_out, plan.h
         fixed = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr())
-        stream = torch.cuda.current_stream().cuda_stream
-        addr = {}
-
-        def ptr(t):
-            a = addr.get(id(t))
-            if a is None:
-                a = addr[id(t)] = t.data_ptr()
-            return a
+        dev_index = torch.device(device).index
+        if dev_index is None:
+            dev_index = torch.cuda.current_device()
+        raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw_stream is None:
+            def raw_stream(i):
+                return torch.cuda.current_stream(i).cuda_stream
+        # device addresses are cached for the segment views only (they live as long as this object, so neither
+        # their addresses nor their ids can be reused); any other tensor is asked for its address every time
+        seg_addr = {}
 
         def local_spmv_out(y_in, y_out):
-            rc = fn(handle, fixed[0], fixed[1], fixed[2], fixed[3], ptr(y_in), ptr(y_out), stream)
+            a_in = seg_addr.get(id(y_in)) or y_in.data_ptr()
+            a_out = seg_addr.get(id(y_out)) or y_out.data_ptr()
+            rc = fn(handle, fixed[0], fixed[1], fixed[2], fixed[3], a_in, a_out, raw_stream(dev_index))
             if rc != 0:
                 capi.check(rc)
 
@@ -129,8 +136,9 @@ class DistributedCsrSpmv:
                    local_spmv_out=local_spmv_out, pingpong=pingpong)
         self.plan = plan
         self._keep = (tp, tc, tv, tx)
-        for t in self.seg:  # the segment views live as long as this object: their addresses may be cached
-            ptr(t)
+        self._seg_keep = list(self.seg)  # pins the ids the cache is keyed by
+        for t in self._seg_keep:
+            seg_addr[id(t)] = t.data_ptr()
         return self
 
     @property
