@@ -62,7 +62,9 @@ extern "C" {
 /* plan / ctx flags */
 #define SPMV_HIP_FLAG_XCD_REMAP 0x1u   /* give each XCD one contiguous run of tiles instead of the round-robin
                                            deal (measured SLOWER on MI355X for streaming SpMV: off by default) */
-#define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows) */
+#define SPMV_HIP_FLAG_EXACT_ORDER 0x2u  /* force one lane per row everywhere (bit-exact, slower on long rows); for ELLPACK
+                                           uploads: rows of more than 16 entries too (default: 2..64 lanes per such row,
+                                           1e-10 class; rows of <= 16 entries are bit-exact either way) */
 #define SPMV_HIP_FLAG_NO_INDEX_COMPRESSION 0x10u /* ctx: keep 32-bit column indices for every tile */
 #define SPMV_HIP_FLAG_COO_KEEP_ORDER 0x20u /* ctx: keep COO triplets in file order on the device */
 #define SPMV_HIP_FLAG_READ_ROW_PTR 0x40u /* wavetile: read row_ptr even for tiles whose rows are all equally long
@@ -71,8 +73,9 @@ extern "C" {
 #define SPMV_HIP_FLAG_ROWS128 0x100u     /* ... or up to 128 (lanes own two short rows); default: 128 once the matrix
                                             exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
-                                                kernel (default only for row_length > 80; shorter rows run in place
-                                                as uniform wave tiles, one lane per row) */
+                                                kernel (bit-exact for any row length).  Default: the row-major arrays in
+                                                place as uniform wave tiles; with SPMV_HIP_FLAG_EXACT_ORDER the
+                                                column-major kernel takes rows of more than 80 entries */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
@@ -108,6 +111,10 @@ extern "C" {
                                              the reference's ceil(rows / G) rows per device; y slots are as long as
                                              the longest block.  For matrices whose row lengths differ between the
                                              top and the bottom (a KKT system's two row populations). */
+#define SPMV_HIP_FLAG_NO_SEGMENT_WINDOW 0x800000u /* plan_csr_compress: no segment windows (x staged through LDS per block of 32
+                                             tiles in up to 8 far-apart column segments: rows of a 3-D mesh in natural
+                                             ordering, KKT systems; the tiles' 16-bit column stream then holds window
+                                             slots).  Unstructured bands fall back to the one-ring block window. */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -305,7 +312,9 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [15] stored entries in shifted tiles  [16] stored entries in 16-bit tiles
  *        [17] rows in uniform tiles  [18] 1 if the plan holds a snapshot of the values (column panels)
  *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES)
- *        [20] size of the value dictionary (0 = none; see spmv_hip_plan_csr_index_values) */
+ *        [20] size of the value dictionary (0 = none; see spmv_hip_plan_csr_index_values)
+ *        [21] tiles multiplied by the segment-window kernel (a subset of [12]; x staged through LDS per block of 32 tiles
+ *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

@@ -1,0 +1,892 @@
+// plan_csr.hip -- CSR launch plans (Level 2 of include/spmv_hip.h): wave tiles from the host row_ptr, tile classes
+// from the device columns (16-bit columns, shifted tiles, patterns, x windows, block / segment windows), column
+// panels, the value dictionary, and the content guards that tie a plan to the arrays it was derived from.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+#include <utility>
+
+using namespace spmvi;
+
+namespace spmvi {
+
+// flags[0]: an index outside [0, limit); flags[1] (if asked): not non-decreasing
+int device_index_check(const int32_t * d_idx, long long n, int limit, bool want_sorted, bool * bad, bool * sorted, hipStream_t s)
+{
+    *bad = false;
+    if (sorted)
+        *sorted = true;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    int * d_flags = nullptr;
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMalloc((void **) &d_flags, sizeof(flags)));
+    hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(flags), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::index_check_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, limit,
+                           d_idx, d_flags, want_sorted ? 1 : 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_flags);
+    if (e != hipSuccess)
+        return fail_hip(e, "index check");
+    *bad = flags[0] != 0;
+    if (sorted)
+        *sorted = flags[1] == 0;
+    return SPMV_HIP_OK;
+}
+
+int device_column_checksum(const int32_t * d_col, long long n, unsigned long long * out, hipStream_t s)
+{
+    *out = 0;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    unsigned long long * d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_sum, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::column_checksum_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, d_col, d_sum);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_sum);
+    return e == hipSuccess ? SPMV_HIP_OK : fail_hip(e, "column checksum");
+}
+
+int device_value_checksum(const double * d_val, long long n, unsigned long long * out, hipStream_t s)
+{
+    *out = 0;
+    if (n <= 0)
+        return SPMV_HIP_OK;
+    unsigned long long * d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_sum, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::value_checksum_kernel, dim3((unsigned) grid_for(n, kBlock, cu_count() * 16)), dim3(256), 0, s, n, d_val, d_sum);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(d_sum);
+    return e == hipSuccess ? SPMV_HIP_OK : fail_hip(e, "value checksum");
+}
+
+// the value dictionary belongs to ONE value array with ONE content: same rule as for the columns below
+int verify_plan_values(const spmv_hip_plan * pl, const double * d_value, hipStream_t s)
+{
+    if (pl->nvalues == 0 || pl->values_from != d_value)
+        return SPMV_HIP_OK; // another array: its values are read as they are
+    unsigned long long sum = 0;
+    int rc = device_value_checksum(d_value, pl->nnz, &sum, s);
+    if (rc != SPMV_HIP_OK)
+        return rc;
+    if (sum != pl->value_checksum)
+        return fail(SPMV_HIP_ERR_STATE, "the value array changed since spmv_hip_plan_csr_index_values: call "
+                                        "spmv_hip_plan_csr_refresh_values after changing values");
+    return SPMV_HIP_OK;
+}
+
+// The plan's derived data (16-bit column stream, tile marks, patterns) belong to ONE column array.
+// Pointer identity alone cannot tell a new matrix that an allocator placed at the old address, so
+// the contents are checked: on the first multiply after compress, on every multiply with
+// SPMV_HIP_FLAG_VERIFY_PLAN, and on demand (spmv_hip_plan_verify).
+int verify_plan(const spmv_hip_plan * pl, const int32_t * d_column_index, hipStream_t s)
+{
+    if (!pl->d_col16 || pl->compressed_from != d_column_index)
+        return SPMV_HIP_OK; // another array: the plan falls back to its 32-bit path, nothing derived is used
+    unsigned long long sum = 0;
+    int rc = device_column_checksum(d_column_index, pl->nnz, &sum, s);
+    if (rc != SPMV_HIP_OK)
+        return rc;
+    if (sum != pl->column_checksum)
+        return fail(SPMV_HIP_ERR_STATE, "the column array at this address is not the one the plan was compressed from "
+                                        "(contents changed): make a new plan");
+    return SPMV_HIP_OK;
+}
+
+// Bytes one multiply streams with the tile classes chosen (bookkeeping for the roofline report):
+// values 8 B per entry; columns 4 B (wide), 2 B (16-bit), one first row (shifted) or nothing
+// (shifted with a pattern); row_ptr 4 B per row of a non-uniform tile; y 16 B per row; x once;
+// 16 B of descriptor per tile.
+int plan_account(spmv_hip_plan * pl, bool compressed)
+{
+    const long long algorithmic = 12LL * pl->nnz + 4LL * (pl->rows + 1LL) + 16LL * pl->rows + 8LL * pl->cols;
+    pl->streamed_bytes = algorithmic;
+    pl->shifted_entries = pl->narrow_entries = pl->uniform_rows = 0;
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0)
+        return SPMV_HIP_OK;
+    std::vector<int4> d((size_t) pl->ntiles + 1);
+    HIP_TRY(hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost));
+    long long bytes = 8LL * pl->cols;
+    for (int w = 0; w < pl->ntiles; ++w) {
+        const long long entries = (long long) d[(size_t) w + 1].y - d[(size_t) w].y;
+        const long long rows = (long long) (d[(size_t) w + 1].x & 0x7FFFFFFF) - (d[(size_t) w].x & 0x7FFFFFFF);
+        const int meta = d[(size_t) w].z;
+        const bool stream_tile = !(d[(size_t) w].x & 0x80000000) && entries > 0 && (meta & spmv::kTileMetaFast);
+        const bool shifted = compressed && stream_tile && (meta & spmv::kTileMetaShifted);
+        const bool narrow = compressed && stream_tile && (meta & spmv::kTileMetaNarrow);
+        const bool uniform = stream_tile && (meta & spmv::kTileMetaUniform);
+        long long col_bytes = 4 * entries;
+        if (shifted) {
+            col_bytes = (meta & spmv::kTileMetaPattern) ? 0 : 4LL * (meta & 0xFFFF);
+            pl->shifted_entries += entries;
+        } else if (narrow || (compressed && stream_tile && (meta & spmv::kTileMetaBlockWin))) {
+            col_bytes = 2 * entries; // 16-bit offsets from the tile's base, or window slots (segment windows: any column range)
+            pl->narrow_entries += entries;
+        }
+        if (uniform)
+            pl->uniform_rows += rows;
+        // with a value dictionary the stream tiles of the default kernel read one byte per entry
+        const long long val_bytes = (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
+        bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+    }
+    pl->streamed_bytes = bytes;
+    return SPMV_HIP_OK;
+}
+
+} // namespace spmvi
+
+namespace {
+
+int pick_lanes(double mean_len)
+{
+    int l = 2;
+    while (l < 64 && l < mean_len)
+        l *= 2;
+    return l;
+}
+
+} // namespace
+
+extern "C" {
+
+/* ================================ Level 2 ======================================= */
+
+int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
+                      int algorithm, int lanes_per_row, unsigned flags)
+{
+    return plan_csr_internal(out, rows, cols, p, algorithm, lanes_per_row, flags, 0);
+}
+
+} // extern "C"
+
+// break_rows > 0: no tile may contain a row index that is a multiple of break_rows except as its
+// first row (column panels: tiles stay inside one panel)
+namespace spmvi {
+int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const int32_t * p,
+                             int algorithm, int lanes_per_row, unsigned flags, int32_t break_rows)
+{
+    if (!out)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    *out = nullptr;
+    if (rows < 0 || cols < 0 || !p)
+        return fail(SPMV_HIP_ERR_INVALID, "rows/cols negative or row_ptr null");
+    if (p[0] < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] is negative");
+    for (int32_t r = 0; r < rows; ++r)
+        if (p[r + 1] < p[r])
+            return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
+    if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_WAVETILE)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
+    if (flags & ~kKnownFlags)
+        return fail(SPMV_HIP_ERR_INVALID, "unknown flag bits");
+    if (lanes_per_row != 0 &&
+        (lanes_per_row < 2 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1))))
+        return fail(SPMV_HIP_ERR_INVALID, "lanes_per_row must be 0 or a power of two in 2..64");
+
+    spmv_hip_plan * pl = new (std::nothrow) spmv_hip_plan;
+    if (!pl)
+        return fail(SPMV_HIP_ERR_ALLOC, "plan allocation failed");
+    pl->rows = rows;
+    pl->cols = cols;
+    pl->nnz = p[rows];
+    pl->flags = flags;
+    const double mean = rows > 0 ? double(p[rows] - p[0]) / rows : 0.0;
+
+    if (algorithm == SPMV_HIP_CSR_AUTO)
+        algorithm = SPMV_HIP_CSR_WAVETILE;
+    if (flags & SPMV_HIP_FLAG_EXACT_ORDER) {
+        if (algorithm == SPMV_HIP_CSR_VECTOR)
+            algorithm = SPMV_HIP_CSR_WAVETILE;
+    }
+    pl->algorithm = algorithm;
+
+    if (algorithm == SPMV_HIP_CSR_SCALAR) {
+        pl->workgroups = grid_for(rows, kBlock);
+    } else if (algorithm == SPMV_HIP_CSR_VECTOR) {
+        pl->lanes_per_row = lanes_per_row ? lanes_per_row : pick_lanes(mean);
+        pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, cu_count() * 32);
+    } else if (algorithm == SPMV_HIP_CSR_WAVETILE) {
+        // wave tiles: <= 64 rows and <= tile entries (from the 4-aligned start) per wave
+        const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
+        const bool exact = (flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
+        pl->tile = tile;
+        std::vector<int4> desc;
+        desc.reserve((size_t) rows / 48 + 16);
+        int32_t r = 0;
+        int next_panel = 0;
+        long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
+        while (r < rows) {
+            if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
+                while (next_panel <= 8 && next_panel <= r / break_rows)
+                    pl->pinfo.first[next_panel++] = (int) desc.size();
+            const int32_t kb = p[r] & ~3;
+            int32_t r1 = r;
+            int32_t maxlen = 0, minlen = INT32_MAX;
+            // rows per tile: 128 (two short rows per lane, fuller quads) pays once the matrix streams from
+            // HBM (twice the 256 MiB Infinity Cache); below that more, smaller tiles win (measured:
+            // Poisson 4096^2 223 vs 238 us, half of it 103 vs 107 us, a quarter 48 vs 43 us, 2048^2 57 vs 50 us)
+            const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
+            const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
+                : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 512e6 ? 128 : 64);
+            // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
+            // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
+            // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
+            auto lanes_for = [](int len) {
+                int l = 0;
+                while (l < 6 && (16 << l) < len)
+                    ++l;
+                return l;
+            };
+            while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
+                if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
+                    break;
+                const int len = p[r1 + 1] - p[r1];
+                if (!exact && r1 > r) {
+                    const int l = lanes_for(std::max(maxlen, len));
+                    if (l > 0 && ((r1 - r + 1) << l) > 64)
+                        break;
+                }
+                maxlen = std::max(maxlen, len);
+                minlen = std::min(minlen, len);
+                ++r1;
+            }
+            if (r1 == r) { // one row longer than a tile
+                const long long len = (long long) p[r + 1] - p[r];
+                pl->long_blocks++;
+                if (!exact && len > kSplitThreshold) {
+                    pl->split_rows++;
+                    for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                        desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+                } else {
+                    desc.push_back(make_int4(r, p[r], 0, 0));
+                }
+                r1 = r + 1;
+            } else {
+                // one lane per row (rows of <= 16 entries) keeps the reference's summation order
+                const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
+                pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+                // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
+                const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+                const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
+                if (uniform)
+                    pl->uniform_tiles++;
+                stream_tiles++;
+                stream_tile_entries += (long long) p[r1] - p[r];
+                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
+                                                      (uniform ? (1 << 26) : 0), 0));
+            }
+            r = r1;
+        }
+        // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
+        // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
+        // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
+        // Regular matrices (every tile already full, or only short rows) keep the tiles above and with
+        // them the reference's summation order.
+        {
+            int longest = 0;
+            for (int32_t q = 0; q < rows; ++q)
+                longest = std::max(longest, (int) (p[q + 1] - p[q]));
+            // (rows with a wave or more to themselves are the same in both tilings and do not count)
+            const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
+                && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
+            if (want) {
+                desc.clear();
+                pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
+                r = 0;
+                while (r < rows) {
+                    const int32_t kb = p[r] & ~3;
+                    int32_t r1 = r;
+                    int32_t maxlen = 0;
+                    while (r1 < rows && (r1 - r) < spmv::kSegMaxRows && (long long) p[r1 + 1] - kb <= tile) {
+                        maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
+                        ++r1;
+                    }
+                    if (r1 == r) { // one row longer than a tile
+                        const long long len = (long long) p[r + 1] - p[r];
+                        pl->long_blocks++;
+                        if (len > kSplitThreshold) {
+                            pl->split_rows++;
+                            for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                                desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+                        } else {
+                            desc.push_back(make_int4(r, p[r], 0, 0));
+                        }
+                        r1 = r + 1;
+                    } else {
+                        pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+                        const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+                        desc.push_back(make_int4(r, p[r], maxlen | (fast ? (1 << 25) : 0) | spmv::kTileMetaSeg, 0));
+                    }
+                    r = r1;
+                }
+                pl->balanced = true;
+            }
+        }
+        pl->ntiles = (int) desc.size();
+        if (break_rows > 0) {
+            while (next_panel <= 8)
+                pl->pinfo.first[next_panel++] = pl->ntiles;
+            pl->pinfo.rows = break_rows;
+        }
+        desc.push_back(make_int4(rows, p[rows], 0, 0));
+        pl->nblk = pl->ntiles;
+        pl->workgroups = (pl->ntiles + 3) / 4;
+        if (pl->ntiles > 0) {
+            pl->meta_bytes = desc.size() * sizeof(int4);
+            hipError_t e = hipMalloc((void **) &pl->d_tiles, pl->meta_bytes);
+            if (e == hipSuccess)
+                e = hipMemcpy(pl->d_tiles, desc.data(), pl->meta_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                int rc = fail_hip(e, "plan metadata upload");
+                if (pl->d_tiles)
+                    (void) hipFree(pl->d_tiles);
+                delete pl;
+                return rc;
+            }
+        }
+    } else {
+        // adaptive: cut rows into blocks of <= kTile entries (from the 4-aligned
+        // start of the block's first row) and <= kBlock rows
+        std::vector<int32_t> blk;
+        blk.reserve((size_t) rows / 64 + 16);
+        blk.push_back(0);
+        int32_t r = 0;
+        while (r < rows) {
+            const int32_t kb = p[r] & ~3;
+            int32_t r1 = r;
+            while (r1 < rows && (r1 - r) < kBlock && (long long) p[r1 + 1] - kb <= kTile)
+                ++r1;
+            if (r1 == r) { // one row longer than a tile
+                r1 = r + 1;
+                pl->long_blocks++;
+            }
+            blk.push_back(r1);
+            r = r1;
+        }
+        pl->nblk = (int) blk.size() - 1;
+        pl->workgroups = pl->nblk;
+        if (pl->nblk > 0) {
+            pl->meta_bytes = blk.size() * sizeof(int32_t);
+            hipError_t e = hipMalloc((void **) &pl->d_blk_row, pl->meta_bytes);
+            if (e == hipSuccess)
+                e = hipMemcpy(pl->d_blk_row, blk.data(), pl->meta_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                int rc = fail_hip(e, "plan metadata upload");
+                if (pl->d_blk_row)
+                    (void) hipFree(pl->d_blk_row);
+                delete pl;
+                return rc;
+            }
+        }
+    }
+    int rc_acc = plan_account(pl, false);
+    if (rc_acc != SPMV_HIP_OK) {
+        spmv_hip_plan_destroy(pl);
+        return rc_acc;
+    }
+    *out = pl;
+    return SPMV_HIP_OK;
+}
+
+} // namespace spmvi
+
+extern "C" {
+
+void spmv_hip_plan_destroy(spmv_hip_plan * pl)
+{
+    if (!pl)
+        return;
+    if (pl->d_blk_row)
+        (void) hipFree(pl->d_blk_row);
+    if (pl->d_tiles)
+        (void) hipFree(pl->d_tiles);
+    if (pl->d_col16)
+        (void) hipFree(pl->d_col16);
+    if (pl->d_patterns)
+        (void) hipFree(pl->d_patterns);
+    if (pl->d_blocks)
+        (void) hipFree(pl->d_blocks);
+    if (pl->d_segblocks)
+        (void) hipFree(pl->d_segblocks);
+    if (pl->d_vidx)
+        (void) hipFree(pl->d_vidx);
+    if (pl->d_vtab)
+        (void) hipFree(pl->d_vtab);
+    if (pl->inner)
+        spmv_hip_plan_destroy(pl->inner);
+    if (pl->d_vrow_ptr)
+        (void) hipFree(pl->d_vrow_ptr);
+    if (pl->d_pcol)
+        (void) hipFree(pl->d_pcol);
+    if (pl->d_pval)
+        (void) hipFree(pl->d_pval);
+    delete pl;
+}
+
+int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0 || pl->nnz == 0)
+        return SPMV_HIP_OK; // nothing to compress for the other algorithms
+    if (!d_column_index)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (pl->d_col16)
+        return fail(SPMV_HIP_ERR_STATE, "plan is already compressed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
+    const bool want_patterns = !(pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES);
+    int * d_count = nullptr;
+    unsigned long long * d_fp = nullptr;
+    HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
+    int counts[5] = {0, 0, 0, 0, 0};
+    hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
+    if (e == hipSuccess && want_patterns) {
+        e = hipMalloc((void **) &d_fp, (size_t) pl->ntiles * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d_fp, 0, (size_t) pl->ntiles * sizeof(unsigned long long), s);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
+                           pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
+                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp, std::max(1, (pl->cols + 7) / 8));
+        e = hipGetLastError();
+    }
+    // patterns: the shifted tiles' shape fingerprints come back to the host, the most frequent
+    // shapes become patterns, and the tiles that really have one of those shapes are marked
+    // (first-row columns from the pattern; a window of runs where it pays)
+    if (e == hipSuccess && d_fp) {
+        std::vector<unsigned long long> fp((size_t) pl->ntiles);
+        e = hipMemcpyAsync(fp.data(), d_fp, fp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        std::vector<std::pair<unsigned long long, std::pair<int, int>>> shapes; // fingerprint, (count, first tile)
+        if (e == hipSuccess) {
+            std::unordered_map<unsigned long long, size_t> index;
+            for (int w = 0; w < pl->ntiles; ++w) {
+                if (!fp[(size_t) w])
+                    continue;
+                auto it = index.find(fp[(size_t) w]);
+                if (it == index.end()) {
+                    index.emplace(fp[(size_t) w], shapes.size());
+                    shapes.push_back({fp[(size_t) w], {1, w}});
+                } else {
+                    shapes[it->second].second.first++;
+                }
+            }
+            std::sort(shapes.begin(), shapes.end(),
+                      [](auto const & a, auto const & b) { return a.second.first > b.second.first; });
+            if (shapes.size() > (size_t) spmv::kMaxPatterns)
+                shapes.resize((size_t) spmv::kMaxPatterns);
+        }
+        if (e == hipSuccess && !shapes.empty()) {
+            const int np = (int) shapes.size();
+            std::vector<int> rep((size_t) np);
+            std::vector<unsigned long long> pfp((size_t) np);
+            for (int i = 0; i < np; ++i) {
+                rep[(size_t) i] = shapes[(size_t) i].second.second;
+                pfp[(size_t) i] = shapes[(size_t) i].first;
+            }
+            int * d_rep = nullptr;
+            unsigned long long * d_pfp = nullptr;
+            const size_t pat_bytes = (size_t) np * spmv::kPatStride * sizeof(int32_t);
+            e = hipMalloc((void **) &pl->d_patterns, pat_bytes);
+            if (e == hipSuccess) e = hipMalloc((void **) &d_rep, (size_t) np * sizeof(int));
+            if (e == hipSuccess) e = hipMalloc((void **) &d_pfp, (size_t) np * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_rep, rep.data(), (size_t) np * sizeof(int), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_pfp, pfp.data(), (size_t) np * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::csr_pattern_build_kernel, dim3(np), dim3(64), 0, s, d_rep, pl->d_tiles,
+                                   d_column_index, pl->d_patterns);
+                hipLaunchKernelGGL(spmv::csr_pattern_assign_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
+                                   pl->ntiles, pl->d_tiles, d_column_index, d_fp, d_pfp, np, pl->d_patterns, d_count);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (d_rep) (void) hipFree(d_rep);
+            if (d_pfp) (void) hipFree(d_pfp);
+            if (e == hipSuccess) {
+                pl->npatterns = np;
+                pl->meta_bytes += pat_bytes;
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    pl->narrow_tiles = counts[0];
+    pl->shifted_tiles = counts[1];
+    pl->xwin_tiles = counts[2];
+    pl->spread_tiles = counts[4];
+    // segment windows (x staged through LDS per block of 32 tiles, in up to 8 far-apart column segments: meshes in
+    // natural ordering, KKT systems) for what has no cheaper path: first count the tiles that would qualify, and
+    // only if they are the majority mark them and rewrite their 16-bit column stream to window slots
+    if (e == hipSuccess && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * 32
+        && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
+        int per_block = 32, max_slots = 4096;
+#ifdef SPMV_HIP_EXPERIMENTS
+        if (const char * v = std::getenv("SPMV_HIP_SEGWIN_TILES")) per_block = std::max(8, std::min(256, std::atoi(v)));
+        if (const char * v = std::getenv("SPMV_HIP_SEGWIN_SLOTS")) max_slots = std::max(512, std::min(4096, std::atoi(v)));
+#endif
+        const int nb = (pl->ntiles + per_block - 1) / per_block;
+        int shift = 0; // columns per bitmap bit = 2^shift: the whole column space in 65536 bits
+        while (((long long) pl->cols - 1) >> shift >= 65536)
+            ++shift;
+        counts[3] = 0;
+        e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
+                               d_column_index, pl->d_col16, (spmv::SegWinBlock *) nullptr, d_count, 0, shift, max_slots);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess && 2 * (long long) counts[3] > pl->ntiles) {
+            e = hipMalloc((void **) &pl->d_segblocks, (size_t) nb * sizeof(spmv::SegWinBlock));
+            if (e == hipSuccess) e = hipMemsetAsync(pl->d_segblocks, 0, (size_t) nb * sizeof(spmv::SegWinBlock), s);
+            if (e == hipSuccess) e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
+                                   d_column_index, pl->d_col16, pl->d_segblocks, d_count, 1, shift, max_slots);
+                e = hipGetLastError();
+            }
+            std::vector<spmv::SegWinBlock> hb;
+            if (e == hipSuccess) {
+                hb.resize((size_t) nb);
+                e = hipMemcpyAsync(hb.data(), pl->d_segblocks, hb.size() * sizeof(spmv::SegWinBlock), hipMemcpyDeviceToHost, s);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) {
+                pl->nsegblocks = nb;
+                pl->seg_tiles_per_block = per_block;
+                pl->segwin_tiles = 0;
+                pl->segwin_slots = 0;
+                for (auto const & b : hb)
+                    if (b.nseg > 0) {
+                        pl->segwin_tiles += b.ntiles;
+                        pl->segwin_slots = std::max(pl->segwin_slots, b.slots);
+                    }
+                pl->blockwin_tiles = pl->segwin_tiles;
+                pl->meta_bytes += (size_t) nb * sizeof(spmv::SegWinBlock);
+            }
+        }
+        counts[3] = 0;
+        if (e == hipSuccess) e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
+    }
+    // block windows (x staged through LDS per 16 tiles) for what has no cheaper path: first count
+    // the tiles that would qualify, and only if they are the majority mark them
+    if (e == hipSuccess && !pl->d_segblocks && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * spmv::kBlockWinTiles
+        && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
+        const int nb = (pl->ntiles + spmv::kBlockWinTiles - 1) / spmv::kBlockWinTiles;
+        hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile, pl->d_tiles,
+                           pl->d_col16, (int2 *) nullptr, d_count, 0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess && 2 * (long long) counts[3] > pl->ntiles) {
+            e = hipMalloc((void **) &pl->d_blocks, (size_t) nb * sizeof(int2));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile,
+                                   pl->d_tiles, pl->d_col16, pl->d_blocks, d_count, 1);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) {
+                pl->nblocks16 = nb;
+                pl->blockwin_tiles = counts[3];
+                pl->meta_bytes += (size_t) nb * sizeof(int2);
+            }
+        }
+    }
+    if (d_count)
+        (void) hipFree(d_count);
+    if (d_fp)
+        (void) hipFree(d_fp);
+    if (e != hipSuccess) {
+        (void) hipFree(pl->d_col16);
+        pl->d_col16 = nullptr;
+        if (pl->d_patterns) {
+            (void) hipFree(pl->d_patterns);
+            pl->d_patterns = nullptr;
+        }
+        if (pl->d_blocks) {
+            (void) hipFree(pl->d_blocks);
+            pl->d_blocks = nullptr;
+            pl->nblocks16 = 0;
+        }
+        if (pl->d_segblocks) {
+            (void) hipFree(pl->d_segblocks);
+            pl->d_segblocks = nullptr;
+            pl->nsegblocks = 0;
+        }
+        return fail_hip(e, "index compression");
+    }
+    pl->meta_bytes += bytes;
+    pl->compressed_from = d_column_index;
+    int rc = device_column_checksum(d_column_index, pl->nnz, &pl->column_checksum, s);
+    if (rc == SPMV_HIP_OK)
+        rc = plan_account(pl, true);
+    pl->verify_pending = true;
+    return rc;
+}
+
+int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    pl->verify_pending = false; // an explicit check stands in for the first multiply's
+    return verify_plan(pl, d_column_index, static_cast<hipStream_t>(stream));
+}
+
+// defined in coo_sort.hip (hipCUB): out[i] = sum of in[0..i), n elements
+int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
+
+int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                             const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->inner)
+        return fail(SPMV_HIP_ERR_STATE, "plan is already repacked");
+    // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
+    // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
+    const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->balanced || pl->nnz == 0 || pl->rows < 1024
+        || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
+        || !pl->d_col16 /* not compressed: the tile classes are unknown */
+        || pl->d_segblocks /* the gather already comes out of LDS */
+        || (long long) pl->rows * 8 + 1 > 0x7FFFFFF0LL)
+        return SPMV_HIP_OK;
+#ifdef SPMV_HIP_EXPERIMENTS
+    const bool force = (pl->flags & 0x4000u) != 0; // tools/gather_locality.py: panels whatever the shape
+#else
+    const bool force = false;
+#endif
+    if (!force && (!scattered || (long long) pl->cols * 8 < 3 * 1024 * 1024 || (long long) pl->nnz < 4LL * pl->rows
+                   || pl->nnz < (1 << 20) /* too small for the gather to matter; keeps small matrices bit-exact */))
+        return SPMV_HIP_OK;
+    if (!d_row_ptr || !d_column_index || !d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int32_t rows = pl->rows;
+    const long long vrows = 8LL * rows;
+    const int width = (pl->cols + 7) / 8;
+    int32_t * d_count = nullptr;
+    hipError_t e = hipMalloc((void **) &d_count, (size_t) (vrows + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vrow_ptr, (size_t) (vrows + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_pcol, (size_t) pl->nnz * sizeof(int32_t) + 64);
+    if (e == hipSuccess) e = hipMalloc((void **) &pl->d_pval, (size_t) pl->nnz * sizeof(double) + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count + vrows, 0, sizeof(int32_t), s);
+    std::vector<int32_t> vrow_ptr;
+    int rc = SPMV_HIP_OK;
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned) ((rows + 255) / 256);
+        hipLaunchKernelGGL(spmv::csr_panel_count_kernel, dim3(grid), dim3(256), 0, s, rows, width, d_row_ptr, d_column_index, d_count);
+        e = hipGetLastError();
+        if (e == hipSuccess && spmv_hip_internal_exclusive_scan_i32(d_count, pl->d_vrow_ptr, vrows + 1, s) != 0)
+            e = hipErrorUnknown;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::csr_panel_scatter_kernel, dim3(grid), dim3(256), 0, s, rows, width, d_row_ptr, d_column_index,
+                               d_value, pl->d_vrow_ptr, pl->d_pcol, pl->d_pval);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            vrow_ptr.resize((size_t) vrows + 1);
+            e = hipMemcpyAsync(vrow_ptr.data(), pl->d_vrow_ptr, vrow_ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (d_count)
+        (void) hipFree(d_count);
+    if (e == hipSuccess && vrow_ptr.back() != pl->nnz)
+        rc = fail(SPMV_HIP_ERR_INVALID, "column index out of range while forming column panels");
+    if (e == hipSuccess && rc == SPMV_HIP_OK) {
+        // the panel-major matrix is a CSR matrix of 8 * rows virtual rows: plan and classify it like any other
+        // (no x windows: its kernel variant has none)
+        rc = plan_csr_internal(&pl->inner, (int32_t) vrows, pl->cols, vrow_ptr.data(), SPMV_HIP_CSR_WAVETILE, 0,
+                               (pl->flags | SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_NO_COLUMN_PANELS) & ~SPMV_HIP_FLAG_ROWS128, rows);
+        if (rc == SPMV_HIP_OK)
+            rc = spmv_hip_plan_csr_compress(pl->inner, pl->d_pcol, stream);
+    }
+    if (e != hipSuccess || rc != SPMV_HIP_OK) {
+        if (pl->inner) { spmv_hip_plan_destroy(pl->inner); pl->inner = nullptr; }
+        if (pl->d_vrow_ptr) { (void) hipFree(pl->d_vrow_ptr); pl->d_vrow_ptr = nullptr; }
+        if (pl->d_pcol) { (void) hipFree(pl->d_pcol); pl->d_pcol = nullptr; }
+        if (pl->d_pval) { (void) hipFree(pl->d_pval); pl->d_pval = nullptr; }
+        return e != hipSuccess ? fail_hip(e, "column panels") : rc;
+    }
+    pl->pinfo = pl->inner->pinfo;
+    int most = 0;
+    for (int k = 0; k < 8; ++k)
+        most = std::max(most, pl->pinfo.first[k + 1] - pl->pinfo.first[k]);
+    pl->panel_blocks = (most + 3) / 4;
+    pl->panels_from_col = d_column_index;
+    pl->panels_from_val = d_value;
+    pl->meta_bytes += (size_t) (vrows + 1) * sizeof(int32_t) + (size_t) pl->nnz * 12 + pl->inner->meta_bytes;
+    // what the panel copy streams: its own tiles, with y counted once per row and panel that has entries
+    {
+        long long nonempty = 0;
+        for (long long v = 0; v < vrows; ++v)
+            nonempty += vrow_ptr[(size_t) v + 1] > vrow_ptr[(size_t) v];
+        pl->streamed_bytes = pl->inner->streamed_bytes - 16LL * vrows + 16LL * nonempty;
+        pl->shifted_entries = pl->inner->shifted_entries;
+        pl->narrow_entries = pl->inner->narrow_entries;
+        pl->uniform_rows = 0;
+    }
+    return SPMV_HIP_OK;
+}
+
+static void drop_value_dictionary(spmv_hip_plan * pl)
+{
+    if (pl->d_vidx) (void) hipFree(pl->d_vidx);
+    if (pl->d_vtab) (void) hipFree(pl->d_vtab);
+    pl->d_vidx = nullptr;
+    pl->d_vtab = nullptr;
+    pl->nvalues = 0;
+    pl->values_from = nullptr;
+    pl->verify_values_pending = false;
+}
+
+int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t before = (pl->d_vidx ? (size_t) pl->nnz + 64 + spmv::kMaxIndexedValues * sizeof(double) : 0);
+    drop_value_dictionary(pl);
+    pl->meta_bytes -= std::min(pl->meta_bytes, before);
+    // only the default kernel reads the dictionary (row-owned wave tiles with 16-bit-capable plans, x below 4 GiB)
+    // (not with column panels, block windows or a majority of x-window tiles: those launches have their own variants)
+    const bool other_variant = pl->inner || pl->d_blocks || pl->d_segblocks
+        || (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles);
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
+        || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
+        || (pl->flags & SPMV_HIP_FLAG_NO_VALUE_INDEX))
+        return pl->inner ? SPMV_HIP_OK : plan_account(pl, pl->d_col16 != nullptr);
+    if (!d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    unsigned long long * d_keys = nullptr;
+    int * d_state = nullptr;
+    std::vector<unsigned long long> keys((size_t) spmv::kDictSlots, spmv::kDictEmpty);
+    int state[2] = {0, 0};
+    hipError_t e = hipMalloc((void **) &d_keys, keys.size() * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_state, sizeof(state));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_keys, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(state), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::value_dict_insert_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 8)), dim3(256), 0, s,
+                           (long long) pl->nnz, d_value, d_keys, d_state, spmv::kMaxIndexedValues);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int rc = SPMV_HIP_OK;
+    if (e == hipSuccess && state[1] == 0 && state[0] >= 1 && state[0] <= spmv::kMaxIndexedValues) {
+        // few enough distinct values: sort the bit patterns, index every entry
+        std::vector<unsigned long long> table;
+        for (unsigned long long k : keys)
+            if (k != spmv::kDictEmpty)
+                table.push_back(k);
+        std::sort(table.begin(), table.end());
+        std::vector<double> values((size_t) spmv::kMaxIndexedValues, 0.0);
+        for (size_t i = 0; i < table.size(); ++i)
+            std::memcpy(&values[i], &table[i], sizeof(double));
+        unsigned long long * d_table = nullptr;
+        e = hipMalloc((void **) &d_table, (size_t) spmv::kMaxIndexedValues * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vtab, (size_t) spmv::kMaxIndexedValues * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_vidx, (size_t) pl->nnz + 64);
+        if (e == hipSuccess) e = hipMemsetAsync(pl->d_vidx, 0, (size_t) pl->nnz + 64, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(pl->d_vtab, values.data(), values.size() * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(state), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::value_index_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 16)), dim3(256), 0, s,
+                               (long long) pl->nnz, d_value, d_table, (int) table.size(), pl->d_vidx, d_state);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (d_table) (void) hipFree(d_table);
+        if (e == hipSuccess && state[1] == 0) {
+            pl->nvalues = (int) table.size();
+            pl->values_from = d_value;
+            rc = device_value_checksum(d_value, pl->nnz, &pl->value_checksum, s);
+            pl->verify_values_pending = true;
+            pl->meta_bytes += (size_t) pl->nnz + 64 + spmv::kMaxIndexedValues * sizeof(double);
+        } else {
+            drop_value_dictionary(pl); // the values changed between the two passes, or a HIP error
+        }
+    }
+    if (d_keys) (void) hipFree(d_keys);
+    if (d_state) (void) hipFree(d_state);
+    if (e != hipSuccess) {
+        drop_value_dictionary(pl);
+        return fail_hip(e, "value dictionary");
+    }
+    if (rc != SPMV_HIP_OK) {
+        drop_value_dictionary(pl);
+        return rc;
+    }
+    return plan_account(pl, pl->d_col16 != nullptr);
+}
+
+int spmv_hip_plan_csr_refresh_values(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                                     const double * d_value, void * stream)
+{
+    if (!pl)
+        return fail(SPMV_HIP_ERR_INVALID, "plan is null");
+    if (pl->nvalues > 0 || pl->d_vidx) {
+        // the dictionary is rebuilt from the new values (and dropped if they are no longer few)
+        int rc = spmv_hip_plan_csr_index_values(pl, d_value, stream);
+        if (rc != SPMV_HIP_OK)
+            return rc;
+    }
+    if (!pl->inner)
+        return SPMV_HIP_OK; // no snapshot: the multiply reads the caller's values
+    if (!d_row_ptr || !d_column_index || !d_value)
+        return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
+    if (d_column_index != pl->panels_from_col)
+        return fail(SPMV_HIP_ERR_STATE, "the column panels were made from another column array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned) ((pl->rows + 255) / 256);
+    hipLaunchKernelGGL(spmv::csr_panel_scatter_kernel, dim3(grid), dim3(256), 0, s, pl->rows, (pl->cols + 7) / 8, d_row_ptr,
+                       d_column_index, d_value, pl->d_vrow_ptr, pl->d_pcol, pl->d_pval);
+    HIP_TRY(hipGetLastError());
+    pl->panels_from_val = d_value;
+    return SPMV_HIP_OK;
+}
+
+int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
+{
+    if (!pl || !out || n < 0)
+        return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
+    const int64_t v[23] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+                           pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
+                           pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
+                           pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
+                           pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
+                           pl->segwin_tiles, pl->segwin_slots};
+    for (int i = 0; i < n && i < 23; ++i)
+        out[i] = v[i];
+    return SPMV_HIP_OK;
+}
+
+} // extern "C"

@@ -1,2419 +1,23 @@
-// spmv_kernels.hpp -- hand-written gfx950 kernels for y += A*x (fp64 values, int32 indices).
-//
-// Built with -ffp-contract=off: a product is rounded before it is added, as in the
-// reference's x86-64 -O3 build (no FMA), so every path that adds a row's products
-// left to right with one lane is bit-identical to the reference loop
-// (src/matrix/csr-matrix-spmv.cpp:29-32, src/matrix/ell-matrix.cpp:251-257).
-//
-// None of this is GEMM-shaped: ~0.13 flop/byte, HBM-bound.  No MFMA on purpose.
+// spmv_kernels.hpp -- every hand-written gfx950 kernel of y += A*x (fp64 values, int32 indices), by file:
+//   tile_common.hpp       descriptor format, shared helpers
+//   csr_wavetile.hpp      default CSR path (wave tiles and their classes)
+//   csr_segtile.hpp       balanced tiles for skewed rows
+//   csr_blockwin.hpp      one-ring block window (unstructured bands)
+//   csr_segwin.hpp        segment windows (meshes in natural ordering, KKT systems)
+//   csr_panels.hpp        column panels, plan time
+//   csr_plan_kernels.hpp  tile classification, 16-bit columns, patterns
+//   csr_basic.hpp         scalar / vector / adaptive CSR kernels
+//   coo_kernels.hpp, ell_kernels.hpp, upload_kernels.hpp, triad_kernels.hpp
 #pragma once
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "wave_ops.hpp"
-
-namespace spmv {
-
-// ---------------------------------------------------------------------------------
-// XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs
-// (blockIdx b and b+8 share an L2).  Row blocks that are neighbours in the matrix
-// read overlapping windows of x, so give each XCD one contiguous run of blocks:
-// logical = (b % 8) * ceil-ish(n/8) + b / 8, bijective for any n.  Placement is a
-// speed matter only; any mapping gives the same y.
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_remap(int bid, int nblk, bool enable)
-{
-    if (!enable || nblk < 16)
-        return bid;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return xcd * q + (xcd < r ? xcd : r) + idx;
-}
-
-// ---------------------------------------------------------------------------------
-// CSR, one lane per row ("scalar").  Reference order: bit-exact.
-// ---------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void csr_scalar_kernel(
-    int rows, const int32_t * __restrict__ p, const int32_t * __restrict__ j,
-    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y)
-{
-    const long long stride = (long long) gridDim.x * BLOCK;
-    for (long long i = (long long) blockIdx.x * BLOCK + threadIdx.x; i < rows; i += stride) {
-        const int k1 = p[i + 1];
-        double z = 0.0;
-        for (int k = p[i]; k < k1; ++k)
-            z += a[k] * x[j[k]];
-        y[i] += z;
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// CSR, LPR lanes per row ("vector").  A wave owns 64/LPR consecutive rows; the
-// lanes of a row walk its entries with unit stride (coalesced col/val loads), then
-// a DPP / ds_swizzle butterfly adds the LPR partial sums.
-// ---------------------------------------------------------------------------------
-template <int LPR, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void csr_vector_kernel(
-    int rows, const int32_t * __restrict__ p, const int32_t * __restrict__ j,
-    const double * __restrict__ a, const double * __restrict__ x, double * __restrict__ y)
-{
-    constexpr int ROWS_PER_BLOCK = BLOCK / LPR;
-    const int lane = threadIdx.x % LPR;
-    const int sub = threadIdx.x / LPR;
-    const long long stride = (long long) gridDim.x * ROWS_PER_BLOCK;
-    // trip count is uniform per workgroup, so every lane reaches group_sum
-    for (long long base = (long long) blockIdx.x * ROWS_PER_BLOCK; base < rows; base += stride) {
-        const long long row = base + sub;
-        const bool valid = row < rows;
-        int k0 = 0, k1 = 0;
-        if (valid) {
-            k0 = p[row];
-            k1 = p[row + 1];
-        }
-        double z = 0.0;
-        for (int k = k0 + lane; k < k1; k += LPR)
-            z += a[k] * x[j[k]];
-        z = group_sum<LPR>(z);
-        if (valid && lane == 0)
-            y[row] += z;
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// CSR, adaptive row blocks.
-//
-// The host cuts the rows into blocks [blk_row[b], blk_row[b+1]) holding at most
-// TILE stored entries (counted from the 4-aligned start) and at most BLOCK rows;
-// a row longer than TILE is a block by itself.
-//
-// Stream block: the workgroup reads its contiguous slice of column_index / value
-// with 16-byte-per-lane loads (int4 + 2 x double2, perfectly coalesced whatever the
-// row lengths are), gathers x, and parks the rounded products in LDS.  After one
-// barrier each row is summed from LDS by L lanes (L chosen per block from its
-// entries-per-row, L = 1 gives the reference's left-to-right order exactly).
-//
-// Long row: the whole workgroup strides the row, wave butterfly + LDS combine.
-// ---------------------------------------------------------------------------------
-template <int L, int BLOCK>
-__device__ __forceinline__ void sum_rows_from_lds(
-    const double * prod, const int32_t * __restrict__ p, double * __restrict__ y,
-    int r0, int nrows, int kb)
-{
-    constexpr int ROWS_PER_PASS = BLOCK / L;
-    const int lane = threadIdx.x % L;
-    const int sub = threadIdx.x / L;
-    for (int rb = 0; rb < nrows; rb += ROWS_PER_PASS) {
-        const int r = rb + sub;
-        const bool valid = r < nrows;
-        int s = 0, e = 0;
-        if (valid) {
-            s = p[r0 + r] - kb;
-            e = p[r0 + r + 1] - kb;
-        }
-        double z = 0.0;
-        for (int k = s + lane; k < e; k += L)
-            z += prod[k];
-        z = group_sum<L>(z);
-        if (valid && lane == 0)
-            y[r0 + r] += z;
-    }
-}
-
-template <int BLOCK, int TILE>
-__global__ __launch_bounds__(BLOCK) void csr_adaptive_kernel(
-    int nblk, const int32_t * __restrict__ blk_row, const int32_t * __restrict__ p,
-    const int32_t * __restrict__ j, const double * __restrict__ a,
-    const double * __restrict__ x, double * __restrict__ y, int nnz_total, int xcd_aware,
-    int exact_order)
-{
-    __shared__ __attribute__((aligned(16))) double prod[TILE + 4];
-    __shared__ double wave_part[BLOCK / kWave];
-
-    const int b = xcd_remap(blockIdx.x, nblk, xcd_aware != 0);
-    const int r0 = blk_row[b];
-    const int r1 = blk_row[b + 1];
-    const int nrows = r1 - r0;
-    const int k0 = p[r0];
-    const int k1 = p[r1];
-    const int kb = k0 & ~3;
-
-    if (k1 - kb <= TILE) {
-        // ---- stream: products to LDS -------------------------------------------
-        for (int e = kb + 4 * (int) threadIdx.x; e < k1; e += 4 * BLOCK) {
-            int c0, c1, c2, c3;
-            double v0, v1, v2, v3;
-            if (e + 3 < nnz_total) {
-                const int4 c = *reinterpret_cast<const int4 *>(j + e);
-                const double2 va = *reinterpret_cast<const double2 *>(a + e);
-                const double2 vb = *reinterpret_cast<const double2 *>(a + e + 2);
-                c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
-                v0 = va.x; v1 = va.y; v2 = vb.x; v3 = vb.y;
-            } else { // last (partial) quad of the arrays
-                c0 = j[e];
-                v0 = a[e];
-                c1 = (e + 1 < nnz_total) ? j[e + 1] : 0;
-                v1 = (e + 1 < nnz_total) ? a[e + 1] : 0.0;
-                c2 = (e + 2 < nnz_total) ? j[e + 2] : 0;
-                v2 = (e + 2 < nnz_total) ? a[e + 2] : 0.0;
-                c3 = 0;
-                v3 = 0.0;
-            }
-            // entries before k0 / after k1 belong to neighbouring blocks
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            if (e >= k0) q0 = v0 * x[c0];
-            if (e + 1 >= k0 && e + 1 < k1) q1 = v1 * x[c1];
-            if (e + 2 >= k0 && e + 2 < k1) q2 = v2 * x[c2];
-            if (e + 3 >= k0 && e + 3 < k1) q3 = v3 * x[c3];
-            double2 * dst = reinterpret_cast<double2 *>(prod + (e - kb));
-            dst[0] = make_double2(q0, q1);
-            dst[1] = make_double2(q2, q3);
-        }
-        __syncthreads();
-
-        // ---- per-row sums from LDS ------------------------------------------------
-        // lanes per row: enough to keep the workgroup busy, never more than the
-        // rows are long; one lane per row keeps the reference's summation order
-        int lanes = 1;
-        if (!exact_order && nrows > 0) {
-            const int avg = (k1 - k0) / nrows;
-            int cap = BLOCK / nrows; // >= 1 because nrows <= BLOCK
-            if (cap > kWave) cap = kWave;
-            while (lanes * 2 <= cap && lanes * 8 <= avg)
-                lanes *= 2;
-        }
-        switch (lanes) {
-        case 1: sum_rows_from_lds<1, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        case 2: sum_rows_from_lds<2, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        case 4: sum_rows_from_lds<4, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        case 8: sum_rows_from_lds<8, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        case 16: sum_rows_from_lds<16, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        case 32: sum_rows_from_lds<32, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        default: sum_rows_from_lds<64, BLOCK>(prod, p, y, r0, nrows, kb); break;
-        }
-    } else if (!exact_order) {
-        // ---- one long row: whole workgroup strides it --------------------------------
-        double z = 0.0;
-        for (int k = k0 + (int) threadIdx.x; k < k1; k += BLOCK)
-            z += a[k] * x[j[k]];
-        z = group_sum<kWave>(z);
-        if ((threadIdx.x & (kWave - 1)) == 0)
-            wave_part[threadIdx.x / kWave] = z;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int w = 0; w < BLOCK / kWave; ++w)
-                t += wave_part[w];
-            y[r0] += t;
-        }
-    } else {
-        // ---- one long row, reference order: tiles of products, lane 0 adds them ------
-        double z = 0.0;
-        for (int t0 = k0; t0 < k1; t0 += TILE) {
-            const int t1 = (t0 + TILE < k1) ? t0 + TILE : k1;
-            for (int k = t0 + (int) threadIdx.x; k < t1; k += BLOCK)
-                prod[k - t0] = a[k] * x[j[k]];
-            __syncthreads();
-            if (threadIdx.x == 0)
-                for (int k = 0; k < t1 - t0; ++k)
-                    z += prod[k];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0)
-            y[r0] += z;
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// CSR, wave tiles ("wavetile"): per-wavefront row ownership, no workgroup barrier.
-//
-// The host cuts the rows into tiles owned by ONE wave: up to 128 consecutive rows (two per lane
-// when rows are short) holding at most TILE stored entries (counted from the 4-aligned start).
-// A tile is described by an int4 {first row | flags, first entry, meta, column base} with
-//   meta = longest row | log2(lanes per row) << 16 | narrow << 24 | fast << 25 | uniform << 26
-//          | shifted << 27 | x window << 28 | (window chunks - 1) << 29 | window of runs << 31;
-// tile w ends where tile w+1 starts.  In a uniform tile (all rows equally long, e.g. the
-// interior of a stencil) the row bounds follow from the descriptor and row_ptr is not read.
-// A wave reads its descriptor pair and then has everything it needs to issue ALL its
-// independent loads back to back -- the row_ptr pair and old y of the lane's row, then the
-// column/value quads (16 B per lane, coalesced whatever the row lengths are) -- so a tile costs
-// three dependent memory round trips (descriptor -> streams -> x) instead of the six of a
-// row_ptr-driven kernel.  The rounded products are parked in the wave's private LDS slice
-// (same-wave LDS operations execute in order: no barrier, no wait beyond the data dependence),
-// then each row is added up by L lanes, L chosen by the host from the tile's longest row
-// (<= 16 entries per lane); L = 1 walks the row left to right exactly like the reference loop.
-//
-// The kernel is also kept lean in issued instructions, which at 5 entries per row is
-// what bounds it next to HBM: no per-entry predicates (entries of neighbouring tiles
-// that share a 16-byte quad are multiplied too, their products are simply never
-// read), clamped indices instead of divergent branches, the per-tile integer
-// divisions done once on the host (descriptor .z/.w), and a row loop whose trip count
-// is wave-uniform (the tile's longest row).
-//
-// Compressed column indices: when all columns of a tile lie within 65536 of the tile's
-// smallest column (any banded matrix), the plan keeps them as 16-bit offsets from that
-// base in a second index stream, and the tile reads 2 instead of 4 bytes per entry
-// (10 instead of 12 with the value) and gathers x through a scalar base + 32-bit offset.
-// Entries of neighbouring tiles that share a boundary quad decode against the wrong base;
-// their offset is clamped into x so that the (never used) gather stays in bounds.
-//
-// A row longer than TILE is a tile by itself (the wave strides it); rows longer than
-// kSplitThreshold (2048 entries) are cut into chunks spread over several waves (bit 31 of the row
-// field), each adding its partial sum with one fp64 atomic.
-// ---------------------------------------------------------------------------------
-constexpr int kTileFlagPartial = (int) 0x80000000u;
-constexpr int kTileMetaLanesShift = 16;
-constexpr int kTileMetaBlockWin = 1 << 20; // the tile belongs to csr_blockwin_kernel; csr_wavetile_kernel skips it
-constexpr int kTileMetaPattern = 1 << 19; // shifted tile: desc.w is a pattern number (first-row columns = first row + pattern)
-constexpr int kTileMetaNarrow = 1 << 24;
-constexpr int kTileMetaFast = 1 << 25;
-constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries
-// uniform + every row has the columns of the tile's first row shifted by its distance from it
-// (the interior of a stencil, a band matrix): only the first row's columns are read
-constexpr int kTileMetaShifted = 1 << 27;
-// narrow, and the tile's whole column range fits the x window of the XW kernel variant:
-// bits 29-30 hold the number of 64-entry chunks of x to stage, minus one
-constexpr int kTileMetaXWin = 1 << 28;
-constexpr int kTileMetaXChunksShift = 29;
-// shifted tile whose x entries -- `len` runs of `rows` consecutive entries, runs that touch or
-// overlap merged -- fit the window: the plan keeps, in the tile's unused 16-bit column slots,
-// the window position of every first-row column and the x offset of every window slot
-constexpr int kTileMetaXSeg = (int) 0x80000000u;
-// A window-of-runs tile refers (desc.w) to a pattern shared by all tiles with the same row count
-// and the same first-row columns relative to the first row index -- the whole interior of a
-// stencil is one pattern -- so the window tables cost no HBM traffic and no per-tile round trip.
-// Record, in 32-bit words: [0] row length, [1] rows, [2] window slots a window of runs would use
-// (2^20 = none worked out), [3] smallest first-row column - first row index;
-// [16..144) first-row columns - first row index; [144..176) window position of each row position
-// (16 bits each); [176..432) x index - first row index of every window slot.
-constexpr int kPatStride = 432;
-constexpr int kPatRel = 16, kPatXoff = 144, kPatSrc = 176;
-constexpr int kMaxPatterns = 64;
-
-// native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-template <typename T, bool NT>
-__device__ __forceinline__ T stream_load(const T * ptr)
-{
-    if (NT)
-        return __builtin_nontemporal_load(ptr);
-    return *ptr;
-}
-
-// x[c] with a 32-bit byte offset from a scalar base when x is smaller than 4 GiB
-// (global_load saddr + voffset: one shift instead of 64-bit address arithmetic)
-template <bool X32>
-__device__ __forceinline__ double gather_x(const double * __restrict__ x, int c)
-{
-    if (X32)
-        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned) c << 3));
-    return x[c];
-}
-
-// Sum of one row's products from the wave's LDS slice by L lanes; the trip count is wave-uniform
-// (the tile's longest row), lanes whose row is finished add +0.0 without reading LDS.  That is an
-// identity: z starts at +0.0 and can never become -0.0 (a sum that cancels rounds to +0.0), so the
-// bits match a loop that simply stops at the end of the row.  (Reading a shared zero slot instead
-// of predicating the read was measured slower: 245 vs 222 us on the 27-point stencil.)
-template <int L>
-__device__ __forceinline__ double tile_row_sum(const double * prod, int s, int e_row, int part, int trips)
-{
-    double z = 0.0;
-    int k = s + part;
-    for (int t = 0; t < trips; ++t, k += L) {
-        const double v = (k < e_row) ? prod[k] : 0.0;
-        z += v;
-    }
-    return group_sum<L>(z);
-}
-
-// Where a tile's values come from.  VI = false: the value array (two 16-byte loads per lane and quad).
-// VI = true (the plan holds a value dictionary: the matrix has at most kMaxIndexedValues distinct values --
-// a pattern / graph matrix, a constant-coefficient stencil, a mesh of identical elements): one BYTE per
-// entry from the plan's index stream (one dword per lane and quad) and the value itself out of a table
-// in LDS.  The doubles are the stored ones bit for bit; the tile streams 1 instead of 8 bytes per entry.
-constexpr int kMaxIndexedValues = 128;
-
-// Where an index byte finds its double: the dictionary in LDS -- or, for a dictionary of one or two values (a
-// pattern or graph matrix; the 5-point stencil's -1 and 4), two scalar registers and a select: no table, no look-up,
-// and no workgroup barrier at the start of the kernel.
-struct ValueLookup {
-    const double * tab;
-    bool tiny;
-    double t0, t1;
-    __device__ __forceinline__ double operator[](unsigned b) const { return tiny ? (b ? t1 : t0) : tab[b]; }
-};
-
-template <int QUADS, bool VI>
-struct TileValues {
-    v2d va[QUADS], vb[QUADS];
-    unsigned vi[VI ? QUADS : 1];
-
-    // at / vit already point at the tile's 4-aligned first entry
-    __device__ __forceinline__ void load(const double * __restrict__ at, const uint8_t * __restrict__ vit, int last, int lane)
-    {
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            int o = 256 * q + 4 * lane;
-            o = o < last ? o : last; // lanes past the tile's end re-read its last quad
-            if (VI) {
-                vi[q] = *reinterpret_cast<const unsigned *>(vit + o);
-            } else {
-                va[q] = *reinterpret_cast<const v2d *>(at + o);
-                vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-            }
-        }
-    }
-    __device__ __forceinline__ void resolve(ValueLookup vtab)
-    {
-        if (VI) {
-#pragma unroll
-            for (int q = 0; q < QUADS; ++q) {
-                va[q] = v2d{vtab[vi[q] & 0x7Fu], vtab[(vi[q] >> 8) & 0x7Fu]};
-                vb[q] = v2d{vtab[(vi[q] >> 16) & 0x7Fu], vtab[(vi[q] >> 24) & 0x7Fu]};
-            }
-        }
-    }
-};
-
-// Products of one quad-set with 32-bit column indices.
-template <int QUADS, bool X32, bool VI = false>
-__device__ __forceinline__ void tile_products_wide(
-    double * prod, const int32_t * __restrict__ jt, const double * __restrict__ at,
-    const double * __restrict__ x, int last, int lane, const uint8_t * __restrict__ vit = nullptr, ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
-{
-    v4i c[QUADS];
-    TileValues<QUADS, VI> vals;
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last; // lanes past the tile's end re-read its last quad
-        c[q] = *reinterpret_cast<const v4i *>(jt + o);
-    }
-    vals.load(at, vit, last, lane);
-    vals.resolve(vtab);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            const double q0 = vals.va[q].x * gather_x<X32>(x, c[q].x);
-            const double q1 = vals.va[q].y * gather_x<X32>(x, c[q].y);
-            const double q2 = vals.vb[q].x * gather_x<X32>(x, c[q].z);
-            const double q3 = vals.vb[q].y * gather_x<X32>(x, c[q].w);
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-}
-
-// The same with 16-bit column offsets from the tile's base: xt = x + base (scalar), limit =
-// last valid offset from the base (cols - 1 - base).
-template <int QUADS, int ABL, bool VI = false>
-__device__ __forceinline__ void tile_products_narrow(
-    double * prod, const uint16_t * __restrict__ jt, const double * __restrict__ at,
-    const double * __restrict__ xt, unsigned limit, int last, int lane, const uint8_t * __restrict__ vit = nullptr,
-    ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
-{
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    v2u c[QUADS];
-    TileValues<QUADS, VI> vals;
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last;
-        c[q] = *reinterpret_cast<const v2u *>(jt + o); // four 16-bit offsets
-    }
-    vals.load(at, vit, last, lane);
-    vals.resolve(vtab);
-    const char * xb = reinterpret_cast<const char *>(xt);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            unsigned c0 = min(c[q].x & 0xFFFFu, limit), c1 = min(c[q].x >> 16, limit);
-            unsigned c2 = min(c[q].y & 0xFFFFu, limit), c3 = min(c[q].y >> 16, limit);
-            if (ABL & 1) { // timing experiment only: every lane gathers the same four x entries
-                c0 &= 1; c1 &= 1; c2 &= 1; c3 &= 1;
-            }
-            const double q0 = vals.va[q].x * *reinterpret_cast<const double *>(xb + (c0 << 3));
-            const double q1 = vals.va[q].y * *reinterpret_cast<const double *>(xb + (c1 << 3));
-            const double q2 = vals.vb[q].x * *reinterpret_cast<const double *>(xb + (c2 << 3));
-            const double q3 = vals.vb[q].y * *reinterpret_cast<const double *>(xb + (c3 << 3));
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-}
-
-// A "shifted" tile: entry t of the tile (row t / len, position t % len) has column
-// first_row[t % len] + t / len, so the column stream shrinks to the first row's `len` columns,
-// read from the original 32-bit array (the tile's columns may span any range: a 253^3 grid's
-// 27-point rows reach 128 K columns) and parked in the wave's LDS table (len <= 128).  Holding
-// them one per lane and fetching with ds_bpermute measured the same
-// (profiles/r01_sweep_shifted_*.log) and stops at 64.  t / len uses a 22-bit reciprocal, exact
-// while t * len < 2^22 (t < 1024, len <= 512), with t * magic < 2^32.
-constexpr int kShiftedMaxLen = 128;
-
-#ifndef SPMV_VI_ABLATE
-#define SPMV_VI_ABLATE 0 // timing experiments only (tools/ablate.sh builds libraries with -DSPMV_VI_ABLATE=n)
-#endif
-template <int QUADS, bool X32, bool VI = false>
-__device__ __forceinline__ void tile_products_shifted(
-    double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
-    const double * __restrict__ at, const double * __restrict__ x, unsigned limit, int last, int lane,
-    int len, int lead, const uint8_t * __restrict__ vit = nullptr, ValueLookup vtab = ValueLookup{nullptr, false, 0.0, 0.0})
-{
-    static_assert(QUADS * 256 <= 1024, "reciprocal below is exact for t < 1024 only");
-    TileValues<QUADS, VI> vals;
-    // first_row: the tile's own first row in the column array (base 0), or its pattern's columns
-    // relative to the first row index (base = that index; cache-resident, no per-tile read)
-    for (int i = lane; i < len; i += kWave)
-        tab[i] = (uint32_t) (first_row[i] + first_row_base);
-    vals.load(at, vit, last, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len; // wave-uniform
-    // the x gathers depend on the descriptor and the first row only: all of them are issued before anything
-    // waits for the value stream (with a value dictionary the table look-ups below need the index loads back)
-    double xg[QUADS][4];
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // entries in front of the tile (they share its first quad) are multiplied and never
-                // read back, like the ones behind its end; both only need a valid column
-                const int ti = o + i - lead;
-                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-                const unsigned r = (t * magic) >> 22;
-                if (VI && (SPMV_VI_ABLATE & 1))
-                    xg[q][i] = gather_x<X32>(x, (int) ((tab[t - r * (unsigned) len] + r) & 15u)); // no x traffic
-                else
-                    xg[q][i] = gather_x<X32>(x, (int) min(tab[t - r * (unsigned) len] + r, limit));
-            }
-        }
-    }
-    vals.resolve(vtab);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{vals.va[q].x * xg[q][0], vals.va[q].y * xg[q][1]};
-            dst[1] = v2d{vals.vb[q].x * xg[q][2], vals.vb[q].y * xg[q][3]};
-        }
-    }
-}
-
-// A shifted tile whose rows are all equally long (the interior of a stencil), under a value dictionary: ONE LANE
-// PER ROW.  Row r of the tile has the columns first_row[pos] + r, so for a given pos the lanes of a wave read
-// x[first_row[pos] + lane]: 512 contiguous bytes, 8 accesses of the vector L1 -- where the entry-major layout of
-// tile_products_shifted (lane = four consecutive entries) lands the 64 lanes of every gather on all the
-// diagonals at once, ~35 different 64-byte pieces per instruction.  The counters of the value-dictionary launch
-// (71 M L1 accesses in 143 us: 0.85 per clock and CU, profiles/r02_prof_poisson_csr_vi_summary.md) say that this
-// look-up rate, not memory, was what it ran at.  first_row sits one entry per lane in a register and is
-// broadcast with v_readlane (len <= 64); the tile's index bytes go through the wave's LDS slice (two coalesced
-// dwords per lane in, the row's bytes out); the doubles come from the table and are added left to right from
-// +0.0: the reference's order, bit for bit.  Lanes own a second row 64 further on when the tile has more than 64.
-// A lane per row pays while the tile has rows for at least half the wave: rows of up to 16 entries (32+ rows per 512-entry
-// tile).  Longer rows reach this test only under SPMV_HIP_FLAG_EXACT_ORDER (ELLPACK): 33 entries per row would leave
-// 15 lanes gathering in seven dependent rounds -- measured on an ELLPACK band of 33: 199 us against 157 for the
-// entry-major path.
-constexpr int kLanePerRowMaxLen = 16;
-
-template <bool X32>
-__device__ __forceinline__ void tile_rows_uniform_indexed(
-    double * prod, const int32_t * __restrict__ first_row, int first_row_base,
-    const uint8_t * __restrict__ vit, ValueLookup vtab, const double * __restrict__ x, int last, int lane,
-    int len, int lead, int nrows, bool second, double & zA, double & zB)
-{
-    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
-    unsigned * vw = reinterpret_cast<unsigned *>(prod);
-    unsigned vi[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last; // lanes past the tile's end re-read its last dword (and park it where nobody looks)
-        vi[q] = *reinterpret_cast<const unsigned *>(vit + o);
-    }
-    const int rowA = lane < nrows ? lane : nrows - 1;
-    const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
-    zA = 0.0;
-    zB = 0.0;
-    constexpr int CH = 5; // positions per round: a 5-point row in one go
-    double xa[CH], xb[CH];
-    // first round of gathers: they depend on first_row only and leave before the index bytes are back
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        if (i < len) { // wave-uniform
-            const int c = __builtin_amdgcn_readlane(fr, i);
-            xa[i] = gather_x<X32>(x, (SPMV_VI_ABLATE & 1) ? ((c + rowA) & 15) : c + rowA);
-            if (second)
-                xb[i] = gather_x<X32>(x, (SPMV_VI_ABLATE & 1) ? ((c + rowB) & 15) : c + rowB);
-        }
-    }
-    vw[lane] = vi[0];
-    vw[64 + lane] = vi[1];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint8_t * vA = reinterpret_cast<const uint8_t *>(prod) + lead + rowA * len;
-    const uint8_t * vB = reinterpret_cast<const uint8_t *>(prod) + lead + rowB * len;
-    for (int p0 = 0; p0 < len; p0 += CH) {
-        if (p0 > 0) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if (p0 + i < len) {
-                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
-                    xa[i] = gather_x<X32>(x, c + rowA);
-                    if (second)
-                        xb[i] = gather_x<X32>(x, c + rowB);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (p0 + i < len) {
-                zA += vtab[vA[p0 + i] & 0x7Fu] * xa[i];
-                if (second)
-                    zB += vtab[vB[p0 + i] & 0x7Fu] * xb[i];
-            }
-        }
-    }
-}
-
-// The same lane-per-row scheme with the values themselves (no dictionary): the tile's values are loaded as ever --
-// two coalesced 16-byte loads per lane and quad -- and parked in the wave's LDS slice where the products used to
-// go; a lane then reads its row's values back (the access pattern the row sums had) and multiplies them with x
-// read 512 contiguous bytes at a time.  Same bits as the reference's loop.
-template <int QUADS, bool X32>
-__device__ __forceinline__ void tile_rows_uniform_values(
-    double * prod, const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
-    const double * __restrict__ x, int last, int lane, int len, int lead, int nrows, bool second, double & zA, double & zB)
-{
-    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
-    TileValues<QUADS, false> vals;
-    vals.load(at, nullptr, last, lane);
-    const int rowA = lane < nrows ? lane : nrows - 1;
-    const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
-    zA = 0.0;
-    zB = 0.0;
-    constexpr int CH = 5;
-    double xa[CH], xb[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        if (i < len) { // wave-uniform
-            const int c = __builtin_amdgcn_readlane(fr, i);
-            xa[i] = gather_x<X32>(x, c + rowA);
-            if (second)
-                xb[i] = gather_x<X32>(x, c + rowB);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = vals.va[q];
-            dst[1] = vals.vb[q];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double * vA = prod + lead + rowA * len;
-    const double * vB = prod + lead + rowB * len;
-    for (int p0 = 0; p0 < len; p0 += CH) {
-        if (p0 > 0) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if (p0 + i < len) {
-                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
-                    xa[i] = gather_x<X32>(x, c + rowA);
-                    if (second)
-                        xb[i] = gather_x<X32>(x, c + rowB);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (p0 + i < len) {
-                zA += vA[p0 + i] * xa[i];
-                if (second)
-                    zB += vB[p0 + i] * xb[i];
-            }
-        }
-    }
-}
-
-// x staged through LDS (kernel variant XW > 0, tiles marked kTileMetaXWin): the tile's column
-// range [base, base + 64 * chunks) is read once with coalesced loads into the wave's window and the
-// products take x from there (ds_read_b64) instead of gathering it through the vector L1.  All
-// global loads -- window, column offsets or first row, values -- are issued before the first wait.
-template <int QUADS, int XW>
-__device__ __forceinline__ void tile_products_xwin(
-    double * prod, double * xw, uint32_t * tab, const uint16_t * __restrict__ jt,
-    const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
-    const double * __restrict__ xt, int cbase, unsigned limit, int last, int lane, int chunks, bool shifted,
-    int len, int lead)
-{
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
-    double xs[XW / 64];
-#pragma unroll
-    for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks)
-            xs[ch] = xt[min((unsigned) (64 * ch + lane), limit)];
-    v2u c[QUADS];
-    v2d va[QUADS], vb[QUADS];
-    if (shifted) {
-        for (int i = lane; i < len; i += kWave)
-            tab[i] = (uint32_t) (first_row[i] + first_row_base - cbase);
-    }
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last;
-        if (!shifted)
-            c[q] = *reinterpret_cast<const v2u *>(jt + o);
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-    }
-#pragma unroll
-    for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks)
-            xw[64 * ch + lane] = xs[ch];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len;
-    const unsigned wlimit = (unsigned) (64 * chunks - 1); // garbage entries of shared quads stay inside the window
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            unsigned cc[4];
-            if (shifted) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ti = o + i - lead;
-                    const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-                    const unsigned r = (t * magic) >> 22;
-                    cc[i] = min(tab[t - r * (unsigned) len] + r, wlimit);
-                }
-            } else {
-                cc[0] = min(c[q].x & 0xFFFFu, wlimit);
-                cc[1] = min(c[q].x >> 16, wlimit);
-                cc[2] = min(c[q].y & 0xFFFFu, wlimit);
-                cc[3] = min(c[q].y >> 16, wlimit);
-            }
-            const double q0 = va[q].x * xw[cc[0]];
-            const double q1 = va[q].y * xw[cc[1]];
-            const double q2 = vb[q].x * xw[cc[2]];
-            const double q3 = vb[q].y * xw[cc[3]];
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-}
-
-// x window of a shifted tile whose columns are too far apart for one contiguous window (any
-// stencil in 2 or 3 dimensions): entry (row r, position pos) reads x[first_row[pos] + r], i.e. the
-// tile needs `len` runs of `rows` consecutive x entries.  Runs that touch or overlap are merged,
-// and the layout -- where each position's run starts in the window (xoff), which x entry each
-// window slot holds relative to the tile's first row (src) -- comes from the tile's pattern
-// record, which is shared by all tiles of the same shape and therefore cache-resident: the
-// window loads can be issued as soon as the descriptor is there (27-point stencil: 180 slots in
-// 9 runs instead of 486 gathered entries touching ~50 lines per instruction); the products then
-// read x from LDS.  Per-tile tables instead of patterns measured 201 vs 176 us (768 B per tile
-// and one more dependent round trip).
-template <int QUADS, int XW>
-__device__ __forceinline__ void tile_products_xseg(
-    double * prod, double * xw, uint16_t * tab, const int32_t * __restrict__ pat, int r0,
-    const double * __restrict__ at, const double * __restrict__ x,
-    int limit, int last, int lane, int chunks, int len, int lead)
-{
-    static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
-    int so[XW / 64];
-#pragma unroll
-    for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks)
-            so[ch] = pat[kPatSrc + 64 * ch + lane];
-    const unsigned xo = reinterpret_cast<const uint16_t *>(pat + kPatXoff)[lane < len ? lane : len - 1]; // len <= 64
-    v2d va[QUADS], vb[QUADS];
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < last ? o : last;
-        va[q] = *reinterpret_cast<const v2d *>(at + o);
-        vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-    }
-    double xs[XW / 64];
-#pragma unroll
-    for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks) {
-            int c = r0 + so[ch];
-            c = c < 0 ? 0 : (c > limit ? limit : c); // padding slots of the last chunk
-            xs[ch] = x[c];
-        }
-    tab[lane] = (uint16_t) xo;
-#pragma unroll
-    for (int ch = 0; ch < XW / 64; ++ch)
-        if (ch < chunks)
-            xw[64 * ch + lane] = xs[ch];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned magic = ((1u << 22) + (unsigned) len - 1u) / (unsigned) len;
-    const unsigned wlimit = (unsigned) (64 * chunks - 1);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            unsigned cc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ti = o + i - lead;
-                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-                const unsigned r = (t * magic) >> 22;
-                cc[i] = min((unsigned) tab[t - r * (unsigned) len] + r, wlimit);
-            }
-            const double q0 = va[q].x * xw[cc[0]];
-            const double q1 = va[q].y * xw[cc[1]];
-            const double q2 = vb[q].x * xw[cc[2]];
-            const double q3 = vb[q].y * xw[cc[3]];
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-}
-
-// ABL: timing experiments that switch parts of the work off (results are wrong by design):
-// 1 = x gather collapsed to two entries, 2 = row sums reduced to one LDS read per row.
-// Column panels (kernel variant PANELS): the matrix handed to the kernel is the plan's own copy, cut
-// into 8 column panels and stored panel by panel, "row" v = panel * rows + r holding row r's
-// entries of that panel.  Workgroups b, b + 8, b + 16, ... share an XCD (observed dispatch order,
-// used for speed only), so workgroup b works on panel b % 8: every XCD then gathers from one eighth
-// of x, which stays in its private 4 MB L2, instead of dragging all of x through it (2 M rows x 24
-// random columns: 694 us with x = 16 MB, 270 us with x = 2 MB).  A row's eight partial sums meet in
-// y through fp64 atomics.
-struct PanelInfo {
-    int first[9]; // tiles [first[k], first[k+1]) belong to panel k
-    int rows;     // rows of the matrix (= virtual rows per panel)
-};
-
-// VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
-// <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
-// only workgroup barrier of this kernel, passed by every wave before any of them can leave).
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
-__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
-    int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
-    const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
-    const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
-    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
-    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0)
-{
-    // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
-    // different ones (a partitioned multiply whose previous result is still being gathered); every
-    // row is read and written by the same lane, so the in-place case needs no ordering.
-    constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
-    __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
-    __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
-    __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
-    __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
-
-    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    const int lane = (int) __lane_id();
-    int w;
-    double * y = y_arg;
-    const double * y_in = y_in_arg;
-    if (PANELS) {
-        const int pk = (int) blockIdx.x & 7;
-        w = pinfo.first[pk] + ((int) blockIdx.x >> 3) * 4 + wave;
-        if (w >= pinfo.first[pk + 1])
-            return;
-        y = y_arg - (size_t) pk * (size_t) pinfo.rows; // virtual row v of panel pk is row v - pk * rows
-    } else {
-        w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
-        if (!VI && w >= ntiles)
-            return; // whole wave leaves; no workgroup barrier in the kernels without a value dictionary
-    }
-    double * prod = prod_all[wave];
-
-    // (VI: waves past the last tile read its descriptor and leave after the table barrier)
-    const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
-    const int4 d0 = desc[wd];
-    const int4 d1 = desc[wd + 1];
-    ValueLookup vtab{vtab_lds, false, 0.0, 0.0};
-    if (VI) {
-        vtab.tiny = nvalues <= 2; // kernel-uniform
-        if (vtab.tiny) {
-            vtab.t0 = vtable[0]; // scalar loads (the table is padded to kMaxIndexedValues entries)
-            vtab.t1 = vtable[1];
-        } else {
-            // the table load travels together with the descriptor loads; the only workgroup barrier of this kernel
-            if (threadIdx.x < kMaxIndexedValues)
-                vtab_lds[threadIdx.x] = vtable[threadIdx.x];
-            __syncthreads();
-        }
-        if (w >= ntiles)
-            return;
-    }
-    const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
-    const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
-    const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
-    const int meta = __builtin_amdgcn_readfirstlane(d0.z);
-    if (C16 && (meta & kTileMetaBlockWin))
-        return; // done by csr_blockwin_kernel (second launch of the same multiply)
-    const int maxlen = meta & 0xFFFF;
-    const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
-    const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
-    const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
-    const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
-    const int nrows = r1 - r0;
-    const int kb = k0 & ~3;
-
-    // kTileMetaFast (set by the host): a non-empty stream tile whose last quad lies inside the
-    // arrays, i.e. everything but long rows, tiles of empty rows and the ragged end of the matrix
-    if (meta & kTileMetaFast) {
-        // ---- stream tile, fast path ----------------------------------------------------
-        // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row
-        const int sub = lane >> lanes_log2;
-        const int part = lane & ((1 << lanes_log2) - 1);
-        const int rowi = sub < nrows ? sub : nrows - 1; // clamp instead of branching
-        double * yt = y + r0;
-        int ps, pe;
-        if (meta & kTileMetaUniform) {
-            // all rows equally long (the interior of any stencil): row bounds follow from the
-            // descriptor, row_ptr is not read at all
-            ps = k0 + rowi * maxlen;
-            pe = ps + maxlen;
-        } else {
-            const int32_t * pt = p + r0;
-            ps = pt[rowi];
-            pe = pt[rowi + 1];
-        }
-        const double * yin_t = y_in + r0;
-        // (value-dictionary variant: y is read once and written once per launch -- non-temporal, to keep it out of
-        // the way of x in the caches: 143 -> 139 us)
-        const double yv = (PANELS || (VI && (SPMV_VI_ABLATE & 2))) ? 0.0 // panels: the partial sums are added atomically
-            : (VI ? __builtin_nontemporal_load(yin_t + rowi) : yin_t[rowi]);
-        // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
-        const bool second = nrows > kWave; // wave-uniform; implies one lane per row
-        int psB = 0, peB = 0;
-        double yvB = 0.0;
-        if (second) {
-            const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
-            if (meta & kTileMetaUniform) {
-                psB = k0 + rowB * maxlen;
-                peB = psB + maxlen;
-            } else {
-                psB = p[r0 + rowB];
-                peB = p[r0 + rowB + 1];
-            }
-            if (!PANELS && !(VI && (SPMV_VI_ABLATE & 2)))
-                yvB = VI ? __builtin_nontemporal_load(yin_t + rowB) : yin_t[rowB];
-        }
-        const int last = (k1 - 1 - kb) & ~3;
-        if (VI && C16 && TILE == 512 && !PANELS && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen) {
-            // equally long shifted rows under a value dictionary: a lane per row, nothing parked in LDS
-            const bool pattern = (meta & kTileMetaPattern) != 0;
-            double zA, zB;
-            tile_rows_uniform_indexed<X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
-                                           vidx + kb, vtab, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
-            if (lane < nrows && !((SPMV_VI_ABLATE & 8) && lane > 0))
-                __builtin_nontemporal_store(yv + zA, yt + lane);
-            if (second && lane + kWave < nrows && !(SPMV_VI_ABLATE & 8))
-                __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
-            return;
-        }
-        if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen) {
-            const bool pattern = (meta & kTileMetaPattern) != 0;
-            double zA, zB;
-            tile_rows_uniform_values<QUADS, X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
-                                                 a + kb, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
-            if (lane < nrows)
-                yt[lane] = yv + zA;
-            if (second && lane + kWave < nrows)
-                yt[lane + kWave] = yvB + zB;
-            return;
-        }
-        // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
-        // of neighbouring tiles that share the first/last quad are multiplied as well and never
-        // read back
-        if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
-            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0],
-                                      reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]),
-                                      patterns + (size_t) cbase * kPatStride, r0,
-                                      a + kb, x, cols - 1, last, lane,
-                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
-        } else if (XW > 0 && C16 && (meta & kTileMetaXWin)) {
-            // with a pattern, desc.w is its number and the smallest column follows from it
-            const bool pattern = (meta & kTileMetaPattern) != 0;
-            const int32_t * pat = patterns + (size_t) (pattern ? cbase : 0) * kPatStride;
-            const int cb = pattern ? r0 + __builtin_amdgcn_readfirstlane(pat[3]) : cbase;
-            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb,
-                                      pattern ? pat + kPatRel : j + k0, pattern ? r0 : 0,
-                                      a + kb, x + cb, cb, (unsigned) (cols - 1 - cb), last, lane,
-                                      ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
-                                      maxlen > 0 ? maxlen : 1, k0 - kb);
-        }
-        else if (C16 && (meta & kTileMetaShifted)) {
-            const bool pattern = (meta & kTileMetaPattern) != 0;
-            tile_products_shifted<QUADS, X32, VI>(prod, first_row_all[C16 ? wave : 0],
-                                              pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
-                                              a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb, vidx + kb, vtab);
-        }
-        else if (C16 && (meta & kTileMetaNarrow))
-            tile_products_narrow<QUADS, ABL, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);
-        else
-            tile_products_wide<QUADS, X32, VI>(prod, j + kb, a + kb, x, last, lane, vidx + kb, vtab);
-        // same-wave LDS operations execute in order; the fences only pin the compiler
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // (4) row sums from LDS
-        const int s = ps - kb;
-        const int e_row = pe - kb;
-        double z;
-        if ((ABL & 2) || (VI && (SPMV_VI_ABLATE & 4))) {
-            z = prod[s];
-        } else if (lanes_log2 == 0) { // short rows: one lane per row, the reference's order
-            z = tile_row_sum<1>(prod, s, e_row, 0, maxlen);
-        } else {
-            const int trips = (maxlen + (1 << lanes_log2) - 1) >> lanes_log2;
-            switch (lanes_log2) {
-            case 1: z = tile_row_sum<2>(prod, s, e_row, part, trips); break;
-            case 2: z = tile_row_sum<4>(prod, s, e_row, part, trips); break;
-            case 3: z = tile_row_sum<8>(prod, s, e_row, part, trips); break;
-            case 4: z = tile_row_sum<16>(prod, s, e_row, part, trips); break;
-            case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
-            default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
-            }
-        }
-        if (sub < nrows && part == 0 && !(VI && (SPMV_VI_ABLATE & 8) && lane > 0)) {
-            if (PANELS)
-                unsafeAtomicAdd(yt + sub, z);
-            else if (VI)
-                __builtin_nontemporal_store(yv + z, yt + sub);
-            else
-                yt[sub] = yv + z;
-        }
-        if (second) {
-            const double zB = ((ABL & 2) || (VI && (SPMV_VI_ABLATE & 4))) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
-            if (lane + kWave < nrows && !(VI && (SPMV_VI_ABLATE & 8))) {
-                if (PANELS)
-                    unsafeAtomicAdd(yt + lane + kWave, zB);
-                else if (VI)
-                    __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
-                else
-                    yt[lane + kWave] = yvB + zB;
-            }
-        }
-    } else if (!partial && k1 - kb <= TILE) {
-        // ---- stream tile at the ragged end of the arrays, or a tile of empty rows: scalar
-        // loads, one lane per row
-        for (int k = k0 + lane; k < k1; k += kWave)
-            prod[k - kb] = a[k] * x[j[k]];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int r = lane; r < nrows; r += kWave) {
-            const int s = p[r0 + r] - kb, e_row = p[r0 + r + 1] - kb;
-            double z = 0.0;
-            for (int k = s; k < e_row; ++k)
-                z += prod[k];
-            if (PANELS)
-                unsafeAtomicAdd(y + r0 + r, z);
-            else
-                y[r0 + r] = y_in[r0 + r] + z;
-        }
-    } else if (!exact_order) {
-        // ---- one long row, or one chunk of a very long row: the wave strides it ----------
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-        int k = k0 + lane;
-        for (; k + 3 * kWave < k1; k += 4 * kWave) { // 4 independent gathers in flight
-            const int c0 = j[k], c1 = j[k + kWave], c2 = j[k + 2 * kWave], c3 = j[k + 3 * kWave];
-            const double v0 = a[k], v1 = a[k + kWave], v2 = a[k + 2 * kWave], v3 = a[k + 3 * kWave];
-            z0 += v0 * x[c0];
-            z1 += v1 * x[c1];
-            z2 += v2 * x[c2];
-            z3 += v3 * x[c3];
-        }
-        for (; k < k1; k += kWave)
-            z0 += a[k] * x[j[k]];
-        double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
-        if (lane == 0) {
-            if (partial || PANELS)
-                unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ
-            else
-                y[r0] = y_in[r0] + z;
-        }
-    } else {
-        // ---- one long row in the reference's order: lane 0 adds tiles of products ---------
-        double z = 0.0;
-        for (int t0 = k0; t0 < k1; t0 += TILE) {
-            const int t1 = (t0 + TILE < k1) ? t0 + TILE : k1;
-            for (int k = t0 + lane; k < t1; k += kWave)
-                prod[k - t0] = a[k] * x[j[k]];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane == 0)
-                for (int k = 0; k < t1 - t0; ++k)
-                    z += prod[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (lane == 0) {
-            if (PANELS)
-                unsafeAtomicAdd(y + r0, z);
-            else
-                y[r0] = y_in[r0] + z;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// CSR, balanced tiles ("segmented" row sums): for matrices whose rows are short on average but
-// skewed (a web graph: 3 entries per row, a few rows of hundreds).  The wave tiles above give a
-// row at least one lane and a long row several, so one 300-entry row confines its tile to 4 rows
-// and the matrix falls apart into tiles a fifth full: 29 556 waves for 3.1 M entries, 3.6 rounds
-// of waves that each wait out the same chain of memory round trips (measured, webbase-like:
-// 29 us, 61 % of the wave cycles waiting on memory; profiles/r02_prof_webbase_csr_summary.md).
-// Here a tile is filled by ENTRIES: up to 512 of them in up to 256 whole rows, whatever their
-// lengths (rows of more than 512 entries keep the long-row path).  The products go to the wave's
-// LDS slice as before; then every lane takes 8 CONSECUTIVE products and the row sums come out of a
-// segmented reduction whose cost does not depend on the row lengths:
-//   * every non-empty row marks its first entry's slot with its number (rowat[], 16 bit);
-//   * a lane adds its 8 products run by run, left to right (a row that begins and ends inside the
-//     lane is summed in the reference's order, bit for bit);
-//   * runs that cross lanes meet in one segmented inclusive scan over the lanes' last runs
-//     (ds_bpermute moves), and the lane in which the next row starts closes the row before it;
-//   * the sums are parked in LDS by row number (the product slots are free by then: every lane
-//     has its 8 products in registers), and the lanes write y for the rows they loaded y for.
-// No atomics, the same result on every run.  Rows that span two or more lanes are added in a
-// different order than the reference's loop: within 1e-10, not bit-identical
-// (SPMV_HIP_FLAG_EXACT_ORDER keeps the one-lane-per-row tiles).
-// ---------------------------------------------------------------------------------
-constexpr int kSegMaxRows = 256;
-constexpr int kTileMetaSeg = 1 << 21;
-
-template <bool C16, bool X32, bool XCD>
-__global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
-    int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
-    const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
-    const double * __restrict__ a, const double * __restrict__ x, const double * y_in, double * y,
-    int nnz_total, int cols)
-{
-    constexpr int TILE = 512, QUADS = 2, RPL = kSegMaxRows / kWave; // rows per lane
-    __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t rowat_all[4][TILE];
-
-    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    const int lane = (int) __lane_id();
-    // XCD: workgroups b, b + 8, b + 16, ... share an XCD and its L2; give each XCD one contiguous run of
-    // tiles, so that the x entries its rows refer to (a web graph links mostly within the neighbourhood
-    // of the row) collect in ONE L2 instead of being fetched over the fabric into all eight
-    const int w = (XCD ? xcd_remap((int) blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
-    if (w >= ntiles)
-        return; // whole wave leaves; no workgroup barrier in this kernel
-    double * prod = prod_all[wave];
-    uint16_t * rowat = rowat_all[wave];
-
-    const int4 d0 = desc[w];
-    const int4 d1 = desc[w + 1];
-    const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
-    const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
-    const int k0 = __builtin_amdgcn_readfirstlane(d0.y);
-    const int meta = __builtin_amdgcn_readfirstlane(d0.z);
-    const int cbase = __builtin_amdgcn_readfirstlane(d0.w);
-    const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
-    const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
-    const int nrows = r1 - r0;
-    const int kb = k0 & ~3;
-
-    if (meta & kTileMetaFast) {
-        // (1) row bounds and old y of up to four rows per lane: nobody waits for these yet
-        int ps[RPL], pe[RPL];
-        double yv[RPL];
-        const int32_t * pt = p + r0;
-        const double * yin_t = y_in + r0;
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            const int row = lane + kWave * i;
-            const int rc = row < nrows ? row : nrows - 1; // clamp instead of branching
-            ps[i] = pt[rc];
-            pe[i] = pt[rc + 1];
-            yv[i] = yin_t[rc];
-        }
-        // (2) the tile's column/value quads, gather x, park the rounded products
-        const int last = (k1 - 1 - kb) & ~3;
-        if (C16 && (meta & kTileMetaNarrow))
-            tile_products_narrow<QUADS, 0>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
-        else
-            tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
-        // (3) every non-empty row marks the slot of its first entry
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<v4u *>(rowat + 8 * lane) = v4u{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            const int row = lane + kWave * i;
-            if (row < nrows && pe[i] > ps[i])
-                rowat[ps[i] - kb] = (uint16_t) row;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // (4) this lane's 8 consecutive products and marks
-        const int e0 = 8 * lane;
-        double q[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const v2d t = *reinterpret_cast<const v2d *>(prod + e0 + 2 * i);
-            q[2 * i] = t.x;
-            q[2 * i + 1] = t.y;
-        }
-        const v4u rm = *reinterpret_cast<const v4u *>(rowat + e0);
-        int ra[8];
-        ra[0] = (int) (rm.x & 0xFFFFu); ra[1] = (int) (rm.x >> 16);
-        ra[2] = (int) (rm.y & 0xFFFFu); ra[3] = (int) (rm.y >> 16);
-        ra[4] = (int) (rm.z & 0xFFFFu); ra[5] = (int) (rm.z >> 16);
-        ra[6] = (int) (rm.w & 0xFFFFu); ra[7] = (int) (rm.w >> 16);
-        // the row my first entry belongs to = the last mark in the lanes before me (-1: none, i.e.
-        // the entries in front of the tile that share its first quad)
-        int mylast = -1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (ra[i] != 0xFFFF)
-                mylast = ra[i];
-        int incl = mylast;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int up = lane_up(incl, d);
-            if (lane >= d && incl < 0)
-                incl = up;
-        }
-        int carry = lane_up(incl, 1);
-        if (lane == 0)
-            carry = -1;
-        // everything below only reads registers and writes row sums: the product slots are free
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // (5) runs inside the lane, left to right
-        const int nend = k1 - kb;
-        int cur = carry;
-        double s = 0.0, s_first = 0.0;
-        bool multi = false; // a row starts somewhere in this lane
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (ra[i] != 0xFFFF) {
-                if (!multi) {
-                    s_first = s; // my part of the row that came in from the left (possibly nothing)
-                    multi = true;
-                } else {
-                    prod[cur] = s; // began and ended inside this lane: the reference's order
-                }
-                cur = ra[i];
-                s = 0.0;
-            }
-            if (e0 + i < nend)
-                s += q[i];
-        }
-        // (6) runs that cross lanes: segmented inclusive scan over the lanes' last runs
-        int head = multi ? 1 : 0;
-        double sc = s;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const double sp = lane_up(sc, d);
-            const int hp = lane_up(head, d);
-            if (lane >= d && !head) {
-                sc += sp;
-                head |= hp;
-            }
-        }
-        double s_prev = lane_up(sc, 1);
-        if (lane == 0)
-            s_prev = 0.0;
-        if (multi && carry >= 0)
-            prod[carry] = s_prev + s_first; // the row before my first mark ends here
-        if (lane == kWave - 1 && cur >= 0)
-            prod[cur] = sc; // the tile's last row
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // (7) y for the rows this lane loaded it for (empty rows: y unchanged but copied to y_out)
-        double * yt = y + r0;
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            const int row = lane + kWave * i;
-            if (row < nrows) {
-                const double z = pe[i] > ps[i] ? prod[row] : 0.0;
-                yt[row] = yv[i] + z;
-            }
-        }
-    } else if (!partial && k1 - kb <= TILE) {
-        // ---- tile at the ragged end of the arrays, or a tile of empty rows: scalar loads, one lane per row
-        for (int k = k0 + lane; k < k1; k += kWave)
-            prod[k - kb] = a[k] * x[j[k]];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int r = lane; r < nrows; r += kWave) {
-            const int s0 = p[r0 + r] - kb, e_row = p[r0 + r + 1] - kb;
-            double z = 0.0;
-            for (int k = s0; k < e_row; ++k)
-                z += prod[k];
-            y[r0 + r] = y_in[r0 + r] + z;
-        }
-    } else {
-        // ---- one long row, or one chunk of a very long row: the wave strides it
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-        int k = k0 + lane;
-        for (; k + 3 * kWave < k1; k += 4 * kWave) { // 4 independent gathers in flight
-            const int c0 = j[k], c1 = j[k + kWave], c2 = j[k + 2 * kWave], c3 = j[k + 3 * kWave];
-            const double v0 = a[k], v1 = a[k + kWave], v2 = a[k + 2 * kWave], v3 = a[k + 3 * kWave];
-            z0 += v0 * x[c0];
-            z1 += v1 * x[c1];
-            z2 += v2 * x[c2];
-            z3 += v3 * x[c3];
-        }
-        for (; k < k1; k += kWave)
-            z0 += a[k] * x[j[k]];
-        const double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
-        if (lane == 0) {
-            if (partial)
-                unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ
-            else
-                y[r0] = y_in[r0] + z;
-        }
-    }
-}
-
-// Plan-time kernels of the column panels.  csr_panel_count_kernel: entries of row r in panel k
-// -> count[k * rows + r] (one thread per row); after an exclusive scan over the 8 * rows counts,
-// csr_panel_scatter_kernel copies every entry to its panel's place, rows in order, entries of a
-// row in their original order.
-__global__ __launch_bounds__(256) void csr_panel_count_kernel(
-    int rows, int width, const int32_t * __restrict__ p, const int32_t * __restrict__ j, int32_t * __restrict__ count)
-{
-    const long long r = (long long) blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows)
-        return;
-    int n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = p[r]; k < p[r + 1]; ++k) {
-        const int pk = j[k] / width;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            n[q] += (pk == q);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-        count[(size_t) q * rows + r] = n[q];
-}
-
-__global__ __launch_bounds__(256) void csr_panel_scatter_kernel(
-    int rows, int width, const int32_t * __restrict__ p, const int32_t * __restrict__ j, const double * __restrict__ a,
-    const int32_t * __restrict__ vrow_ptr, int32_t * __restrict__ pj, double * __restrict__ pa)
-{
-    const long long r = (long long) blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows)
-        return;
-    int cur[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-        cur[q] = vrow_ptr[(size_t) q * rows + r];
-    for (int k = p[r]; k < p[r + 1]; ++k) {
-        const int c = j[k];
-        const int pk = c / width;
-        int dst = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (pk == q)
-                dst = cur[q]++;
-        pj[dst] = c;
-        pa[dst] = a[k];
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Block window: x staged through LDS for a whole workgroup.  A row whose columns are scattered
-// over a band (a finite-element matrix: 27 blocks of 3 columns anywhere within +-3000 of the
-// diagonal) gets nothing from a per-tile window -- no x entry is used twice inside a tile --
-// and its gather runs at the rate at which 128-byte lines come out of L2 (measured: 260 of
-// 465 us).  Sixteen consecutive tiles, however, share one window of a few thousand columns:
-// the workgroup (16 waves, one tile each) reads it once with coalesced loads into 48 KB of LDS
-// and every wave gathers from there.  One workgroup per CU fits (48 KB window + 16 product
-// slices), so the stream runs at half the usual occupancy: only blocks whose window fits and
-// whose tiles have no cheaper path are marked (csr_blockwin_mark_kernel), and the kernel is
-// only launched when they are the majority; csr_wavetile_kernel skips the marked tiles.
-// ---------------------------------------------------------------------------------
-constexpr int kBlockWinSlots = 8192; // doubles (the ring of csr_blockwin_stream_kernel)
-constexpr int kBlockWinTiles = 16;
-
-template <int TILE>
-__global__ __launch_bounds__(1024) void csr_blockwin_kernel(
-    int ntiles, const int4 * __restrict__ desc, const int2 * __restrict__ blocks,
-    const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
-    const double * __restrict__ x, const double * y_in, double * y)
-{
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    constexpr int QUADS = TILE / 256;
-    __shared__ double xwin[kBlockWinSlots];
-    __shared__ __attribute__((aligned(16))) double prod_all[kBlockWinTiles][TILE + 4];
-
-    const int2 bd = blocks[blockIdx.x];
-    const int xbase = __builtin_amdgcn_readfirstlane(bd.x);
-    const int span = __builtin_amdgcn_readfirstlane(bd.y);
-    if (span <= 0)
-        return; // not a window block: its tiles went through csr_wavetile_kernel
-    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    const int lane = (int) __lane_id();
-    const int w = blockIdx.x * kBlockWinTiles + wave;
-    const bool active = w < ntiles; // wave-uniform
-    double * prod = prod_all[wave];
-
-    // (1) the tile's own loads first: they do not depend on the window
-    int r0 = 0, k0 = 0, meta = 0, cbase = 0, nrows = 1, kb = 0, last = 0, maxlen = 1, lanes_log2 = 0;
-    int ps = 0, pe = 0, psB = 0, peB = 0;
-    double yv = 0.0, yvB = 0.0;
-    bool second = false;
-    v2u c[QUADS];
-    v2d va[QUADS], vb[QUADS];
-    if (active) {
-        const int4 d0 = desc[w];
-        const int4 d1 = desc[w + 1];
-        r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
-        k0 = __builtin_amdgcn_readfirstlane(d0.y);
-        meta = __builtin_amdgcn_readfirstlane(d0.z);
-        cbase = __builtin_amdgcn_readfirstlane(d0.w);
-        const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
-        const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
-        maxlen = meta & 0xFFFF;
-        lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
-        nrows = r1 - r0;
-        kb = k0 & ~3;
-        last = (k1 - 1 - kb) & ~3;
-        const int sub = lane >> lanes_log2;
-        const int rowi = sub < nrows ? sub : nrows - 1;
-        if (meta & kTileMetaUniform) {
-            ps = k0 + rowi * maxlen;
-            pe = ps + maxlen;
-        } else {
-            ps = p[r0 + rowi];
-            pe = p[r0 + rowi + 1];
-        }
-        yv = y_in[r0 + rowi];
-        second = nrows > kWave;
-        if (second) {
-            const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
-            if (meta & kTileMetaUniform) {
-                psB = k0 + rowB * maxlen;
-                peB = psB + maxlen;
-            } else {
-                psB = p[r0 + rowB];
-                peB = p[r0 + rowB + 1];
-            }
-            yvB = y_in[r0 + rowB];
-        }
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            int o = 256 * q + 4 * lane;
-            o = o < last ? o : last;
-            c[q] = *reinterpret_cast<const v2u *>(j16 + kb + o);
-            va[q] = *reinterpret_cast<const v2d *>(a + kb + o);
-            vb[q] = *reinterpret_cast<const v2d *>(a + kb + o + 2);
-        }
-    }
-    // (2) the block's window of x, by all 1024 threads
-    for (int i = (int) threadIdx.x; i < span; i += 1024)
-        xwin[i] = x[xbase + i];
-    __syncthreads();
-    if (!active)
-        return;
-    // (3) products from the window
-    const unsigned off = (unsigned) (cbase - xbase), wlimit = (unsigned) (span - 1);
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            const unsigned c0 = min(off + (c[q].x & 0xFFFFu), wlimit), c1 = min(off + (c[q].x >> 16), wlimit);
-            const unsigned c2 = min(off + (c[q].y & 0xFFFFu), wlimit), c3 = min(off + (c[q].y >> 16), wlimit);
-            const double q0 = va[q].x * xwin[c0];
-            const double q1 = va[q].y * xwin[c1];
-            const double q2 = vb[q].x * xwin[c2];
-            const double q3 = vb[q].y * xwin[c3];
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (4) row sums, as in csr_wavetile_kernel
-    const int sub = lane >> lanes_log2;
-    const int part = lane & ((1 << lanes_log2) - 1);
-    const int s = ps - kb, e_row = pe - kb;
-    double z;
-    if (lanes_log2 == 0) {
-        z = tile_row_sum<1>(prod, s, e_row, 0, maxlen);
-    } else {
-        const int trips = (maxlen + (1 << lanes_log2) - 1) >> lanes_log2;
-        switch (lanes_log2) {
-        case 1: z = tile_row_sum<2>(prod, s, e_row, part, trips); break;
-        case 2: z = tile_row_sum<4>(prod, s, e_row, part, trips); break;
-        case 3: z = tile_row_sum<8>(prod, s, e_row, part, trips); break;
-        case 4: z = tile_row_sum<16>(prod, s, e_row, part, trips); break;
-        case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
-        default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
-        }
-    }
-    if (sub < nrows && part == 0)
-        y[r0 + sub] = yv + z;
-    if (second) {
-        const double zB = tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
-        if (lane + kWave < nrows)
-            y[r0 + lane + kWave] = yvB + zB;
-    }
-}
-
-// The same with persistent workgroups and a sliding window.  Consecutive blocks of a band need
-// almost the same columns (the window moves on by the block's rows), so a workgroup that walks
-// through consecutive blocks keeps x in a ring of 8192 LDS slots (slot = column mod 8192) and only
-// loads what is new; and because the next block's streams -- and that window increment -- are
-// requested before the current block is multiplied, something is always in flight although only
-// one workgroup fits a CU.  Two barriers per block: before the ring is written (the previous
-// block's gathers are done) and after.
-constexpr int kBlockRing = 8192;
-
-template <int QUADS>
-struct BwTile {
-    int r0, k0, kb, last, nrows, maxlen, lanes_log2, cbase;
-    int ps, pe, psB, peB;
-    double yv, yvB;
-    unsigned cx[QUADS], cy[QUADS];
-    v2d va[QUADS], vb[QUADS];
-    bool valid, second;
-};
-
-template <int TILE>
-__device__ __forceinline__ void bw_load_tile(
-    BwTile<TILE / 256> & t, int w, int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
-    const uint16_t * __restrict__ j16, const double * __restrict__ a, const double * y, int lane)
-{
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    constexpr int QUADS = TILE / 256;
-    t.valid = w < ntiles;
-    if (!t.valid)
-        return;
-    const int4 d0 = desc[w];
-    const int4 d1 = desc[w + 1];
-    const int meta = __builtin_amdgcn_readfirstlane(d0.z);
-    t.valid = (meta & kTileMetaBlockWin) != 0;
-    if (!t.valid)
-        return;
-    t.r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
-    t.k0 = __builtin_amdgcn_readfirstlane(d0.y);
-    t.cbase = __builtin_amdgcn_readfirstlane(d0.w);
-    const int r1 = __builtin_amdgcn_readfirstlane(d1.x & ~kTileFlagPartial);
-    const int k1 = __builtin_amdgcn_readfirstlane(d1.y);
-    t.maxlen = meta & 0xFFFF;
-    t.lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7;
-    t.nrows = r1 - t.r0;
-    t.kb = t.k0 & ~3;
-    t.last = (k1 - 1 - t.kb) & ~3;
-    const int sub = lane >> t.lanes_log2;
-    const int rowi = sub < t.nrows ? sub : t.nrows - 1;
-    const bool uniform = (meta & kTileMetaUniform) != 0;
-    if (uniform) {
-        t.ps = t.k0 + rowi * t.maxlen;
-        t.pe = t.ps + t.maxlen;
-    } else {
-        t.ps = p[t.r0 + rowi];
-        t.pe = p[t.r0 + rowi + 1];
-    }
-    t.yv = y[t.r0 + rowi];
-    t.second = t.nrows > kWave;
-    t.psB = t.peB = 0;
-    t.yvB = 0.0;
-    if (t.second) {
-        const int rowB = lane + kWave < t.nrows ? lane + kWave : t.nrows - 1;
-        if (uniform) {
-            t.psB = t.k0 + rowB * t.maxlen;
-            t.peB = t.psB + t.maxlen;
-        } else {
-            t.psB = p[t.r0 + rowB];
-            t.peB = p[t.r0 + rowB + 1];
-        }
-        t.yvB = y[t.r0 + rowB];
-    }
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        int o = 256 * q + 4 * lane;
-        o = o < t.last ? o : t.last;
-        const v2u c = *reinterpret_cast<const v2u *>(j16 + t.kb + o);
-        t.cx[q] = c.x;
-        t.cy[q] = c.y;
-        t.va[q] = *reinterpret_cast<const v2d *>(a + t.kb + o);
-        t.vb[q] = *reinterpret_cast<const v2d *>(a + t.kb + o + 2);
-    }
-}
-
-template <int TILE>
-__device__ __forceinline__ void bw_compute_tile(
-    const BwTile<TILE / 256> & t, double * prod, const double * xring, double * y, int lane)
-{
-    constexpr int QUADS = TILE / 256;
-    const unsigned base = (unsigned) t.cbase;
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= t.last) {
-            // columns of the tile proper lie inside the ring's window; entries of neighbouring tiles
-            // that share a quad read some slot or other and are never summed
-            const unsigned c0 = (base + (t.cx[q] & 0xFFFFu)) & (kBlockRing - 1), c1 = (base + (t.cx[q] >> 16)) & (kBlockRing - 1);
-            const unsigned c2 = (base + (t.cy[q] & 0xFFFFu)) & (kBlockRing - 1), c3 = (base + (t.cy[q] >> 16)) & (kBlockRing - 1);
-            const double q0 = t.va[q].x * xring[c0];
-            const double q1 = t.va[q].y * xring[c1];
-            const double q2 = t.vb[q].x * xring[c2];
-            const double q3 = t.vb[q].y * xring[c3];
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = v2d{q0, q1};
-            dst[1] = v2d{q2, q3};
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int sub = lane >> t.lanes_log2;
-    const int part = lane & ((1 << t.lanes_log2) - 1);
-    const int s = t.ps - t.kb, e_row = t.pe - t.kb;
-    double z;
-    if (t.lanes_log2 == 0) {
-        z = tile_row_sum<1>(prod, s, e_row, 0, t.maxlen);
-    } else {
-        const int trips = (t.maxlen + (1 << t.lanes_log2) - 1) >> t.lanes_log2;
-        switch (t.lanes_log2) {
-        case 1: z = tile_row_sum<2>(prod, s, e_row, part, trips); break;
-        case 2: z = tile_row_sum<4>(prod, s, e_row, part, trips); break;
-        case 3: z = tile_row_sum<8>(prod, s, e_row, part, trips); break;
-        case 4: z = tile_row_sum<16>(prod, s, e_row, part, trips); break;
-        case 5: z = tile_row_sum<32>(prod, s, e_row, part, trips); break;
-        default: z = tile_row_sum<64>(prod, s, e_row, part, trips); break;
-        }
-    }
-    if (sub < t.nrows && part == 0)
-        y[t.r0 + sub] = t.yv + z;
-    if (t.second) {
-        const double zB = tile_row_sum<1>(prod, t.psB - t.kb, t.peB - t.kb, 0, t.maxlen);
-        if (lane + kWave < t.nrows)
-            y[t.r0 + lane + kWave] = t.yvB + zB;
-    }
-    // the product slice is reused by this wave's next tile: its reads above come first
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int TILE>
-__global__ __launch_bounds__(1024) void csr_blockwin_stream_kernel(
-    int ntiles, int nblocks, int blocks_per_group, const int4 * __restrict__ desc, const int2 * __restrict__ blocks,
-    const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
-    const double * __restrict__ x, const double * y_in, double * y)
-{
-    constexpr int XS = kBlockWinSlots / 1024; // window increments a thread may have to carry
-    __shared__ double xring[kBlockRing];
-    __shared__ __attribute__((aligned(16))) double prod_all[kBlockWinTiles][TILE + 4];
-    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    const int lane = (int) __lane_id();
-    const int tid = (int) threadIdx.x;
-    double * prod = prod_all[wave];
-    const int b_begin = (int) blockIdx.x * blocks_per_group;
-    const int b_end = min(nblocks, b_begin + blocks_per_group);
-    if (b_begin >= b_end)
-        return;
-
-    int wlo = 0, whi = 0; // columns [wlo, whi) are in the ring (wave-uniform)
-    BwTile<TILE / 256> cur, nxt;
-    double xs[XS];
-    int xs_from = 0, xs_hi = 0, xs_lo = 0; // the increment carried in xs belongs to window [xs_lo, xs_hi)
-    // prologue: the first block's streams and its whole window
-    {
-        const int2 bd = blocks[b_begin];
-        const int span = __builtin_amdgcn_readfirstlane(bd.y);
-        xs_lo = xs_from = __builtin_amdgcn_readfirstlane(bd.x);
-        xs_hi = xs_lo + (span > 0 ? span : 0);
-        bw_load_tile<TILE>(nxt, b_begin * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y_in, lane);
-#pragma unroll
-        for (int k = 0; k < XS; ++k) {
-            const int i = xs_from + tid + 1024 * k;
-            xs[k] = i < xs_hi ? x[i] : 0.0;
-        }
-    }
-    for (int b = b_begin; b < b_end; ++b) {
-        cur = nxt;
-        const bool window = xs_hi > xs_lo; // this block has a window
-        __syncthreads(); // the previous block's gathers are done: ring slots may be overwritten
-        if (window) {
-#pragma unroll
-            for (int k = 0; k < XS; ++k) {
-                const int i = xs_from + tid + 1024 * k;
-                if (i < xs_hi)
-                    xring[i & (kBlockRing - 1)] = xs[k];
-            }
-            wlo = xs_lo;
-            whi = xs_hi;
-        } else {
-            wlo = whi = 0;
-        }
-        __syncthreads();
-        // requests for the next block: its tiles' streams and what its window adds to the ring
-        if (b + 1 < b_end) {
-            const int2 bd = blocks[b + 1];
-            const int span = __builtin_amdgcn_readfirstlane(bd.y);
-            xs_lo = __builtin_amdgcn_readfirstlane(bd.x);
-            xs_hi = xs_lo + (span > 0 ? span : 0);
-            // columns already in the ring stay valid if the new window starts inside the old one
-            xs_from = (whi > wlo && xs_lo >= wlo && xs_lo <= whi) ? max(whi, xs_lo) : xs_lo;
-            bw_load_tile<TILE>(nxt, (b + 1) * kBlockWinTiles + wave, ntiles, desc, p, j16, a, y_in, lane);
-#pragma unroll
-            for (int k = 0; k < XS; ++k) {
-                const int i = xs_from + tid + 1024 * k;
-                xs[k] = i < xs_hi ? x[i] : 0.0;
-            }
-        } else {
-            nxt.valid = false;
-            xs_lo = xs_hi = xs_from = 0;
-        }
-        if (window && cur.valid)
-            bw_compute_tile<TILE>(cur, prod, xring, y, lane);
-    }
-}
-
-// Plan-time: one workgroup per 16 consecutive tiles.  The block gets a window if every tile is a
-// plain narrow fast tile (no shifted tile, no per-tile window: those are cheaper), the union of
-// their column ranges fits kBlockWinSlots and has at least as many entries as slots.  With
-// apply == 0 only counts[3] += tiles that would be marked; with apply != 0 the tiles are marked
-// and blocks[b] = {first column, slots} (0 slots = no window).
-__global__ __launch_bounds__(1024) void csr_blockwin_mark_kernel(
-    int ntiles, int tile, int4 * __restrict__ desc, const uint16_t * __restrict__ j16,
-    int2 * __restrict__ blocks, int * __restrict__ counts, int apply)
-{
-    __shared__ int s_min[kBlockWinTiles], s_max[kBlockWinTiles], s_ok[kBlockWinTiles], s_entries[kBlockWinTiles];
-    __shared__ int s_decision[2];
-    const int wave = (int) threadIdx.x >> 6;
-    const int lane = (int) __lane_id();
-    const int w = blockIdx.x * kBlockWinTiles + wave;
-    int ok = 1, cmin = 0x7FFFFFFF, cmax = -1, entries = 0;
-    if (w < ntiles) {
-        const int4 d0 = desc[w];
-        const int k0 = d0.y, k1 = desc[w + 1].y;
-        const int m = d0.z;
-        ok = !(d0.x & kTileFlagPartial) && (m & kTileMetaNarrow) && (m & kTileMetaFast)
-             && !(m & (kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern)) && k1 - (k0 & ~3) <= tile;
-        if (ok) {
-            int mx = 0;
-            for (int k = k0 + lane; k < k1; k += kWave)
-                mx = max(mx, (int) j16[k]);
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1)
-                mx = max(mx, __shfl_xor(mx, d));
-            cmin = d0.w;
-            cmax = d0.w + mx;
-            entries = k1 - k0;
-        }
-    }
-    if (lane == 0) {
-        s_min[wave] = cmin;
-        s_max[wave] = cmax;
-        s_ok[wave] = ok;
-        s_entries[wave] = entries;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int all = 1, lo = 0x7FFFFFFF, hi = -1, n = 0, tiles = 0;
-        for (int t = 0; t < kBlockWinTiles; ++t) {
-            all &= s_ok[t];
-            if (s_max[t] >= 0) {
-                lo = min(lo, s_min[t]);
-                hi = max(hi, s_max[t]);
-                n += s_entries[t];
-                ++tiles;
-            }
-        }
-        const int span = hi - lo + 1;
-        const int yes = all && tiles > 0 && span <= kBlockWinSlots && n >= span;
-        s_decision[0] = yes ? lo : 0;
-        s_decision[1] = yes ? span : 0;
-        if (yes)
-            atomicAdd(counts + 3, tiles);
-        if (apply)
-            blocks[blockIdx.x] = make_int2(yes ? lo : 0, yes ? span : 0);
-    }
-    __syncthreads();
-    if (apply && s_decision[1] > 0 && w < ntiles && lane == 0)
-        desc[w].z |= kTileMetaBlockWin;
-}
-
-// Plan-time pass (one wave per tile) that classifies the stream tiles and writes the second index
-// stream; counts[0..2] receive the number of narrow / shifted / windowed tiles.
-//  narrow:  the columns span < 65536: their offsets from the smallest one go to j16 (10 instead of
-//           12 bytes per entry), desc.w = that column;
-//  shifted: at least two equally long rows (<= kShiftedMaxLen entries) that all repeat the first
-//           row's columns moved right by the row distance -- whatever range they span: the kernel
-//           reads the first row's 32-bit columns and no others (8 bytes per entry);
-//  window:  x staged through LDS by the XW kernel variant, for a narrow tile whose columns span
-//           < 256 (kTileMetaXWin) or a shifted tile whose merged runs of x fit 256 slots
-//           (kTileMetaXSeg; the run tables go to the tile's j16 slots, which a shifted tile does not
-//           read), in both cases only if every slot is used at least twice (measured: 81/row band
-//           5.6 uses per slot 284 -> 257 us, 27-point stencil 2.7 uses 216 -> 199 us, 5-point
-//           stencil 1.65 uses 44.9 -> 51.3 us on a cache-resident 2048^2 grid).
-__global__ __launch_bounds__(256) void csr_tile_compress_kernel(
-    int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ j16, int * __restrict__ counts, int detect_shifted,
-    unsigned long long * __restrict__ fingerprint, int panel_width)
-{
-    const int wave = (int) threadIdx.x >> 6;
-    const int lane = (int) __lane_id();
-    const int w = blockIdx.x * 4 + wave;
-    if (w >= ntiles)
-        return;
-    const int4 d0 = desc[w];
-    const int k0 = d0.y, k1 = desc[w + 1].y;
-    if ((d0.x & kTileFlagPartial) || k1 <= k0 || k1 - (k0 & ~3) > tile)
-        return; // long rows and empty tiles keep 32-bit indices
-    int cmin = 0x7FFFFFFF, cmax = -1;
-    for (int k = k0 + lane; k < k1; k += kWave) {
-        const int c = j[k];
-        cmin = c < cmin ? c : cmin;
-        cmax = c > cmax ? c : cmax;
-    }
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int omin = __shfl_xor(cmin, d), omax = __shfl_xor(cmax, d);
-        cmin = omin < cmin ? omin : cmin;
-        cmax = omax > cmax ? omax : cmax;
-    }
-    if (cmin < 0)
-        return;
-    // counts[4]: tiles whose columns reach further than one column panel (an eighth of the matrix):
-    // what "scattered" means for spmv_hip_plan_csr_repack
-    if (lane == 0 && cmax - cmin >= panel_width)
-        atomicAdd(counts + 4, 1);
-    const bool narrow = cmax - cmin < 65536;
-    if (narrow)
-        for (int k = k0 + lane; k < k1; k += kWave)
-            j16[k] = (uint16_t) (j[k] - cmin);
-    const int len = d0.z & 0xFFFF;
-    int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
-                  && len <= kShiftedMaxLen && k1 - k0 >= 2 * len && tile <= 1024;
-    if (shifted) {
-        int ok = 1;
-        for (int k = k0 + lane; k < k1; k += kWave) {
-            const int t = k - k0, r = t / len;
-            ok &= (j[k] == j[k0 + (t - r * len)] + r);
-        }
-        shifted = __all(ok);
-    }
-    int xwin = 0;
-    if (narrow && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
-        xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
-    if (shifted && fingerprint) {
-        // the tile's shape: (row length, rows, first-row columns relative to the first row);
-        // csr_pattern_assign_kernel gives it its pattern later (and a window of runs if it pays)
-        const int r0 = d0.x & ~kTileFlagPartial;
-        unsigned long long h = 0;
-        for (int pos = lane; pos < len; pos += kWave) {
-            unsigned long long t = (unsigned long long) (unsigned) (j[k0 + pos] - r0) + 0x9E3779B97F4A7C15ull * (unsigned long long) (pos + 1);
-            t ^= t >> 29;
-            t *= 0xBF58476D1CE4E5B9ull;
-            t ^= t >> 32;
-            h += t;
-        }
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1)
-            h += __shfl_xor(h, s);
-        h += 0x94D049BB133111EBull * (unsigned long long) len + 0xD6E8FEB86659FD93ull * (unsigned long long) ((k1 - k0) / len);
-        if (lane == 0)
-            fingerprint[w] = h | 1ull; // 0 = no shape
-    }
-    if (!narrow && !shifted)
-        return;
-    if (lane == 0) {
-        desc[w].z = d0.z | (narrow ? kTileMetaNarrow : 0) | (shifted ? kTileMetaShifted : 0) | xwin;
-        if (narrow) {
-            desc[w].w = cmin;
-            atomicAdd(counts, 1);
-        }
-        if (shifted)
-            atomicAdd(counts + 1, 1);
-        if (xwin)
-            atomicAdd(counts + 2, 1);
-    }
-}
-
-// One wave per pattern: write the record of pattern p from its representative tile.  Rows of up
-// to 64 entries also get the layout of a window of runs: lane = position in the row; a position
-// whose column is within `rows` of the previous one continues its run, so the runs' x ranges
-// [column, column + rows) are merged where they touch or overlap.
-__global__ __launch_bounds__(64) void csr_pattern_build_kernel(
-    const int * __restrict__ rep_tile, const int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    int32_t * __restrict__ patterns)
-{
-    const int lane = (int) __lane_id();
-    const int w = rep_tile[blockIdx.x];
-    int32_t * pat = patterns + (size_t) blockIdx.x * kPatStride;
-    const int4 d0 = desc[w];
-    const int r0 = d0.x & ~kTileFlagPartial;
-    const int k0 = d0.y, k1 = desc[w + 1].y;
-    const int len = d0.z & 0xFFFF;
-    const int nrows = (k1 - k0) / len;
-    int relmin = 0x7FFFFFFF;
-    for (int pos = lane; pos < len; pos += kWave) {
-        const int rel = j[k0 + pos] - r0;
-        pat[kPatRel + pos] = rel;
-        relmin = rel < relmin ? rel : relmin;
-    }
-#pragma unroll
-    for (int s = 1; s < kWave; s <<= 1) {
-        const int o = __shfl_xor(relmin, s);
-        relmin = o < relmin ? o : relmin;
-    }
-    int total = 1 << 20;
-    if (len <= kWave) {
-        const int col = lane < len ? j[k0 + lane] : 0;
-        const int d = col - __shfl_up(col, 1);
-        const int fresh = lane == 0 || d < 0 || d > nrows;
-        int xo = (lane == 0 || lane >= len) ? 0 : (fresh ? nrows : d);
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1) {
-            const int up = __shfl_up(xo, s);
-            if (lane >= s)
-                xo += up;
-        }
-        total = __shfl(xo, len - 1) + nrows;
-        const int d_next = __shfl_down(d, 1), fresh_next = __shfl_down(fresh, 1);
-        uint16_t * xoff = reinterpret_cast<uint16_t *>(pat + kPatXoff);
-        const int col0 = __shfl(col, 0);
-        for (int i = (total < 256 ? total : 256) + lane; i < 256; i += kWave)
-            pat[kPatSrc + i] = col0 - r0; // unused slots: any valid entry
-        if (lane < len) {
-            xoff[lane] = (uint16_t) (xo < 65535 ? xo : 65535);
-            const int cnt = (lane == len - 1 || fresh_next) ? nrows : d_next;
-            for (int i = 0; i < cnt && xo + i < 256; ++i)
-                pat[kPatSrc + xo + i] = col - r0 + i;
-        }
-    }
-    if (lane == 0) {
-        pat[0] = len;
-        pat[1] = nrows;
-        pat[2] = total;
-        pat[3] = relmin;
-    }
-}
-
-// One wave per tile: a candidate (fingerprint != 0) whose fingerprint is among the patterns' and
-// whose shape really equals that pattern's gets the pattern number in desc.w and is marked
-// kTileMetaXSeg; counts[2] += 1.
-__global__ __launch_bounds__(256) void csr_pattern_assign_kernel(
-    int ntiles, int4 * __restrict__ desc, const int32_t * __restrict__ j,
-    const unsigned long long * __restrict__ fingerprint, const unsigned long long * __restrict__ pattern_fp,
-    int npatterns, const int32_t * __restrict__ patterns, int * __restrict__ counts)
-{
-    const int wave = (int) threadIdx.x >> 6;
-    const int lane = (int) __lane_id();
-    const int w = blockIdx.x * 4 + wave;
-    if (w >= ntiles)
-        return;
-    const unsigned long long fp = fingerprint[w];
-    if (fp == 0)
-        return;
-    const unsigned long long hit = __ballot(lane < npatterns && pattern_fp[lane < npatterns ? lane : 0] == fp);
-    if (hit == 0)
-        return;
-    const int p = __builtin_ctzll(hit);
-    const int32_t * pat = patterns + (size_t) p * kPatStride;
-    const int4 d0 = desc[w];
-    const int r0 = d0.x & ~kTileFlagPartial;
-    const int k0 = d0.y, k1 = desc[w + 1].y;
-    const int len = d0.z & 0xFFFF;
-    int same = len == pat[0] && (k1 - k0) == pat[1] * len;
-    if (same)
-        for (int pos = lane; pos < len; pos += kWave)
-            same &= (j[k0 + pos] - r0) == pat[kPatRel + pos];
-    if (!__all(same))
-        return;
-    if (lane == 0) {
-        // a window of runs only where every slot is used at least twice (see above), and a
-        // contiguous window (already marked) is the better one where both apply
-        const int total = pat[2];
-        const bool window = !(d0.z & kTileMetaXWin) && total <= 256 && 2 * total <= k1 - k0;
-        desc[w].z = d0.z | kTileMetaPattern
-                    | (window ? (kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift)) : 0);
-        desc[w].w = p;
-        if (window)
-            atomicAdd(counts + 2, 1);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// COO in any order.  Each wave takes 64 consecutive entries per step, forms the
-// products, adds runs of equal row index inside the wave (segmented inclusive scan
-// over head flags, ds_bpermute moves) and issues ONE fp64 atomic per run, so a
-// row-sorted file costs ~1 atomic per row per wave and an unsorted one degrades to
-// one atomic per entry -- the semantics of the reference's coo_spmv_atomic
-// (src/matrix/coo-matrix.cpp:287-309).
-// ---------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void coo_kernel(
-    int nnz, const int32_t * __restrict__ ri, const int32_t * __restrict__ ci,
-    const double * __restrict__ v, const double * __restrict__ x, double * __restrict__ y)
-{
-    const int lane = (int) __lane_id();
-    const long long total = (long long) gridDim.x * BLOCK;
-    const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
-    for (long long base = 0; base < nnz; base += total) { // uniform trip count
-        const long long k = base + gid;
-        const bool valid = k < nnz;
-        int r = -1;
-        double s = 0.0;
-        if (valid) {
-            r = ri[k];
-            s = v[k] * x[ci[k]];
-        }
-        const int rprev = lane_up(r, 1);
-        int head = (lane == 0) || (rprev != r);
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const double sp = lane_up(s, d);
-            const int hp = lane_up(head, d);
-            if (lane >= d && !head) {
-                s += sp;
-                head |= hp;
-            }
-        }
-        const int rnext = lane_down1(r);
-        const bool tail = (lane == kWave - 1) || (rnext != r);
-        if (valid && tail)
-            unsafeAtomicAdd(y + r, s);
-    }
-}
-
-// The same semantics with 256 consecutive entries per wave, four per lane (one 16-byte load of
-// each index stream and two of the values per lane).  A lane first adds its own entries run by
-// run; runs that begin and end inside the lane are complete.  Across lanes only one (row, sum)
-// pair per lane takes part in the segmented scan: the lane's last run.  A lane's first run is
-// closed by that lane (carry of the preceding lanes + its own part), its last run by the lane
-// where the row changes next.  Row-sorted input with 5 entries per row thus issues one atomic
-// instruction with ~51 active lanes per 256 entries instead of four with ~13: fp64 atomics are
-// paid per wave instruction (MI355X_MICROARCH.md, "Global float atomics").
-// Entries past nnz (last wave only) are loaded one by one and carry row -1.
-// PANELS: the triplets are the context's own copy, grouped by column panel (an eighth of the
-// columns each; inside a panel in row order), every panel padded with row -1 entries to whole
-// workgroups.  Workgroup b takes its 1024 entries from panel b % 8, so each XCD gathers from one
-// eighth of x out of its own L2 (see csr_wavetile_kernel, PANELS).
-struct CooPanels {
-    long long start[9]; // entries [start[k], start[k+1]) are panel k; multiples of 1024
-};
-
-template <bool PANELS>
-__global__ __launch_bounds__(256) void coo_wide_kernel(
-    int nnz, const int32_t * __restrict__ ri, const int32_t * __restrict__ ci,
-    const double * __restrict__ v, const double * __restrict__ x, double * __restrict__ y, CooPanels cp)
-{
-    const int lane = (int) __lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    long long base;
-    if (PANELS) {
-        const int pk = (int) blockIdx.x & 7;
-        base = cp.start[pk] + ((long long) (blockIdx.x >> 3) * 4 + wave) * 256;
-        if (base >= cp.start[pk + 1])
-            return;
-    } else {
-        base = ((long long) blockIdx.x * 4 + wave) * 256;
-    }
-    if (base >= nnz)
-        return; // whole wave
-    const int o = 4 * lane;
-    int r[4];
-    double q[4];
-    if (base + 256 <= nnz) {
-        const v4i rr = *reinterpret_cast<const v4i *>(ri + base + o);
-        const v4i cc = *reinterpret_cast<const v4i *>(ci + base + o);
-        const v2d va = *reinterpret_cast<const v2d *>(v + base + o);
-        const v2d vb = *reinterpret_cast<const v2d *>(v + base + o + 2);
-        r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
-        q[0] = va.x * x[cc.x];
-        q[1] = va.y * x[cc.y];
-        q[2] = vb.x * x[cc.z];
-        q[3] = vb.y * x[cc.w];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long k = base + o + i;
-            const bool valid = k < nnz;
-            r[i] = valid ? ri[k] : -1;
-            q[i] = valid ? v[k] * x[ci[k]] : 0.0;
-        }
-    }
-    // runs inside the lane
-    const int r_first = r[0];
-    int r_cur = r[0];
-    double s_cur = q[0], s_first = 0.0;
-    bool multi = false;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        if (r[i] == r_cur) {
-            s_cur += q[i];
-        } else {
-            if (!multi) {
-                s_first = s_cur;
-                multi = true;
-            } else if (r_cur >= 0) {
-                unsafeAtomicAdd(y + r_cur, s_cur); // began and ended in this lane
-            }
-            r_cur = r[i];
-            s_cur = q[i];
-        }
-    }
-    // segmented inclusive scan over the lanes' last runs
-    const int r_last = r_cur;
-    const int r_prev = lane_up(r_last, 1);
-    const bool cont = lane > 0 && r_prev == r_first; // my first run continues the previous lane's last
-    int head = multi || !cont;
-    double s = s_cur;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const double sp = lane_up(s, d);
-        const int hp = lane_up(head, d);
-        if (lane >= d && !head) {
-            s += sp;
-            head |= hp;
-        }
-    }
-    const double s_prev = lane_up(s, 1);
-    const int next_cont = lane_down1((int) cont);
-    const bool tail = lane == kWave - 1 || !next_cont;
-    // one (row, sum) per lane in the common case: the end of its first run, or of its only run
-    const int r_out = multi ? r_first : (tail ? r_last : -1);
-    const double s_out = multi ? (cont ? s_prev + s_first : s_first) : s;
-    if (r_out >= 0)
-        unsafeAtomicAdd(y + r_out, s_out);
-    if (multi && tail && r_last >= 0)
-        unsafeAtomicAdd(y + r_last, s);
-}
-
-// Plan-time: how many 256-entry chunks of the (row-sorted) triplets have columns that reach further
-// than one column panel -- what "scattered" means for the COO panels.
-__global__ __launch_bounds__(256) void coo_chunk_spread_kernel(
-    int nnz, int width, const int32_t * __restrict__ ci, int * __restrict__ count)
-{
-    const int lane = (int) __lane_id();
-    const long long base = ((long long) blockIdx.x * 4 + (threadIdx.x >> 6)) * 256;
-    if (base >= nnz)
-        return;
-    int lo = 0x7FFFFFFF, hi = -1;
-    for (int i = lane; i < 256 && base + i < nnz; i += kWave) {
-        const int c = ci[base + i];
-        lo = min(lo, c);
-        hi = max(hi, c);
-    }
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        lo = min(lo, __shfl_xor(lo, d));
-        hi = max(hi, __shfl_xor(hi, d));
-    }
-    if (lane == 0 && hi - lo >= width)
-        atomicAdd(count, 1);
-}
-
-// ---------------------------------------------------------------------------------
-// ELLPACK.  The reference stores row-major (k = i*L + l), which on a GPU would make
-// lanes read with stride 12*L bytes; the upload transposes to column-major
-// (k = l*rows + i) so lane i reads consecutive addresses for each l.
-// One lane per row, l ascending, padded entries multiplied like real ones:
-// bit-exact with ell_spmv_inner_loop (src/matrix/ell-matrix.cpp:243-258).
-// ---------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ell_kernel(
-    int rows, int row_length, const int32_t * __restrict__ j, const double * __restrict__ a,
-    const double * __restrict__ x, double * __restrict__ y)
-{
-    const long long stride = (long long) gridDim.x * BLOCK;
-    for (long long i = (long long) blockIdx.x * BLOCK + threadIdx.x; i < rows; i += stride) {
-        double z = 0.0;
-        int l = 0;
-        for (; l + 4 <= row_length; l += 4) {
-            const long long k = (long long) l * rows + i;
-            const int c0 = j[k], c1 = j[k + rows], c2 = j[k + 2LL * rows], c3 = j[k + 3LL * rows];
-            const double v0 = a[k], v1 = a[k + rows], v2 = a[k + 2LL * rows], v3 = a[k + 3LL * rows];
-            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-            z += v0 * x0;
-            z += v1 * x1;
-            z += v2 * x2;
-            z += v3 * x3;
-        }
-        for (; l < row_length; ++l) {
-            const long long k = (long long) l * rows + i;
-            z += a[k] * x[j[k]];
-        }
-        y[i] += z;
-    }
-}
-
-// Row-major -> column-major (upload time only).  A wave reads 64 consecutive
-// row-major elements (coalesced) and scatters them; the scatter is absorbed by L2.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ell_transpose_kernel(
-    int rows, int row_length, const int32_t * __restrict__ j_rm, const double * __restrict__ a_rm,
-    int32_t * __restrict__ j_cm, double * __restrict__ a_cm)
-{
-    const long long n = (long long) rows * row_length;
-    const long long stride = (long long) gridDim.x * BLOCK;
-    for (long long k = (long long) blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
-        const long long i = k / row_length;
-        const long long l = k - i * row_length;
-        j_cm[l * rows + i] = j_rm[k];
-        a_cm[l * rows + i] = a_rm[k];
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Upload-time checks on the device (the host arrays are never walked entry by entry).
-// index_check_kernel: flags[0] |= 1 if any idx[k] is outside [0, limit); with `sorted_flag`,
-// flags[1] |= 1 if idx is not non-decreasing.  column_checksum_kernel: out += sum over k of
-// hash(k, j[k]) -- the plan's content guard (a different array at the same address changes it).
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void index_check_kernel(
-    long long n, int limit, const int32_t * __restrict__ idx, int * __restrict__ flags, int sorted_flag)
-{
-    const long long stride = (long long) gridDim.x * 256;
-    int bad = 0, unsorted = 0;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        const int v = idx[k];
-        bad |= (v < 0) | (v >= limit);
-        if (sorted_flag && k > 0)
-            unsorted |= v < idx[k - 1];
-    }
-    if (__any(bad) && (int) __lane_id() == 0)
-        atomicOr(flags, 1);
-    if (sorted_flag && __any(unsorted) && (int) __lane_id() == 0)
-        atomicOr(flags + 1, 1);
-}
-
-// row_ptr of row-sorted triplets: row_ptr[r] = first k with row[k] >= r (run-length of the row stream),
-// for r = 0 .. rows; thread k fills the rows in (row[k-1], row[k]], thread nnz the tail.
-__global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(
-    long long nnz, int rows, const int32_t * __restrict__ row, int32_t * __restrict__ row_ptr)
-{
-    const long long stride = (long long) gridDim.x * 256;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k <= nnz; k += stride) {
-        const int lo = k == 0 ? 0 : row[k - 1] + 1;
-        const int hi = k == nnz ? rows : row[k];
-        for (int r = lo; r <= hi; ++r)
-            row_ptr[r] = (int32_t) k;
-    }
-}
-
-// Hybrid ELLPACK + COO -> one row-major matrix: row r = its ELL entries (row_length of them, padding
-// included: a padded entry multiplies 0.0 by x like in the reference) followed by its COO entries.
-// One thread per row (upload time only).
-__global__ __launch_bounds__(256) void hybrid_merge_kernel(
-    int rows, int row_length, const int32_t * __restrict__ ell_col, const double * __restrict__ ell_val,
-    const int32_t * __restrict__ coo_ptr, const int32_t * __restrict__ coo_col, const double * __restrict__ coo_val,
-    int32_t * __restrict__ out_col, double * __restrict__ out_val)
-{
-    const long long r = (long long) blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows)
-        return;
-    long long dst = r * row_length + coo_ptr[r];
-    for (long long k = r * row_length; k < (r + 1) * row_length; ++k, ++dst) {
-        out_col[dst] = ell_col[k];
-        out_val[dst] = ell_val[k];
-    }
-    for (int k = coo_ptr[r]; k < coo_ptr[r + 1]; ++k, ++dst) {
-        out_col[dst] = coo_col[k];
-        out_val[dst] = coo_val[k];
-    }
-}
-
-// Value dictionary, plan time.  value_dict_insert_kernel: every distinct bit pattern among the n values goes
-// into an open-addressing table of kDictSlots 64-bit keys (kDictEmpty = free); state[0] counts the distinct
-// values, state[1] is raised when there are more than `limit` (or a value equals the free marker) and
-// everybody stops.  Almost every probe ends on its first load: a matrix that qualifies has few values.
-constexpr int kDictSlots = 1024;
-constexpr unsigned long long kDictEmpty = 0x7FF8DEADBEEF0001ull; // a NaN payload nobody stores
-
-__global__ __launch_bounds__(256) void value_dict_insert_kernel(
-    long long n, const double * __restrict__ a, unsigned long long * __restrict__ keys, int * __restrict__ state, int limit)
-{
-    const long long stride = (long long) gridDim.x * 256;
-    int round = 0;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride, ++round) {
-        // a matrix with more distinct values than the dictionary holds is found out within the first few thousand
-        // entries: every thread looks at the verdict every eighth round and leaves
-        if ((round & 7) == 0 && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            return;
-        const unsigned long long key = (unsigned long long) __double_as_longlong(a[k]);
-        if (key == kDictEmpty) {
-            atomicOr(state + 1, 1);
-            return;
-        }
-        unsigned long long h = key * 0x9E3779B97F4A7C15ull;
-        unsigned slot = (unsigned) (h >> 54) & (kDictSlots - 1);
-        for (int probe = 0; probe < kDictSlots; ++probe, slot = (slot + 1) & (kDictSlots - 1)) {
-            unsigned long long cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == key)
-                break;
-            if (cur == kDictEmpty) {
-                cur = atomicCAS(keys + slot, kDictEmpty, key);
-                if (cur == kDictEmpty) {
-                    if (atomicAdd(state, 1) + 1 > limit)
-                        atomicOr(state + 1, 1);
-                    break;
-                }
-                if (cur == key)
-                    break;
-            }
-        }
-    }
-}
-
-// value_index_kernel: idx[k] = position of a[k] in the dictionary `table` (nvalues bit patterns, ascending as
-// unsigned 64-bit integers); state[1] is raised if a value is not in it (the array changed under the plan).
-__global__ __launch_bounds__(256) void value_index_kernel(
-    long long n, const double * __restrict__ a, const unsigned long long * __restrict__ table, int nvalues,
-    uint8_t * __restrict__ idx, int * __restrict__ state)
-{
-    __shared__ unsigned long long t[kMaxIndexedValues];
-    if (threadIdx.x < kMaxIndexedValues)
-        t[threadIdx.x] = threadIdx.x < (unsigned) nvalues ? table[threadIdx.x] : ~0ull;
-    __syncthreads();
-    const long long stride = (long long) gridDim.x * 256;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        const unsigned long long key = (unsigned long long) __double_as_longlong(a[k]);
-        int lo = 0, hi = nvalues - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (t[mid] < key)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        if (t[lo] != key)
-            atomicOr(state + 1, 1);
-        idx[k] = (uint8_t) lo;
-    }
-}
-
-__global__ __launch_bounds__(256) void value_checksum_kernel(
-    long long n, const double * __restrict__ a, unsigned long long * __restrict__ out)
-{
-    const long long stride = (long long) gridDim.x * 256;
-    unsigned long long h = 0;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        unsigned long long t = (unsigned long long) k * 0x9E3779B97F4A7C15ull ^ (unsigned long long) __double_as_longlong(a[k]);
-        t ^= t >> 29;
-        t *= 0xBF58476D1CE4E5B9ull;
-        t ^= t >> 32;
-        h += t;
-    }
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1)
-        h += __shfl_xor(h, d);
-    if ((int) __lane_id() == 0)
-        atomicAdd(out, h);
-}
-
-__global__ __launch_bounds__(256) void column_checksum_kernel(
-    long long n, const int32_t * __restrict__ j, unsigned long long * __restrict__ out)
-{
-    const long long stride = (long long) gridDim.x * 256;
-    unsigned long long h = 0;
-    for (long long k = (long long) blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        unsigned long long t = (unsigned long long) k * 0x9E3779B97F4A7C15ull + (unsigned long long) (unsigned) j[k];
-        t ^= t >> 29;
-        t *= 0xBF58476D1CE4E5B9ull;
-        t ^= t >> 32;
-        h += t;
-    }
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1)
-        h += __shfl_xor(h, d);
-    if ((int) __lane_id() == 0)
-        atomicAdd(out, h);
-}
-
-// ---------------------------------------------------------------------------------
-// STREAM triad a = b + q*c (reference src/kernels/triad.cpp:48-54): two doubles per
-// lane per step (16-byte loads/stores), grid-stride.  The measured rate of this
-// kernel is the empirical HBM roofline the SpMV kernels are compared against.
-// ---------------------------------------------------------------------------------
-template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void triad_kernel(
-    long long n, double * __restrict__ a, const double * __restrict__ b,
-    const double * __restrict__ c, double q)
-{
-    const long long n2 = n >> 1; // double2 elements
-    const double2 * __restrict__ b2 = reinterpret_cast<const double2 *>(b);
-    const double2 * __restrict__ c2 = reinterpret_cast<const double2 *>(c);
-    double2 * __restrict__ a2 = reinterpret_cast<double2 *>(a);
-    const long long stride = (long long) gridDim.x * BLOCK;
-    const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
-    long long i = gid;
-    // UNROLL independent 16-byte loads per array in flight per lane
-    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
-        double2 vb[UNROLL], vc[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            vb[u] = b2[i + u * stride];
-            vc[u] = c2[i + u * stride];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            a2[i + u * stride] = make_double2(vb[u].x + q * vc[u].x, vb[u].y + q * vc[u].y);
-    }
-    for (; i < n2; i += stride) {
-        const double2 vb = b2[i], vc = c2[i];
-        a2[i] = make_double2(vb.x + q * vc.x, vb.y + q * vc.y);
-    }
-    if ((n & 1) && gid == 0)
-        a[n - 1] = b[n - 1] + q * c[n - 1];
-}
-
-// Experiment variants of the triad (tools/kernel_sweep.py --triad-variants): not part of the ABI.
-template <int BLOCK, bool NT_STORE>
-__global__ __launch_bounds__(BLOCK) void triad_flat_kernel(
-    long long n2, double * __restrict__ a, const double * __restrict__ b,
-    const double * __restrict__ c, double q)
-{
-    const long long i = (long long) blockIdx.x * BLOCK + threadIdx.x; // one 16-byte element per lane
-    if (i < n2) {
-        const v2d vb = reinterpret_cast<const v2d *>(b)[i];
-        const v2d vc = reinterpret_cast<const v2d *>(c)[i];
-        const v2d r = v2d{vb.x + q * vc.x, vb.y + q * vc.y};
-        if (NT_STORE)
-            __builtin_nontemporal_store(r, reinterpret_cast<v2d *>(a) + i);
-        else
-            reinterpret_cast<v2d *>(a)[i] = r;
-    }
-}
-
-} // namespace spmv
+#include "tile_common.hpp"
+#include "csr_basic.hpp"
+#include "csr_wavetile.hpp"
+#include "csr_segtile.hpp"
+#include "csr_panels.hpp"
+#include "csr_blockwin.hpp"
+#include "csr_plan_kernels.hpp"
+#include "coo_kernels.hpp"
+#include "ell_kernels.hpp"
+#include "upload_kernels.hpp"
+#include "triad_kernels.hpp"

@@ -32,6 +32,7 @@ FLAG_NO_RUN_EVENTS = 0x80000
 FLAG_NO_VALUE_INDEX = 0x100000
 FLAG_PEER_GATHER = 0x200000
 FLAG_BALANCE_ENTRIES = 0x400000
+FLAG_NO_SEGMENT_WINDOW = 0x800000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -299,11 +300,12 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(21, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 21))
+        out = np.zeros(23, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 23))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
-                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values"]
+                "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
+                "segwin_tiles", "segwin_slots"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

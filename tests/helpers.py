@@ -83,6 +83,20 @@ def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what=""):
             what, bad.size, bad[0], y_gpu[bad[0]], y_cpu[bad[0]])
 
 
+def assert_ell(y_gpu, y_cpu, L, flags, ell_col, ell_val, x, y0=None, runs=1, what=""):
+    """The ELLPACK tolerance classes: rows of <= 16 entries, SPMV_HIP_FLAG_EXACT_ORDER (0x2) and
+    SPMV_HIP_FLAG_ELL_COLUMN_MAJOR (0x200) sum every row with one lane in the reference's order
+    (src/matrix/ell-matrix.cpp:243-258): bit-exact.  Longer rows are summed by 2..64 lanes by default:
+    1e-10 relative, per row against the magnitude of its products (BASELINE.json)."""
+    if L <= 16 or (flags & (0x2 | 0x200)):
+        return assert_bitexact(y_gpu, y_cpu, what)
+    rows = len(np.asarray(y_cpu))
+    scale = (np.abs(np.asarray(ell_val).reshape(rows, L)) * np.abs(np.asarray(x)[np.asarray(ell_col).reshape(rows, L)])).sum(axis=1) * runs
+    if y0 is not None:
+        scale = scale + np.abs(y0)
+    assert_close(y_gpu, y_cpu, scale, what=what)
+
+
 def assert_bitexact(y_gpu, y_cpu, what=""):
     y_gpu = np.ascontiguousarray(y_gpu, dtype=np.float64)
     y_cpu = np.ascontiguousarray(y_cpu, dtype=np.float64)

@@ -78,7 +78,15 @@ def main():
                 with capi.Context() as ctx:
                     ctx.upload_ell(rows, cols, L, ec.ravel(), ev.ravel())
                     ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
-                    assert_bitexact(ctx.get_y(), want2, "seed %d ELLPACK L=%d" % (seed, L))
+                    # rows of <= 16 entries: one lane per row, the reference's bits; longer rows: several lanes, 1e-10
+                    if L <= 16:
+                        assert_bitexact(ctx.get_y(), want2, "seed %d ELLPACK L=%d" % (seed, L))
+                    else:
+                        assert_close(ctx.get_y(), want2, scale2, what="seed %d ELLPACK L=%d" % (seed, L))
+                with capi.Context(0, flags=capi.FLAG_EXACT_ORDER) as ctx:
+                    ctx.upload_ell(rows, cols, L, ec.ravel(), ev.ravel())
+                    ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
+                    assert_bitexact(ctx.get_y(), want2, "seed %d ELLPACK L=%d, exact order" % (seed, L))
             os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
             with capi.Context(num_gpus=3, flags=capi.FLAG_PEER_GATHER | capi.FLAG_BALANCE_ENTRIES) as ctx:
                 ctx.upload_csr(rows, cols, p, c, v0)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import helpers
-from helpers import unhex, assert_bitexact, assert_close, abs_products
+from helpers import unhex, assert_bitexact, assert_close, assert_ell, abs_products
 from spmv_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -97,7 +97,15 @@ def test_golden_ell_bitexact(ctx, oracle, golden):
         ctx.upload_ell(rows, cols, L, c, v)
         ctx.set_x(unhex(case["x"]))
         ctx.run(case["runs"])
-        assert_bitexact(ctx.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell")
+        assert_ell(ctx.get_y(), unhex(case["ell"]["y"]), L, 0, c, v, unhex(case["x"]), runs=case["runs"], what=case["name"] + "/ell")
+    with capi.Context(0, flags=capi.FLAG_EXACT_ORDER) as exact:  # one lane per row whatever the length: the reference's bits
+        for case in golden["cases"]:
+            rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
+            rc, L, c, v = oracle.ell_from_coordinate(rows, i, j, a)
+            exact.upload_ell(rows, cols, L, c, v)
+            exact.set_x(unhex(case["x"]))
+            exact.run(case["runs"])
+            assert_bitexact(exact.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell exact order")
 
 
 def test_golden_hybrid(ctx, oracle, golden):
@@ -315,9 +323,10 @@ def test_synthetic_coo_sorted_and_shuffled(ctx, oracle, name, gen):
         assert_close(ctx.get_y(), want, scale, what="%s/coo/%s" % (name, order))
 
 
-@pytest.mark.parametrize("flags", [0, capi.FLAG_ELL_COLUMN_MAJOR, capi.FLAG_NO_INDEX_COMPRESSION | capi.FLAG_ROWS128])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_EXACT_ORDER, capi.FLAG_ELL_COLUMN_MAJOR, capi.FLAG_NO_INDEX_COMPRESSION | capi.FLAG_ROWS128])
 def test_ell_paths_bitexact(oracle, golden, flags):
-    """Short rows run in place as uniform wave tiles, long rows column-major: same bits either way."""
+    """ELLPACK runs in place as uniform wave tiles (rows of up to 16 entries, or any length under EXACT_ORDER: one lane
+    per row, bit-exact; longer rows by default several lanes: 1e-10) or column-major on request (bit-exact)."""
     c2 = capi.Context(0, flags=flags)
     try:
         for name, gen in SYNTH[:4] + SYNTH[6:7]:
@@ -330,14 +339,14 @@ def test_ell_paths_bitexact(oracle, golden, flags):
             c2.set_x(x)
             c2.set_y(y0)
             c2.run(2)
-            assert_bitexact(c2.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2), "%s/ell/flags%x" % (name, flags))
+            assert_ell(c2.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2), L, flags, ec, ev, x, y0, 2, "%s/ell/flags%x" % (name, flags))
         for case in golden["cases"]:
             rows, cols, i, j, a, _, _ = helpers.parse_mtx_text(helpers.case_mtx(golden, case))
             rc, L, ec, ev = oracle.ell_from_coordinate(rows, i, j, a)
             c2.upload_ell(rows, cols, L, ec, ev)
             c2.set_x(unhex(case["x"]))
             c2.run(case["runs"])
-            assert_bitexact(c2.get_y(), unhex(case["ell"]["y"]), case["name"] + "/ell/flags%x" % flags)
+            assert_ell(c2.get_y(), unhex(case["ell"]["y"]), L, flags, ec, ev, unhex(case["x"]), runs=case["runs"], what=case["name"] + "/ell/flags%x" % flags)
     finally:
         c2.close()
 
@@ -355,7 +364,7 @@ def test_synthetic_ell_bitexact(ctx, oracle, name, gen):
     ctx.set_x(x)
     ctx.set_y(y0)
     ctx.run(2)
-    assert_bitexact(ctx.get_y(), want, name + "/ell")
+    assert_ell(ctx.get_y(), want, L, 0, ec, ev, x, y0, 2, name + "/ell")
 
 
 # ---- edge cases ------------------------------------------------------------------------
@@ -837,8 +846,9 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
 
 @pytest.mark.parametrize("L", [1, 16, 27, 255, 256, 257, 300, 600])
 def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
-    """ELLPACK rows up to half a tile run in place as wave tiles, longer ones through the
-    column-major kernel; both keep the reference's order (bit-exact), padding included."""
+    """ELLPACK runs in place as wave tiles.  Default: rows of more than 16 entries are summed by several lanes (1e-10);
+    EXACT_ORDER keeps one lane per row (in place up to 80 entries per row, column-major beyond) and ELL_COLUMN_MAJOR
+    the column-major kernel: both the reference's order, bit-exact, padding included."""
     rng = np.random.default_rng(L)
     rows, cols = 3000, 5000
     lens = rng.integers(0, L + 1, size=rows)
@@ -852,7 +862,7 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
     x = synth.x_vector(cols, seed=3)
     y0 = synth.x_vector(rows, seed=4)
     want = oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2)
-    for flags in (0, capi.FLAG_ELL_COLUMN_MAJOR):
+    for flags in (0, capi.FLAG_EXACT_ORDER, capi.FLAG_ELL_COLUMN_MAJOR):
         c2 = capi.Context(0, flags=flags)
         try:
             c2.upload_ell(rows, cols, L, ec, ev)
@@ -860,7 +870,12 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.set_y(y0)
             c2.run()
             c2.run()
-            assert_bitexact(c2.get_y(), want, "ell L=%d flags %x" % (L, flags))
+            assert_ell(c2.get_y(), want, L, flags, ec, ev, x, y0, 2, "ell L=%d flags %x" % (L, flags))
+            if flags == 0 and L > 16:
+                # several lanes per row on the row-major arrays in place -- except where whole rows would leave more than
+                # 30 % of a 512-entry tile empty (L = 257, 300 here): those take the column-major kernel
+                poor_fill = L <= 512 and (512 // L) * L * 10 < 512 * 7
+                assert (c2.info()["row_blocks"] > 0) == (not poor_fill), (L, c2.info())
         finally:
             c2.close()
 
@@ -1046,6 +1061,70 @@ def test_block_window_kernel(oracle, case):
     assert np.array_equal(ys[0].view(np.uint64), ys[capi.FLAG_NO_X_WINDOW].view(np.uint64))
 
 
+@pytest.mark.parametrize("spec", ["synthetic:kkt:40,50", "synthetic:kkt:44,100", "synthetic:kkt:40", "synthetic:queen:200,180,3",
+                                  "synthetic:queen:200,180,3,6", "kkt+scatter"])
+def test_segment_window_kernel(oracle, spec):
+    """Rows whose columns sit in a few clusters MORE than 65536 columns apart (a KKT row's diagonal plus three planes
+    of its grid millions of columns away; a mesh whose planes hold 36 000 nodes) cannot have 16-bit column offsets;
+    they go through csr_segwin_kernel: x staged in LDS per block of 32 tiles, the tiles' 16-bit column stream holding
+    window slots.  Same lanes per row and same order as csr_wavetile_kernel: y must be identical bit for bit with and
+    without the windows, after two accumulating multiplies (both launches of a multiply finished in order)."""
+    import torch
+    from spmv_amd import hostapi
+    flags0 = 0
+    if spec == "kkt+scatter":  # KKT rows, then rows with columns all over the matrix (blocks without a window), then KKT rows again
+        A = hostapi.load("synthetic:kkt:30,50", "csr")
+        r1, cols, p1, c1, v1 = A.rows, A.cols, np.array(A.row_ptr), np.array(A.column_index), np.array(A.value)
+        r2, _, p2, c2, v2 = synth.random_uniform(3000, cols, 30, seed=5)
+        rows = r1 + r2 + r1
+        p = np.concatenate([p1, p1[-1] + p2[1:], p1[-1] + p2[-1] + p1[1:]]).astype(np.int32)
+        c = np.concatenate([c1, c2, c1])
+        v = np.concatenate([v1, v2, v1])
+        A.close()
+    else:
+        A = hostapi.load(spec, "csr")
+        rows, cols, p, c, v = A.rows, A.cols, np.array(A.row_ptr), np.array(A.column_index), np.array(A.value)
+        A.close()
+        # the plain KKT stand-in's interior rows are shifted copies of each other: take that (cheaper) class away to see the windows
+        flags0 = capi.FLAG_NO_SHIFTED_TILES if spec == "synthetic:kkt:40" else 0
+    x = synth.x_vector(cols, seed=7)
+    y0 = synth.x_vector(rows, seed=8)
+    want = y0 + oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    dev = torch.device("cuda:0")
+    tp, tc, tv, tx = (torch.from_numpy(t).to(dev) for t in (p, c, v, x))
+    stream = torch.cuda.current_stream().cuda_stream
+    ys = {}
+    for flags in (flags0, flags0 | capi.FLAG_NO_X_WINDOW):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_WAVETILE, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        info = plan.info()
+        if not (flags & capi.FLAG_NO_X_WINDOW):
+            assert info["segwin_tiles"] > 0.5 * info["row_blocks"], (spec, info)
+            assert info["segwin_tiles"] == info["blockwin_tiles"] and 0 < info["segwin_slots"] <= 4096
+            if spec == "kkt+scatter":
+                assert info["segwin_tiles"] < info["row_blocks"]
+        else:
+            assert info["segwin_tiles"] == 0 and info["blockwin_tiles"] == 0
+        ty = torch.from_numpy(y0).to(dev)
+        for _ in range(2):
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ys[flags] = ty.cpu().numpy()
+        # a different column array at another address: nothing derived (slots, marks) may be used
+        tc2 = tc.clone()
+        ty2 = torch.from_numpy(y0).to(dev)
+        plan.spmv(tp.data_ptr(), tc2.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_close(ty2.cpu().numpy(), want, scale, what="%s other column array flags %x" % (spec, flags))
+        plan.close()
+    want2 = want + (want - y0)
+    for flags, got in ys.items():
+        assert_close(got, want2, 2 * scale, what="%s flags %x" % (spec, flags))
+    a, b = ys.values()
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_block_window_long_walks(oracle):
     """Enough blocks that every persistent workgroup walks through many of them (sliding ring,
     increments only, many wrap-arounds), with a few rows of scattered columns in between that break
@@ -1206,7 +1285,7 @@ def test_many_small_random_structures_other_formats(ctx, oracle):
         ctx.set_x(x)
         ctx.set_y(y0)
         ctx.run()
-        assert_bitexact(ctx.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0), "ell " + what)
+        assert_ell(ctx.get_y(), oracle.ell_spmv(rows, L, ec, ev, x, y=y0), L, 0, ec, ev, x, y0, 1, "ell " + what)
         # hybrid
         H = oracle.hybrid_from_coordinate(rows, i, j, a)
         ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])

@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
     mkdir -p tools/ablate
     for n in ${ABLATE_MASKS:-1 2 4 8 15}; do
         (cd spmv-cache-trace_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics \
-            -I../include -DSPMV_HIP_EXPERIMENTS -DSPMV_VI_ABLATE=$n -shared csrc/spmv_hip.hip csrc/coo_sort.hip -o ../tools/ablate/ablate_$n.so) &
+            -I../include -DSPMV_HIP_EXPERIMENTS -DSPMV_VI_ABLATE=$n -shared csrc/*.hip -o ../tools/ablate/ablate_$n.so) &
     done
     wait
 else

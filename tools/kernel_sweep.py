@@ -148,6 +148,7 @@ def main():
         "wavetile_c16_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_noshift_rows128": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_SHIFTED_TILES | capi.FLAG_ROWS128 | 0x100000),
         "wavetile_c16_noxwin": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | 0x100000),
+        "wavetile_c16_ring": (capi.CSR_WAVETILE, 0, 0x100000 | 0x400000),  # 0x400000: sweep-local marker = no segment windows (the one-ring block window instead)
         "wavetile_c16_noxwin_noshift": (capi.CSR_WAVETILE, 0, capi.FLAG_NO_X_WINDOW | capi.FLAG_NO_SHIFTED_TILES | 0x100000),
         "wavetile_c16_blockwin_simple": (capi.CSR_WAVETILE, 0, 0x2000 | 0x100000),
         "wavetile_c16_panels": (capi.CSR_WAVETILE, 0, 0x100000 | 0x200000),
@@ -168,7 +169,8 @@ def main():
     }
     if args.variants:
         variants = {k: variants[k] for k in args.variants.split(",")}
-    plans = {k: capi.CsrPlan(rows, cols, p, a, l, f & 0x3FFFF) for k, (a, l, f) in variants.items()}  # sweep-local markers are above bit 17
+    plans = {k: capi.CsrPlan(rows, cols, p, a, l, (f & 0x3FFFF) | (capi.FLAG_NO_SEGMENT_WINDOW if f & 0x400000 else 0))
+             for k, (a, l, f) in variants.items()}  # sweep-local markers are above bit 17
     for k, (a, l, f) in variants.items():
         if f & 0x100000:
             plans[k].compress(tc.data_ptr(), stream)
