@@ -89,6 +89,11 @@ def parse_args():
     ap.add_argument("--snapshot", action="store_true",
                     help="N > 1 with overlap: accumulate in place and copy the segment to a send buffer (round 1's way) "
                          "instead of alternating two segment buffers")
+    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "peer-fused", "peer-push"],
+                    help="N > 1: how the y segments reach the other ranks.  rccl = one in-place all-gather per step; peer-fused = "
+                         "the multiply kernel stores its row sums into every rank's vector (inter-process device memory); "
+                         "peer-push = the multiply, then one kernel that pushes the segment; auto (default) = time a few steps "
+                         "of each scheme that can be set up and take the fastest")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N > 1 on a box with one GPU")
     ap.add_argument("--share-gpu", action="store_true",
@@ -426,6 +431,19 @@ def main():
         x = synth.x_vector(cols, "uniform", seed=12345)
         op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
                                        overlap=not args.no_overlap, ranges=ranges, pingpong=not args.snapshot)
+        ops = {"rccl": op}
+        peer_note = None
+        if use_dist and args.gather != "rccl":
+            # the same rows, plan and device arrays behind vectors the other ranks can store into (spmv_amd/peer.py)
+            from spmv_amd.peer import PeerCsrSpmv, PeerUnavailable
+            try:
+                for name, fused in (("peer-fused", True), ("peer-push", False)):
+                    if args.gather in ("auto", name):
+                        ops[name] = PeerCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
+                                                       ranges=ranges, fused=fused, uploaded=op.uploaded)
+            except PeerUnavailable as e:
+                peer_note = "peer stores not available: %s" % e
+                ops = {"rccl": op}
         local_rows, local_nnz = end - begin, int(p[-1])
         local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
         total_bytes = synth.csr_bytes(rows, cols, nnz)
@@ -476,6 +494,37 @@ def main():
             torch.cuda.synchronize()
             y_check = op.y()
             op.zero_y()
+
+    # ---- N > 1: which gather?  A few steps of every scheme that could be set up, max over ranks, fastest wins ----------
+    schemes = None
+    if fmt == "csr" and use_dist:
+        def timed_steps(o, n):
+            torch.cuda.synchronize()
+            dist.barrier()
+            c0 = time.perf_counter()
+            for _ in range(n):
+                o.multiply_local()
+                if o.collective:
+                    o.gather_async() if o.overlap else o.gather()
+            o.finish()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item() / n
+        schemes = {}
+        ncal = max(5, min(20, args.warmup))
+        for name, o in ops.items():
+            timed_steps(o, 3)
+            schemes[name] = {"t_total_us": round(timed_steps(o, ncal) * 1e6, 2), "calibration_steps": ncal}
+            if not o.collective:
+                schemes[name]["multiply_forwards_row_sums"] = bool(o.fused)
+        chosen = args.gather if args.gather in ops else min(schemes, key=lambda k: schemes[k]["t_total_us"])
+        if args.gather != "auto" and args.gather not in ops:
+            chosen = "rccl"
+        op = ops[chosen]
+        step = op.step
+        op.zero()  # y accumulates warm-up + K multiplies from here on (gather_check)
 
     # ---- warm-up, then K timed steps -------------------------------------------------------
     for _ in range(args.warmup):
@@ -589,12 +638,14 @@ def main():
     # blocking all-gathers, max over ranks, so the line shows where a step's time goes.
     gather_us = None
     if use_dist:
+        op.finish()
+        rc_op = ops["rccl"] if fmt == "csr" else op
         times = []
         for _ in range(5):
             torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
-            dist.all_gather_into_tensor(op.y_full, op.y_local, group=op.group)
+            dist.all_gather_into_tensor(rc_op.y_full, rc_op.y_local, group=rc_op.group)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - g0)
         gt = torch.tensor([float(np.median(times))], dtype=torch.float64, device=device)
@@ -605,6 +656,8 @@ def main():
     # the last rank's rows on its own GPU (product kernel, one multiply) and compares it with the
     # gathered segment, which has accumulated warm-up + K multiplies.
     gather_check = None
+    if use_dist:
+        op.finish()  # every rank (the peer schemes meet at a barrier here); below, rank 0 reads its vector without one
     if use_dist and world > 1 and rank == 0 and spec is not None and spec.startswith("synthetic:") and ranges is None:
         ob, oe = partition.row_range(rows, world - 1, world)
         strip = min(4096, oe - ob)
@@ -615,23 +668,52 @@ def main():
         plan_s.spmv(tps.data_ptr(), tcs.data_ptr(), tvs.data_ptr(), op._keep[3].data_ptr(), ys.data_ptr(), stream)
         torch.cuda.synchronize()
         want = ys * float(args.steps + args.warmup)
-        got = op.y()[ob:ob + strip]
+        got = op.y_full[ob:ob + strip]  # static row chunks: the gathered vector is y itself
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-300))
         gather_check = {"rows_checked": strip, "of_rank": world - 1, "max_rel_err": err, "pass": bool(err <= 1e-10)}
         plan_s.close()
         S.close()
+
+    if use_dist and schemes is not None:
+        # per scheme: the local multiply alone (no delivery of any kind), the delivery alone where it is a launch
+        # or a call of its own, and the whole step from the calibration above
+        def events_us(fn, n=10):
+            fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([a.elapsed_time(b) * 1e3 / n], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(t.item(), 2)
+        t_local = events_us(ops["rccl"].multiply_local)
+        ops["rccl"].finish()
+        for name in schemes:
+            schemes[name]["t_local_us"] = t_local
+        schemes["rccl"]["t_gather_us"] = round(gather_us, 2)
+        if "peer-push" in ops:
+            schemes["peer-push"]["t_gather_us"] = events_us(ops["peer-push"].deliver) if ops["peer-push"].deliver else 0.0
+        if "peer-fused" in ops:
+            schemes["peer-fused"]["t_gather_us"] = None  # inside the multiply: t_total - t_local is what it adds
+        for o in ops.values():
+            o.finish()
 
     # N > 1, for information only (never `value`): the same K multiplies with ONE all-gather after the
     # last of them -- what a caller pays who, like the reference's timed loop, looks at y only after
     # the loop.  `value` above gathers after every multiply.
     deferred = None
     if use_dist:
+        dop = ops["rccl"] if fmt == "csr" else op
         torch.cuda.synchronize()
         dist.barrier()
         d0 = time.perf_counter()
         for _ in range(args.steps):
-            op.multiply_local()
-        op.gather()
+            dop.multiply_local()
+        dop.gather()
         torch.cuda.synchronize()
         dist.barrier()
         dt = torch.tensor([time.perf_counter() - d0], dtype=torch.float64, device=device)
@@ -651,10 +733,12 @@ def main():
         config = {"workload": wname, "rows": rows, "cols": cols, "nnz": nnz, "format": fmt,
                   "index_dtype": "int32", "x": "uniform(-1,1) seed 12345",
                   "symmetric_file_expanded": bool(getattr(keep, "expanded", False)),
-                  "partition": ("%s, x replicated, 1 all-gather(y)/step%s" % (
+                  "partition": ("%s, x replicated, %s" % (
                       ("rows/%d static chunks" % world) if ranges is None else ("%d row ranges of equal stored entries" % world),
-                      (", gather k overlaps multiply k+1 (%s)" % ("two alternating segment buffers" if op.pingpong else "snapshot copy"))
-                      if op.overlap else "")) if use_dist else "single GPU",
+                      ("1 all-gather(y)/step" + ((", gather k overlaps multiply k+1 (%s)" % ("two alternating segment buffers" if op.pingpong else "snapshot copy"))
+                                                 if op.overlap else "")) if op.collective else
+                      ("y segments stored into every rank's vector by %s" % ("the multiply kernel itself" if getattr(op, "fused", False) else "a push kernel after the multiply")))
+                      ) if use_dist else "single GPU",
                   "backend": args.backend if use_dist else None, "rehearsal_shared_gpu": bool(args.share_gpu)}
         if fmt == "csr":
             config.update({"algorithm": capi.CSR_ALGORITHM_NAMES[info["algorithm"]], "lanes_per_row": info["lanes_per_row"],
@@ -718,7 +802,10 @@ def main():
                                           "predicted_us": round(max(kern_s * 1e6, model_gather_us), 1),
                                           "predicted_us_at_%.0f_GBs_per_link" % XGMI_LINK_GBS_QUOTED: round(max(kern_s * 1e6, model_gather_us_fast), 1),
                                           "measured_us": round(ms_per_step * 1e3, 1)},
-                                "note": "all_gather_us: blocking collective alone, median of 5 after the timed region",
+                                "gather": chosen if schemes is not None else "rccl",
+                                "schemes": schemes, "peer_note": peer_note if fmt == "csr" else None,
+                                "note": "all_gather_us: blocking collective alone, median of 5 after the timed region; schemes: t_total = a "
+                                        "whole step (max over ranks) timed before the warm-up, `gather` = the one the timed region ran",
                                 "one_all_gather_after_the_k_multiplies": deferred}
         if gather_check:
             out["gather_check"] = gather_check
@@ -751,6 +838,10 @@ def main():
                     if cold is not None:
                         rp["flushed"] = {k: cold.get(k) for k in ("command", "execution_time_ns", "gflops_median", "device_ns_last_run", "error") if k in cold}
         print(json.dumps(out), flush=True)
+    if fmt == "csr":
+        for o in ops.values():
+            if not o.collective:
+                o.close()  # collective: mappings are closed before their owners free the memory
     finish(code, message)
 
 

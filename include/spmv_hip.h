@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define SPMV_HIP_VERSION 120 /* 1.2.0: peer gather, entry-balanced blocks, COO / ELLPACK in multi-GPU contexts, spmv_hip_flush_caches */
+#define SPMV_HIP_VERSION 130 /* 1.3.0: segment windows, several lanes per long ELLPACK row, peer stores for one process per GPU
+                                (spmv_hip_ipc_*, spmv_hip_peer_push, spmv_hip_csr_spmv_out_peers) */
 
 /* ---- error codes ---------------------------------------------------------- */
 #define SPMV_HIP_OK 0
@@ -111,6 +112,10 @@ extern "C" {
                                              the reference's ceil(rows / G) rows per device; y slots are as long as
                                              the longest block.  For matrices whose row lengths differ between the
                                              top and the bottom (a KKT system's two row populations). */
+#define SPMV_HIP_FLAG_FUSED_PEER_STORE 0x1000000u /* spmv_hip_create_multi: like SPMV_HIP_FLAG_PEER_GATHER (no RCCL, peer access needed), but
+                                             where a device's multiply is the default CSR kernel it stores every row sum into all
+                                             G copies of y itself as each tile finishes -- the gather overlaps the SAME multiply
+                                             and needs no launch of its own; other kernels are followed by the push kernel */
 #define SPMV_HIP_FLAG_NO_SEGMENT_WINDOW 0x800000u /* plan_csr_compress: no segment windows (x staged through LDS per block of 32
                                              tiles in up to 8 far-apart column segments: rows of a 3-D mesh in natural
                                              ordering, KKT systems; the tiles' 16-bit column stream then holds window
@@ -331,6 +336,32 @@ int spmv_hip_csr_spmv(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
 int spmv_hip_csr_spmv_out(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
                           const int32_t *d_column_index, const double *d_value,
                           const double *d_x, const double *d_y_in, double *d_y_out, void *stream);
+
+/* ---- one process per GPU: the all-gather of the y segments as stores into the other ranks' memory ------------------
+ * The row blocks of src/matrix/csr-matrix.cpp:77-95 on G GPUs driven by G processes (bench.py --gpus G,
+ * python/spmv_amd/distributed.py).  Every rank allocates its copy of the whole y with spmv_hip_ipc_alloc, the ranks
+ * exchange the 64-byte handles over whatever channel they share, and spmv_hip_ipc_open maps the other ranks' copies
+ * into this process (peer access between the devices must be possible; on this driver HSA_ENABLE_IPC_MODE_LEGACY=0
+ * must be in the environment).  Close the mappings (spmv_hip_ipc_close) before their owner frees the memory
+ * (spmv_hip_ipc_free).  The memory comes back zeroed. */
+int spmv_hip_ipc_alloc(void **d_ptr, size_t bytes, void *handle64);
+int spmv_hip_ipc_open(const void *handle64, void **d_ptr);
+int spmv_hip_ipc_close(void *d_ptr);
+int spmv_hip_ipc_free(void *d_ptr);
+/* d_dst[k][i] = d_src[i], i < n, for every k < ndst: one kernel that reads the segment once and writes it into up to 8
+ * peers per launch (coalesced stores that leave over the xGMI link to each peer). */
+int spmv_hip_peer_push(const double *d_src, double *const *d_dst, int ndst, int64_t n, void *stream);
+/* spmv_hip_csr_spmv_out that ALSO delivers this rank's rows to the other ranks: peer_y[k] (host array of npeers DEVICE
+ * pointers) is where this rank's first row lives in rank k's copy of y.  Where the plan runs the default kernel
+ * (row-owned wave tiles, with or without a value dictionary, no split rows, no window kernels) every row sum is stored
+ * into all copies by the multiply itself as each tile finishes (*fused = 1, up to 7 peers): the transfer overlaps the
+ * same multiply and costs no launch of its own.  Otherwise the multiply is followed by spmv_hip_peer_push of
+ * d_y_out on the same stream (*fused = 0).  Either way the peers' copies are complete once this stream has been
+ * synchronised; a reader on another rank additionally needs to know that (a barrier between the processes).
+ * fused may be NULL. */
+int spmv_hip_csr_spmv_out_peers(const spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
+                                const double *d_value, const double *d_x, const double *d_y_in, double *d_y_out,
+                                double *const *peer_y, int npeers, int *fused, void *stream);
 
 /* y += A*x, COO in any order: wave-level segmented sums + fp64 atomics, i.e. the
  * semantics of coo_spmv_atomic (src/matrix/coo-matrix.cpp:287-309); equals

@@ -381,11 +381,12 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     // differ from the reference's in the last bits (1e-10 class, like CSR rows of that length).
     // SPMV_HIP_FLAG_EXACT_ORDER keeps one lane per row for every length: in place up to kEllInPlaceMaxLength
     // entries per row, through the column-major kernel beyond (measured crossover, same log).
-    // One exception: whole rows only fill a 512-entry tile to floor(512 / L) * L entries, and where that leaves more
-    // than 30 % of a tile's load slots idle (L = 172..179, 257..358) the column-major kernel is the faster one
-    // (L = 301, one row per tile: 849 us in place against 674 us; profiles/r03_ell_row_lengths.log).
+    // One exception, measured (profiles/r03_ell_row_lengths.log, fraction of the roofline in place / column-major):
+    // L = 129 0.88 / 0.72, but L = 201 0.58 / 0.69, 361 0.59 / 0.68, 441 0.66 / 0.70 -- one or two whole rows per
+    // 512-entry tile leave load slots idle and the x window no longer applies -- and L = 601 (a wave strides the row)
+    // 0.69 / 0.69.  So rows of 161..512 entries take the column-major kernel.
     const bool exact = (c->flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
-    const bool poor_fill = row_length > 16 && row_length <= 512 && (512 / row_length) * row_length * 10 < 512 * 7;
+    const bool poor_fill = row_length > 160 && row_length <= 512;
     c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR)
         && (exact ? row_length <= kEllInPlaceMaxLength : !poor_fill || c->ell_in_place_any_length);
     if (c->ell_in_place_any_length)
@@ -612,16 +613,23 @@ int spmv_hip_run(spmv_hip_ctx * c)
     if (timed)
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
     int rc = SPMV_HIP_OK;
+    bool delivered = false;
+    // a part of a multi-GPU context with SPMV_HIP_FLAG_FUSED_PEER_STORE: the CSR multiply delivers its rows to the other
+    // devices' copies of y itself (row sums forwarded by the kernel, or pushed behind it: spmv_hip_csr_spmv_out_peers)
+    auto csr_run = [&]() {
+        if (c->peer_y.empty())
+            return spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+        delivered = true;
+        return spmv_hip_csr_spmv_out_peers(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->d_y, c->peer_y.data(),
+                                           (int) c->peer_y.size(), nullptr, c->stream);
+    };
     switch (c->format) {
-    case 1: rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream); break;
+    case 1: rc = csr_run(); break;
     case 2:
-        rc = c->as_csr ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
-                       : ctx_coo_run(c, c->nnz, c->d_idx, c->d_col, c->d_val);
+        rc = c->as_csr ? csr_run() : ctx_coo_run(c, c->nnz, c->d_idx, c->d_col, c->d_val);
         break;
     case 3:
-        rc = c->ell_as_tiles
-            ? spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream)
-            : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+        rc = c->ell_as_tiles ? csr_run() : spmv_hip_ell_spmv(c->rows, c->row_length, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
         break;
     case 4:
         if (c->as_csr) { // ELL part and remainder merged into one row-major matrix: one launch
@@ -637,6 +645,9 @@ int spmv_hip_run(spmv_hip_ctx * c)
     }
     if (rc != 0)
         return rc;
+    if (!c->peer_y.empty() && c->rows > 0 && !delivered) // kernels without a forwarding variant: the push kernel behind them
+        if ((rc = spmv_hip_peer_push(c->d_y, c->peer_y.data(), (int) c->peer_y.size(), c->rows, c->stream)) != 0)
+            return rc;
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         c->timed = true;

@@ -372,17 +372,44 @@ struct PanelInfo {
     int rows;     // rows of the matrix (= virtual rows per panel)
 };
 
+// Kernel variant PEER (one process per GPU, rows partitioned, src/matrix/csr-matrix.cpp:77-95): every row sum is stored
+// not only into this rank's y but straight into the same place of up to kMaxPeers OTHER ranks' copies of y (their
+// memory, mapped here through hipIpcOpenMemHandle; the stores leave over the xGMI link to each peer).  The all-gather
+// of the y segments then costs no launch and no collective of its own: it travels while the tiles are multiplied.
+constexpr int kMaxPeers = 7;
+struct PeerY {
+    double * y[kMaxPeers]; // where this rank's FIRST row lives in each peer's y
+    int n;
+};
+
+template <bool PEER, bool NT>
+__device__ __forceinline__ void y_store(double * y, const PeerY & peers, long long idx, double v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, y + idx);
+    else
+        y[idx] = v;
+    if (PEER) {
+#pragma unroll
+        for (int k = 0; k < kMaxPeers; ++k) // static indices: the pointers stay in scalar registers
+            if (k < peers.n)
+                peers.y[k][idx] = v;
+    }
+}
+
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false>
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false, bool PEER = false>
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
     int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
-    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0)
+    const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0,
+    PeerY peers = PeerY{})
 {
+    static_assert(!PEER || !PANELS, "column panels add partial sums atomically: nothing to forward");
     // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
     // different ones (a partitioned multiply whose previous result is still being gathered); every
     // row is read and written by the same lane, so the in-place case needs no ordering.
@@ -493,9 +520,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             tile_rows_uniform_indexed<X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                            vidx + kb, vtab, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
             if (lane < nrows && !((kViAblate & 8) && lane > 0))
-                __builtin_nontemporal_store(yv + zA, yt + lane);
+                y_store<PEER, true>(y, peers, r0 + lane, yv + zA);
             if (second && lane + kWave < nrows && !(kViAblate & 8))
-                __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
+                y_store<PEER, true>(y, peers, r0 + lane + kWave, yvB + zB);
             return;
         }
         if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
@@ -505,9 +532,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             tile_rows_uniform_values<QUADS, X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                  a + kb, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
             if (lane < nrows)
-                yt[lane] = yv + zA;
+                y_store<PEER, false>(y, peers, r0 + lane, yv + zA);
             if (second && lane + kWave < nrows)
-                yt[lane + kWave] = yvB + zB;
+                y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB);
             return;
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
@@ -567,9 +594,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(yt + sub, z);
             else if (VI)
-                __builtin_nontemporal_store(yv + z, yt + sub);
+                y_store<PEER, true>(y, peers, r0 + sub, yv + z);
             else
-                yt[sub] = yv + z;
+                y_store<PEER, false>(y, peers, r0 + sub, yv + z);
         }
         if (second) {
             const double zB = ((ABL & 2) || (VI && (kViAblate & 4))) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
@@ -577,9 +604,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 if (PANELS)
                     unsafeAtomicAdd(yt + lane + kWave, zB);
                 else if (VI)
-                    __builtin_nontemporal_store(yvB + zB, yt + lane + kWave);
+                    y_store<PEER, true>(y, peers, r0 + lane + kWave, yvB + zB);
                 else
-                    yt[lane + kWave] = yvB + zB;
+                    y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB);
             }
         }
     } else if (!partial && k1 - kb <= TILE) {
@@ -598,7 +625,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(y + r0 + r, z);
             else
-                y[r0 + r] = y_in[r0 + r] + z;
+                y_store<PEER, false>(y, peers, r0 + r, y_in[r0 + r] + z);
         }
     } else if (!exact_order) {
         // ---- one long row, or one chunk of a very long row: the wave strides it ----------
@@ -617,9 +644,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
         if (lane == 0) {
             if (partial || PANELS)
-                unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ
+                unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ (never under PEER)
             else
-                y[r0] = y_in[r0] + z;
+                y_store<PEER, false>(y, peers, r0, y_in[r0] + z);
         }
     } else {
         // ---- one long row in the reference's order: lane 0 adds tiles of products ---------
@@ -642,7 +669,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(y + r0, z);
             else
-                y[r0] = y_in[r0] + z;
+                y_store<PEER, false>(y, peers, r0, y_in[r0] + z);
         }
     }
 }

@@ -26,8 +26,50 @@ int spmv_hip_csr_spmv(const spmv_hip_plan * pl, const int32_t * p, const int32_t
     return spmv_hip_csr_spmv_out(pl, p, j, a, x, y, y, stream);
 }
 
+static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
+                           const double * x, const double * y_in, double * y, void * stream, const spmv::PeerY * peers, int * fused);
+
 int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
                           const double * x, const double * y_in, double * y, void * stream)
+{
+    return csr_spmv_launch(pl, p, j, a, x, y_in, y, stream, nullptr, nullptr);
+}
+
+// defined in peer_gather.hip
+int spmv_hip_peer_push(const double * d_src, double * const * d_dst, int ndst, int64_t n, void * stream);
+
+int spmv_hip_csr_spmv_out_peers(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
+                                const double * x, const double * y_in, double * y, double * const * peer_y, int npeers,
+                                int * fused_out, void * stream)
+{
+    if (npeers < 0 || (npeers > 0 && !peer_y))
+        return fail(SPMV_HIP_ERR_INVALID, "bad peer list");
+    for (int k = 0; k < npeers; ++k)
+        if (!peer_y[k])
+            return fail(SPMV_HIP_ERR_INVALID, "null peer pointer");
+    if (fused_out)
+        *fused_out = 0;
+    if (npeers == 0)
+        return csr_spmv_launch(pl, p, j, a, x, y_in, y, stream, nullptr, nullptr);
+    int fused = 0;
+    spmv::PeerY py{};
+    if (npeers <= spmv::kMaxPeers) {
+        for (int k = 0; k < npeers; ++k)
+            py.y[k] = peer_y[k];
+        py.n = npeers;
+    }
+    int rc = csr_spmv_launch(pl, p, j, a, x, y_in, y, stream, npeers <= spmv::kMaxPeers ? &py : nullptr, &fused);
+    if (rc != SPMV_HIP_OK)
+        return rc;
+    if (fused_out)
+        *fused_out = fused;
+    if (!fused && pl && pl->rows > 0) // this plan's kernel has no forwarding variant: one more launch pushes the segment
+        return spmv_hip_peer_push(y, peer_y, npeers, pl->rows, stream);
+    return SPMV_HIP_OK;
+}
+
+static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const int32_t * j, const double * a,
+                           const double * x, const double * y_in, double * y, void * stream, const spmv::PeerY * peers, int * fused)
 {
     if (!pl)
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
@@ -156,6 +198,19 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan * pl, const int32_t * p, const int
 #endif
             else if (pl->tile == 1024) {
                 if (xcd) SPMV_WT_C(1024, true); else SPMV_WT_C(1024, false);
+            } else if (peers && c16 && x32 && !xcd && pl->split_rows == 0 && !pl->d_blocks && !pl->d_segblocks) {
+                // one process per GPU: the default kernel (with or without the value dictionary) stores every row sum
+                // into the other ranks' copies of y as well (split long rows add partial sums atomically and keep the
+                // separate push; so do the plans whose tiles are shared with a window kernel)
+                if (pl->nvalues > 0 && pl->values_from == a)
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues, *peers);
+                else
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, *peers);
+                *fused = 1;
             } else if (c16 && x32 && pl->nvalues > 0 && pl->values_from == a) {
                 // the default kernel with the value dictionary: one byte per entry instead of eight
                 if (xcd)

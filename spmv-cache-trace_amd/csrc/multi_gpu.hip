@@ -61,6 +61,7 @@ void multi_free_matrix(spmv_hip_ctx * c)
         (void) hipStreamSynchronize(c->parts[g]->stream);
         free_ctx_matrix(c->parts[g]);
         c->parts[g]->borrowed_y = nullptr;
+        c->parts[g]->peer_y.clear();
         if (g < c->yfull.size() && c->yfull[g]) {
             (void) hipFree(c->yfull[g]);
             c->yfull[g] = nullptr;
@@ -116,6 +117,13 @@ int multi_layout(spmv_hip_ctx * c, int32_t rows, const long long * entries_befor
         part->borrowed_y = c->yfull[(size_t) g] + (size_t) g * (size_t) chunk;
         part->csr_algorithm = c->csr_algorithm;
         part->csr_lanes = c->csr_lanes;
+    }
+    for (int g = 0; g < G; ++g) { // fused peer store: where part g's rows live in the other devices' copies
+        c->parts[(size_t) g]->peer_y.clear();
+        if (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE)
+            for (int h = 0; h < G; ++h)
+                if (h != g)
+                    c->parts[(size_t) g]->peer_y.push_back(c->yfull[(size_t) h] + (size_t) g * (size_t) chunk);
     }
     return SPMV_HIP_OK;
 }
@@ -377,7 +385,9 @@ int multi_run(spmv_hip_ctx * c)
         if (rc != 0)
             return rc;
     }
-    if (c->peer_gather) {
+    if (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) {
+        // every part's run has delivered its rows already (spmv_hip_run of a part with peer_y)
+    } else if (c->peer_gather) {
         int rc = multi_peer_gather(c);
         if (rc != 0)
             return rc;
@@ -455,7 +465,7 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
     // SPMV_HIP_SHARE_DEVICES=1 (rehearsals on fewer devices than parts): part g runs on device g mod visible.
     // Only with the peer gather -- RCCL refuses two ranks on one device.
     const char * share_env = std::getenv("SPMV_HIP_SHARE_DEVICES");
-    const bool share = share_env && share_env[0] == '1' && (flags & SPMV_HIP_FLAG_PEER_GATHER);
+    const bool share = share_env && share_env[0] == '1' && (flags & (SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_FUSED_PEER_STORE));
     if (num_gpus < 1 || (num_gpus > n && !share) || num_gpus > 64)
         return fail(SPMV_HIP_ERR_INVALID, "num_gpus must be between 1 and the number of visible devices");
     spmv_hip_ctx * c = new (std::nothrow) spmv_hip_ctx;
@@ -463,7 +473,7 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
         return fail(SPMV_HIP_ERR_ALLOC, "ctx allocation failed");
     c->multi = true;
     c->flags = flags;
-    c->peer_gather = (flags & SPMV_HIP_FLAG_PEER_GATHER) != 0;
+    c->peer_gather = (flags & (SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_FUSED_PEER_STORE)) != 0;
     c->yfull.assign((size_t) num_gpus, nullptr);
     int rc = SPMV_HIP_OK;
     for (int g = 0; g < num_gpus && rc == SPMV_HIP_OK; ++g) {

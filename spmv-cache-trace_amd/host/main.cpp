@@ -81,6 +81,7 @@ enum Key
     key_matrix_cache,
     key_exact_order,
     key_peer_gather,
+    key_fused_peer_store,
     key_balance_entries,
     key_threads,
     key_check,
@@ -168,6 +169,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case key_matrix_cache: setenv("SPMV_MATRIX_CACHE", arg, 1); break;
     case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
     case key_peer_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PEER_GATHER; break;
+    case key_fused_peer_store: a.spmv.hip_flags |= SPMV_HIP_FLAG_FUSED_PEER_STORE; break;
     case key_balance_entries: a.spmv.hip_flags |= SPMV_HIP_FLAG_BALANCE_ENTRIES; break;
     case key_threads:
         if (!parse_count(arg, n) || n < 0 || n > 4096)
@@ -289,6 +291,8 @@ int main(int argc, char ** argv)
          "with --gpus: cut the rows at equal shares of the stored entries instead of ceil(rows/G) rows per device", 3},
         {"peer-gather", key_peer_gather, nullptr, 0,
          "with --gpus: gather y by remote stores over xGMI (one kernel per device) instead of RCCL", 3},
+        {"fused-peer-store", key_fused_peer_store, nullptr, 0,
+         "with --gpus: every device's multiply stores its row sums into all devices' y itself (no RCCL, no gather launch)", 3},
         {"csr-algorithm", key_csr_algorithm, "NAME", 0, "auto, scalar, vector, adaptive or wavetile", 3},
         {"lanes-per-row", key_lanes, "L", 0, "lanes per row of the vector algorithm (2..64, power of two)", 3},
         {"exact-order", key_exact_order, nullptr, 0, "sum every row left to right like the CPU loop (bit-exact)", 3},

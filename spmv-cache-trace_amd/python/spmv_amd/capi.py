@@ -33,6 +33,7 @@ FLAG_NO_VALUE_INDEX = 0x100000
 FLAG_PEER_GATHER = 0x200000
 FLAG_BALANCE_ENTRIES = 0x400000
 FLAG_NO_SEGMENT_WINDOW = 0x800000
+FLAG_FUSED_PEER_STORE = 0x1000000
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -74,6 +75,12 @@ SIGNATURES = {
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_csr_spmv_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "spmv_hip_csr_spmv_out_peers": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _vp]),
+    "spmv_hip_ipc_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.c_char_p]),
+    "spmv_hip_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "spmv_hip_ipc_close": (C.c_int, [_vp]),
+    "spmv_hip_ipc_free": (C.c_int, [_vp]),
+    "spmv_hip_peer_push": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, _vp]),
     "spmv_hip_coo_spmv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_coo_sort_by_row": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "spmv_hip_ell_to_column_major": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
@@ -337,6 +344,33 @@ class CsrPlan:
     def refresh_values(self, d_row_ptr, d_col, d_val, stream=0):
         """Re-copy the values into the plan's column-panel copy (no-op without panels)."""
         check(self.lib.spmv_hip_plan_csr_refresh_values(self.h, d_row_ptr, d_col, d_val, stream))
+
+
+def ipc_alloc(nbytes):
+    """(device address, 64-byte handle) of zeroed device memory other processes can map (ipc_open)."""
+    h = C.create_string_buffer(64)
+    p = _vp()
+    check(load().spmv_hip_ipc_alloc(C.byref(p), nbytes, h))
+    return p.value, h.raw
+
+
+def ipc_open(handle):
+    p = _vp()
+    check(load().spmv_hip_ipc_open(handle, C.byref(p)))
+    return p.value
+
+
+def ipc_close(addr):
+    check(load().spmv_hip_ipc_close(addr))
+
+
+def ipc_free(addr):
+    check(load().spmv_hip_ipc_free(addr))
+
+
+def peer_push(d_src, d_dst_list, n, stream=0):
+    arr = (_vp * len(d_dst_list))(*d_dst_list)
+    check(load().spmv_hip_peer_push(d_src, arr, len(d_dst_list), n, stream))
 
 
 def coo_spmv(rows, nnz, d_row, d_col, d_val, d_x, d_y, stream=0):

@@ -37,9 +37,36 @@ import torch.distributed as dist
 from . import capi, partition
 
 
+def upload_and_plan(local_rows, cols, device, p_local, c_local, v_local, x_host, algorithm, lanes_per_row, flags):
+    """This rank's rows on its GPU and the launch plan for them (tile classes, column panels, value dictionary)."""
+    plan = capi.CsrPlan(local_rows, cols, p_local, algorithm, lanes_per_row, flags)
+    tp = torch.from_numpy(np.ascontiguousarray(p_local, dtype=np.int32)).to(device)
+    tc = torch.from_numpy(np.ascontiguousarray(c_local, dtype=np.int32)).to(device)
+    tv = torch.from_numpy(np.ascontiguousarray(v_local, dtype=np.float64)).to(device)
+    tx = torch.from_numpy(np.ascontiguousarray(x_host, dtype=np.float64)).to(device)
+    if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
+        stream = torch.cuda.current_stream().cuda_stream
+        plan.compress(tc.data_ptr(), stream)
+        # column panels keep a snapshot of the values: the operator holds the tensors it was taken from for as
+        # long as the plan lives, so it cannot go stale
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        # ... and so does the value dictionary of a matrix with few distinct values (same lifetime argument)
+        plan.index_values(tv.data_ptr(), stream)
+    return plan, tp, tc, tv, tx
+
+
+def raw_stream_getter():
+    """torch's current stream of a device as a raw hipStream_t, looked up per call with one C call."""
+    fn = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if fn is None:
+        def fn(i):
+            return torch.cuda.current_stream(i).cuda_stream
+    return fn
+
+
 class DistributedCsrSpmv:
     def __init__(self, rows, cols, rank, world, device, local_rows, local_spmv, group=None, overlap=False,
-                 ranges=None, local_spmv_out=None, pingpong=True):
+                 ranges=None, local_spmv_out=None, pingpong=True, full=None):
         self.rows, self.cols = rows, cols
         self.rank, self.world = rank, world
         if ranges is None:
@@ -72,7 +99,11 @@ class DistributedCsrSpmv:
         # [rank * chunk, (rank + 1) * chunk), so the all-gather is in place (send buffer = the rank's
         # slot of the receive buffer): the collective moves only what comes from other ranks and the
         # rank's own segment is never copied.  Two such vectors alternate with pingpong.
-        self.full = [torch.zeros(self.chunk * world, dtype=torch.float64, device=device) for _ in range(2 if self.pingpong else 1)]
+        if full is not None:  # the caller's vector(s): memory the other ranks can store into (PeerCsrSpmv)
+            assert len(full) == (2 if self.pingpong else 1) and all(f.numel() == self.chunk * world for f in full)
+            self.full = list(full)
+        else:
+            self.full = [torch.zeros(self.chunk * world, dtype=torch.float64, device=device) for _ in range(2 if self.pingpong else 1)]
         self.seg = [f[rank * self.chunk:(rank + 1) * self.chunk] for f in self.full]
         self.cur = 0  # the buffer that holds the current y_local (and, after its gather, the current y)
         self.send_buf = None
@@ -82,26 +113,18 @@ class DistributedCsrSpmv:
             self.seg = [torch.zeros(self.chunk, dtype=torch.float64, device=device)]
             self.send_buf = torch.zeros(self.chunk, dtype=torch.float64, device=device)
         self.inflight = []  # outstanding gathers, oldest first
+        self.collective = True  # the gather is a collective call (PeerCsrSpmv: stores into the other ranks' vectors)
 
     @classmethod
     def on_gpu(cls, rows, cols, rank, world, device, p_local, c_local, v_local, x_host,
                algorithm=capi.CSR_AUTO, lanes_per_row=0, flags=0, group=None, overlap=False, ranges=None,
-               pingpong=True):
+               pingpong=True, uploaded=None):
         """Product path: local slice uploaded to `device`, multiplied by the HIP kernel
-        on torch's current stream.  Raises if the HIP library or the GPU is missing."""
+        on torch's current stream.  Raises if the HIP library or the GPU is missing.
+        `uploaded`: the (plan, row_ptr, column, value, x) of another operator on the same rows, to share."""
         local_rows = len(p_local) - 1
-        plan = capi.CsrPlan(local_rows, cols, p_local, algorithm, lanes_per_row, flags)
-        tp = torch.from_numpy(np.ascontiguousarray(p_local, dtype=np.int32)).to(device)
-        tc = torch.from_numpy(np.ascontiguousarray(c_local, dtype=np.int32)).to(device)
-        tv = torch.from_numpy(np.ascontiguousarray(v_local, dtype=np.float64)).to(device)
-        tx = torch.from_numpy(np.ascontiguousarray(x_host, dtype=np.float64)).to(device)
-        if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
-            plan.compress(tc.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            # column panels keep a snapshot of the values: this object holds the tensors it was taken
-            # from (self._keep) for as long as the plan lives, so it cannot go stale
-            plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            # ... and so does the value dictionary of a matrix with few distinct values (same lifetime argument)
-            plan.index_values(tv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        plan, tp, tc, tv, tx = uploaded or upload_and_plan(local_rows, cols, device, p_local, c_local, v_local, x_host, algorithm,
+                                                           lanes_per_row, flags)
 
         # The launch itself is one foreign call with everything resolved beforehand (device addresses, the plan
         # handle): a rank-local multiply of a partitioned matrix lasts 20-30 us, and ten attribute look-ups per
@@ -114,10 +137,7 @@ class DistributedCsrSpmv:
         dev_index = torch.device(device).index
         if dev_index is None:
             dev_index = torch.cuda.current_device()
-        raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-        if raw_stream is None:
-            def raw_stream(i):
-                return torch.cuda.current_stream(i).cuda_stream
+        raw_stream = raw_stream_getter()
         # device addresses are cached for the segment views only (they live as long as this object, so neither
         # their addresses nor their ids can be reused); any other tensor is asked for its address every time
         seg_addr = {}
@@ -136,6 +156,7 @@ class DistributedCsrSpmv:
                    local_spmv_out=local_spmv_out, pingpong=pingpong)
         self.plan = plan
         self._keep = (tp, tc, tv, tx)
+        self.uploaded = (plan, tp, tc, tv, tx)
         self._seg_keep = list(self.seg)  # pins the ids the cache is keyed by
         for t in self._seg_keep:
             seg_addr[id(t)] = t.data_ptr()

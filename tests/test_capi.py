@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_strerror():
     lib = capi.load()
-    assert lib.spmv_hip_version() == 120
+    assert lib.spmv_hip_version() == 130
     assert lib.spmv_hip_strerror(0) == b"success"
     # the ELL overflow message is the reference's (src/matrix/ell-matrix.cpp:202-204)
     assert b"Integer overflow when computing number of non-zeros" in lib.spmv_hip_strerror(capi.ERR_OVERFLOW)

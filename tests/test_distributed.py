@@ -105,3 +105,94 @@ def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced
     mp.spawn(_worker, args=(world, port, 5, str(tmp_path), overlap, balanced, pingpong), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
+
+
+class _ShmVectors:
+    """Test double of peer.HipPeerVectors: every rank's copy of y in POSIX shared memory, the others' mapped."""
+
+    def __init__(self, n, rank, world, tag):
+        import torch
+        import torch.distributed as dist
+        from multiprocessing import shared_memory
+        self.rank, self.world = rank, world
+        self.mine = shared_memory.SharedMemory(create=True, size=8 * n, name="%s_%d" % (tag, rank))
+        np.ndarray((n,), dtype=np.float64, buffer=self.mine.buf)[:] = 0.0
+        dist.barrier()
+        self.theirs = {h: shared_memory.SharedMemory(name="%s_%d" % (tag, h)) for h in range(world) if h != rank}
+        self.views = {h: np.ndarray((n,), dtype=np.float64, buffer=s.buf) for h, s in self.theirs.items()}
+        self.own = torch.from_numpy(np.ndarray((n,), dtype=np.float64, buffer=self.mine.buf))
+
+    def close(self):
+        import torch.distributed as dist
+        self.own = None
+        self.views = {}
+        dist.barrier()
+        for s in self.theirs.values():
+            s.close()
+        dist.barrier()
+        self.mine.close()
+        self.mine.unlink()
+
+
+def _peer_worker(rank, world, port, steps, out_dir, balanced):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    sys.path.insert(0, os.path.join(root, "spmv-cache-trace_amd", "python"))
+    import torch
+    import torch.distributed as dist
+    import oracle_py
+    from spmv_amd import partition, synth
+    from spmv_amd.peer import PeerCsrSpmv
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = oracle_py.Oracle()
+    if balanced:
+        rows, cols, p, c, v = synth.powerlaw(700, 700, seed=4, max_len=300)
+        ranges = partition.nnz_balanced_ranges(p, world)
+        chunk = max(e - b for b, e in ranges)
+    else:
+        rows, cols, p, c, v = synth.stencil27_like(11, 9, 7, seed=5)
+        ranges = None
+        chunk = partition.row_chunk(rows, world)
+    x = synth.x_vector(cols, seed=9)
+    b, e = ranges[rank] if balanced else partition.row_range(rows, rank, world)
+    pl, cl, vl = partition.csr_slice(p, c, v, b, e)
+    vec = _ShmVectors(chunk * world, rank, world, "spmvt%d" % port)
+
+    def local_spmv(y_local):  # the oracle on this rank's rows, in place in its slot of its own vector
+        y = y_local.numpy()
+        y[:e - b] = O.csr_spmv(e - b, pl, cl, vl, x, y=y[:e - b])
+
+    def deliver():  # what spmv_hip_peer_push / the fused kernel do: my slot into everybody else's vector
+        mine = vec.own.numpy()[rank * chunk: rank * chunk + (e - b)]
+        for h, view in vec.views.items():
+            view[rank * chunk: rank * chunk + (e - b)] = mine
+
+    op = PeerCsrSpmv(rows, cols, rank, world, torch.device("cpu"), e - b, local_spmv, vec, ranges=ranges, deliver=deliver)
+    ok = not op.collective and not op.pingpong and len(op.full) == 1 and op.full[0] is vec.own
+    for _ in range(steps):
+        op.step()  # no collective inside: ranks may drift apart here
+    want = O.csr_spmv(rows, p, c, v, x, runs=steps)
+    ok = ok and np.array_equal(op.y().numpy(), want)  # y() = finish(): complete on EVERY rank
+    op.zero()
+    ok = ok and float(op.y().abs().max()) == 0.0
+    op.step()
+    ok = ok and np.array_equal(op.y().numpy(), O.csr_spmv(rows, p, c, v, x))
+    open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")
+    op.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,balanced", [(2, False), (3, False), (3, True)])
+def test_partitioned_spmv_with_peer_stores_gloo(tmp_path, world, balanced):
+    """The gather as stores into the other ranks' vectors (spmv_amd/peer.py): partition, slots, completion by
+    finish() (sync + barrier), zero(), uneven segments -- on CPU with the vectors in shared memory."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_peer_worker, args=(world, port, 4, str(tmp_path), balanced), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"

@@ -347,15 +347,21 @@ def test_cli_synthetic_full_size_gpus_and_check():
     assert d["kernel"]["device"]["gpus"] == 4 and d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
 
 
+@pytest.mark.parametrize("gather", ["push", "fused"])
 @pytest.mark.parametrize("parts,balance", [(2, False), (3, False), (8, False), (3, True), (8, True)])
-def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, balance):
+def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, balance, gather):
     """The G > 1 flow of spmv_hip_create_multi -- ceil(rows / G) row blocks (src/matrix/csr-matrix.cpp:77-95), one
     plan per block, y slots, the gather, set_y / get_y -- with every part on this box's one device
     (SPMV_HIP_SHARE_DEVICES=1) and the gather done by the peer-push kernel (SPMV_HIP_FLAG_PEER_GATHER; RCCL cannot put
     two ranks on a device).  Rows are not a multiple of G, the last block is short, one block is empty of entries.
-    balance: SPMV_HIP_FLAG_BALANCE_ENTRIES, blocks of equal stored entries (unequal rows, padded y slots)."""
+    balance: SPMV_HIP_FLAG_BALANCE_ENTRIES, blocks of equal stored entries (unequal rows, padded y slots).
+    gather "fused": SPMV_HIP_FLAG_FUSED_PEER_STORE -- every part's run delivers its rows itself; on a 27-point stencil
+    (the default kernel: row sums forwarded by the multiply) and on power-law rows (balanced tiles: pushed behind it)."""
     import os
-    rows, cols, p, c, v = synth.powerlaw(30011, 30011, seed=13)
+    if gather == "fused" and not balance:
+        rows, cols, p, c, v = synth.stencil27_like(31, 29, 33)
+    else:
+        rows, cols, p, c, v = synth.powerlaw(30011, 30011, seed=13)
     # rows of the second block hold nothing: a part without entries
     chunk = -(-rows // parts)
     lens = np.diff(p).astype(np.int64)
@@ -371,12 +377,13 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
     scale = 3 * abs_products(rows, p, c, v, x) + np.abs(y0)
     os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
     try:
-        with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
+        gflag = capi.FLAG_PEER_GATHER if gather == "push" else capi.FLAG_FUSED_PEER_STORE
+        with capi.Context(num_gpus=parts, flags=gflag | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
             ctx.upload_csr(rows, cols, p, c, v)
             ctx.set_x(x)
             ctx.set_y(y0)
             ctx.run(3)
-            assert_close(ctx.get_y(), want, scale, what="G=%d on one device, balance=%s" % (parts, balance))
+            assert_close(ctx.get_y(), want, scale, what="G=%d on one device, balance=%s, gather %s" % (parts, balance, gather))
             info = ctx.info()
             assert info["devices"] == parts and info["rows"] == rows and info["stored"] == len(c)
             k_ns, g_ns = ctx.last_run_times()
