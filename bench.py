@@ -673,6 +673,8 @@ def main():
         gather_check = {"rows_checked": strip, "of_rank": world - 1, "max_rel_err": err, "pass": bool(err <= 1e-10)}
         plan_s.close()
         S.close()
+    if use_dist:
+        dist.barrier()  # rank 0 is done reading its vector: the ranks may multiply on
 
     if use_dist and schemes is not None:
         # per scheme: the local multiply alone (no delivery of any kind), the delivery alone where it is a launch

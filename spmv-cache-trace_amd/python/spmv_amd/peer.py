@@ -14,7 +14,9 @@ contiguous split).  Two ways the doubles travel, both through include/spmv_hip.h
 
 Nothing is received by a kernel.  Row blocks are disjoint, so ranks may drift apart without ever touching the
 same doubles; a rank's vector is complete -- and may be read -- after ``finish()``: every rank synchronises its
-device, then the ranks meet at a barrier.  The vectors live in device memory the other processes map with HIP's
+device, then the ranks meet at a barrier.  It stays valid until ANY rank multiplies again (that rank's stores land in
+it without asking): a reader calls ``finish()`` once more when it is done, before the ranks go on -- the place an
+all-gather's implicit hand-shake would have taken.  The vectors live in device memory the other processes map with HIP's
 inter-process handles (``HipPeerVectors``); the partition / completion logic is exercised on CPU with vectors in
 POSIX shared memory (``tests/test_distributed.py``).
 """

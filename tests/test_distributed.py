@@ -107,6 +107,16 @@ def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
 
 
+def _leave_together(out_dir, rank, world, timeout=60.0):
+    """A rank that tears its sockets down while another is still inside the last barrier resets that one's read (gloo):
+    every rank says on the file system that it is out of its last collective, and waits for the others to say so."""
+    import time
+    open(os.path.join(out_dir, "left%d" % rank), "w").write("x")
+    t0 = time.time()
+    while time.time() - t0 < timeout and not all(os.path.exists(os.path.join(out_dir, "left%d" % r)) for r in range(world)):
+        time.sleep(0.01)
+
+
 class _ShmVectors:
     """Test double of peer.HipPeerVectors: every rank's copy of y in POSIX shared memory, the others' mapped."""
 
@@ -177,13 +187,18 @@ def _peer_worker(rank, world, port, steps, out_dir, balanced):
         op.step()  # no collective inside: ranks may drift apart here
     want = O.csr_spmv(rows, p, c, v, x, runs=steps)
     ok = ok and np.array_equal(op.y().numpy(), want)  # y() = finish(): complete on EVERY rank
-    op.zero()
+    op.zero()  # (begins with finish(): nobody multiplies on while another rank still compares)
     ok = ok and float(op.y().abs().max()) == 0.0
+    op.finish()  # a vector may be read until ANY rank multiplies again: tell the others this rank is done reading
     op.step()
     ok = ok and np.array_equal(op.y().numpy(), O.csr_spmv(rows, p, c, v, x))
     open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")
-    op.close()
-    dist.barrier()
+    try:
+        op.close()  # ends with two barriers
+    except Exception:  # say which rank failed first: the others only see their connections drop
+        import traceback
+        open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("close failed:\n" + traceback.format_exc())
+    _leave_together(out_dir, rank, world)
     dist.destroy_process_group()
 
 
@@ -194,5 +209,5 @@ def test_partitioned_spmv_with_peer_stores_gloo(tmp_path, world, balanced):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_peer_worker, args=(world, port, 4, str(tmp_path), balanced), nprocs=world, join=True)
-    for r in range(world):
-        assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
+    verdicts = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() for r in range(world)]
+    assert verdicts == ["ok"] * world, verdicts
