@@ -15,7 +15,8 @@ namespace spmv {
 // while t * len < 2^22 (t < 1024, len <= 512), with t * magic < 2^32.
 constexpr int kShiftedMaxLen = 128;
 
-// Timing experiments of the value-dictionary path (parts of the work compiled out: wrong results by design).  They exist
+// Timing experiments of the value-dictionary path (bits 1-8: parts of the work compiled out, wrong results by design;
+// 16: y read with a plain instead of a non-temporal load, 32: y written with a plain store -- right results).  They exist
 // only in libraries built by tools/ablate.sh with -DSPMV_HIP_EXPERIMENTS -DSPMV_VI_ABLATE=n; everywhere else the constant
 // is 0 and every test on it folds away.
 #if defined(SPMV_HIP_EXPERIMENTS) && defined(SPMV_VI_ABLATE)
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         // (value-dictionary variant: y is read once and written once per launch -- non-temporal, to keep it out of
         // the way of x in the caches: 143 -> 139 us)
         const double yv = (PANELS || (VI && (kViAblate & 2))) ? 0.0 // panels: the partial sums are added atomically
-            : (VI ? __builtin_nontemporal_load(yin_t + rowi) : yin_t[rowi]);
+            : ((VI && !(kViAblate & 16)) ? __builtin_nontemporal_load(yin_t + rowi) : yin_t[rowi]);
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
         const bool second = nrows > kWave; // wave-uniform; implies one lane per row
         int psB = 0, peB = 0;
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 peB = p[r0 + rowB + 1];
             }
             if (!PANELS && !(VI && (kViAblate & 2)))
-                yvB = VI ? __builtin_nontemporal_load(yin_t + rowB) : yin_t[rowB];
+                yvB = (VI && !(kViAblate & 16)) ? __builtin_nontemporal_load(yin_t + rowB) : yin_t[rowB];
         }
         const int last = (k1 - 1 - kb) & ~3;
         if (VI && C16 && TILE == 512 && !PANELS && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
@@ -520,9 +521,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             tile_rows_uniform_indexed<X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                            vidx + kb, vtab, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
             if (lane < nrows && !((kViAblate & 8) && lane > 0))
-                y_store<PEER, true>(y, peers, r0 + lane, yv + zA);
+                y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + lane, yv + zA);
             if (second && lane + kWave < nrows && !(kViAblate & 8))
-                y_store<PEER, true>(y, peers, r0 + lane + kWave, yvB + zB);
+                y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + lane + kWave, yvB + zB);
             return;
         }
         if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             if (PANELS)
                 unsafeAtomicAdd(yt + sub, z);
             else if (VI)
-                y_store<PEER, true>(y, peers, r0 + sub, yv + z);
+                y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + sub, yv + z);
             else
                 y_store<PEER, false>(y, peers, r0 + sub, yv + z);
         }
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
                 if (PANELS)
                     unsafeAtomicAdd(yt + lane + kWave, zB);
                 else if (VI)
-                    y_store<PEER, true>(y, peers, r0 + lane + kWave, yvB + zB);
+                    y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + lane + kWave, yvB + zB);
                 else
                     y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB);
             }

@@ -268,6 +268,21 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 minlen = std::min(minlen, len);
                 ++r1;
             }
+#ifdef SPMV_HIP_EXPERIMENTS
+            // tools/ab.py: tiles of short rows end on a multiple of SPMV_HIP_TILE_ROW_ALIGN rows (whole 128-byte lines of y per tile)
+            if (const char * al = std::getenv("SPMV_HIP_TILE_ROW_ALIGN")) {
+                const int align = std::atoi(al);
+                if (align > 1 && r1 - r > 2 * align && r1 < rows && (r1 % align) != 0 && (r1 / align) * align > r) {
+                    r1 = (r1 / align) * align;
+                    maxlen = 0;
+                    minlen = INT32_MAX;
+                    for (int32_t q = r; q < r1; ++q) {
+                        maxlen = std::max(maxlen, p[q + 1] - p[q]);
+                        minlen = std::min(minlen, p[q + 1] - p[q]);
+                    }
+                }
+            }
+#endif
             if (r1 == r) { // one row longer than a tile
                 const long long len = (long long) p[r + 1] - p[r];
                 pl->long_blocks++;
