@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Performance floor of the hot path: one launch time per workload class, measured with HIP events on the launch
+stream, compared by tests/test_gpu_perf_floor.py with the committed table tests/golden/perf_floor.json.
+
+    python tools/perf_floor.py                 # measure and print
+    python tools/perf_floor.py --write         # ... and merge into tests/golden/perf_floor.json (the slower of old and
+                                               #     new survives: the table is a floor for every box, not a record)
+    python tools/perf_floor.py --write --reset # ... or replace the table
+
+Each workload is HBM-resident at a size that loads in about a second; together they touch every kernel family a
+BASELINE configuration runs through: the lane-per-row stencil tiles with and without a value dictionary, shifted
+tiles with an x window, ELLPACK rows summed by one and by several lanes, narrow tiles with several lanes per row
+(queen-like), shifted KKT tiles, segment windows (KKT-like with jittered stencils), balanced tiles (web graph, as COO
+and as hybrid), column panels (uniformly random columns).  The number compared is the MINIMUM over a few rounds of
+the mean launch time of 20 back-to-back launches: the most repeatable figure a shared box gives.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
+TABLE = os.path.join(ROOT, "tests", "golden", "perf_floor.json")
+
+# name -> (matrix spec, format, flags)
+WORKLOADS = {
+    "poisson4096_csr_dictionary": ("synthetic:poisson2d:4096", "csr", 0),
+    "poisson4096_csr_values": ("synthetic:poisson2d:4096", "csr", 0x100000),  # SPMV_HIP_FLAG_NO_VALUE_INDEX
+    "banded27_csr": ("synthetic:banded:4000000,13", "csr", 0),
+    "banded33_ell": ("synthetic:banded:2000000,16", "ell", 0),
+    "queen_small_ell": ("synthetic:queen:80,60,60", "ell", 0),
+    "queen_small_csr": ("synthetic:queen:80,60,60", "csr", 0),
+    "kkt125_csr": ("synthetic:kkt:125", "csr", 0),
+    "kkt125_jitter50_csr": ("synthetic:kkt:125,50", "csr", 0),
+    "webbase_coo": ("synthetic:webbase", "coo", 0),
+    "webbase_hybrid": ("synthetic:webbase", "hybrid", 0),
+    "random24_csr": ("synthetic:random:2000000,24,3", "csr", 0),
+}
+
+
+def measure(name, rounds=5, reps=20):
+    """(min over rounds of the mean launch time in us, info dict)."""
+    import torch
+    from spmv_amd import capi, hostapi, synth
+    spec, fmt, flags = WORKLOADS[name]
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    M = hostapi.load(spec, fmt)
+    x = synth.x_vector(M.cols, "uniform", seed=12345)
+    keep = []
+    if fmt == "csr":
+        plan = capi.CsrPlan(M.rows, M.cols, M.row_ptr, capi.CSR_AUTO, 0, flags)
+        tp, tc, tv = (torch.from_numpy(np.asarray(t)).to(dev) for t in (M.row_ptr, M.column_index, M.value))
+        tx = torch.from_numpy(x).to(dev)
+        ty = torch.zeros(M.rows, dtype=torch.float64, device=dev)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr())
+
+        def launch():
+            plan.spmv(*ptrs, stream)
+        info = plan.info()
+        keep = [plan, tp, tc, tv, tx, ty]
+    else:
+        ctx = capi.Context(0, flags | capi.FLAG_NO_RUN_EVENTS)
+        ctx.set_stream(stream)
+        if fmt == "coo":
+            ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
+        elif fmt == "ell":
+            ctx.upload_ell(M.rows, M.cols, M.row_length, M.column_index, M.value)
+        else:
+            ctx.upload_hybrid(M.rows, M.cols, M.row_length, M.column_index, M.value, M.coo_row_index, M.coo_column_index, M.coo_value)
+        ctx.set_x(x)
+
+        def launch():
+            ctx.run(1, sync=False)
+        info = ctx.info()
+        keep = [ctx]
+    M.close()
+    best = None
+    for rnd in range(rounds + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        if rnd > 0:  # round 0 warms up
+            us = e0.elapsed_time(e1) / reps * 1e3
+            best = us if best is None else min(best, us)
+    for k in keep:
+        if hasattr(k, "close"):
+            k.close()
+    del keep
+    torch.cuda.empty_cache()
+    return best, info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write", action="store_true")
+    ap.add_argument("--reset", action="store_true")
+    ap.add_argument("names", nargs="*")
+    args = ap.parse_args()
+    table = {}
+    if os.path.exists(TABLE) and not args.reset:
+        table = json.load(open(TABLE))["workloads"]
+    for name in (args.names or WORKLOADS):
+        us, info = measure(name)
+        old = table.get(name, {}).get("us")
+        print("%-28s %9.2f us%s" % (name, us, "" if old is None else "   (table %.2f)" % old), flush=True)
+        spec, fmt, flags = WORKLOADS[name]
+        table[name] = {"matrix": spec, "format": fmt, "flags": flags, "us": round(max(us, old or 0.0), 2)}
+    if args.write:
+        json.dump({"what": "minimum over 5 rounds of the mean launch time of 20 back-to-back launches, HIP events, one MI355X; "
+                           "the slower of all boxes measured so far (tools/perf_floor.py --write)",
+                   "tolerance": 1.15, "workloads": table}, open(TABLE, "w"), indent=1)
+        print("wrote", TABLE)
+
+
+if __name__ == "__main__":
+    main()
