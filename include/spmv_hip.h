@@ -331,7 +331,7 @@ int spmv_hip_csr_spmv(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
  * another (they must not overlap; y_in == y_out is spmv_hip_csr_spmv).  For a row-partitioned multiply
  * whose previous y segment is still being sent (the all-gather of src/matrix/csr-matrix.cpp:77-95's
  * row blocks across GPUs): two segment buffers alternate and no copy is needed.  Plans that add
- * partial sums with atomics (split rows > 2048 entries, column panels) and the non-default
+ * partial sums with atomics (split rows > 512 entries, column panels) and the non-default
  * algorithms copy y_in to y_out first. */
 int spmv_hip_csr_spmv_out(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
                           const int32_t *d_column_index, const double *d_value,

@@ -401,15 +401,19 @@ __device__ __forceinline__ void y_store(double * y, const PeerY & peers, long lo
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
-template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false, bool PEER = false>
+// LIST: the launch covers only the tiles named in tile_list (`ntiles` of them) -- what is left for this kernel of a plan
+// whose other tiles belong to a window kernel (a launch over ALL tiles in which 99.8 % of the waves read a descriptor
+// and leave cost the KKT-like matrix 61 of 1040 us).
+template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false, bool PEER = false, bool LIST = false>
 __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
     int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
     const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0,
-    PeerY peers = PeerY{})
+    PeerY peers = PeerY{}, const int32_t * __restrict__ tile_list = nullptr)
 {
+    static_assert(!LIST || (!PANELS && !VI && !XCD), "the tile list is for the plain variants that follow a window kernel");
     static_assert(!PEER || !PANELS, "column panels add partial sums atomically: nothing to forward");
     // y_out = y_in + A*x.  The two may be the same array (y += A*x, the reference's form) or two
     // different ones (a partitioned multiply whose previous result is still being gathered); every
@@ -435,6 +439,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         w = (XCD ? xcd_remap(blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
         if (!VI && w >= ntiles)
             return; // whole wave leaves; no workgroup barrier in the kernels without a value dictionary
+        if (LIST)
+            w = __builtin_amdgcn_readfirstlane(tile_list[w]);
     }
     double * prod = prod_all[wave];
 

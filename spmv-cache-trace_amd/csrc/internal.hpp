@@ -54,8 +54,11 @@ constexpr int kBlock = 256;
 constexpr int kTile = 2048;
 // wavetile: rows longer than kSplitThreshold entries are cut into kSplitChunk-entry
 // chunks handled by different waves (each adds its partial sum with one atomic)
-constexpr int kSplitThreshold = 2048;
-constexpr int kSplitChunk = 1024;
+// (round 3: 2048 / 1024 -> 512 / 512.  One wave striding a 2000-entry row -- four gathers in flight per lane, eight dependent
+// trips -- was the tail of the whole launch on a web graph: webbase-like 27.1 -> 24.1 us, power law 43.1 -> 40.9 us,
+// profiles/r03_split_rows.log)
+constexpr int kSplitThreshold = 512;
+constexpr int kSplitChunk = 512;
 
 inline bool aligned16(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 // compute units of the current device (MI355X: 256); asked once per device, 256 if the query fails
@@ -95,6 +98,8 @@ struct spmv_hip_plan {
     int2 * d_blocks = nullptr; // block windows: {first column, slots} per 16 tiles (csr_blockwin_kernel)
     int nblocks16 = 0;
     int blockwin_tiles = 0;
+    int32_t * d_rest_tiles = nullptr; // with block / segment windows: the tiles NOT marked for them (what csr_wavetile_kernel<LIST> multiplies)
+    int nrest_tiles = 0;
     // segment windows (csr_segwin.hpp): x staged through LDS per block of seg_tiles_per_block tiles, in up to 8 column segments
     spmv::SegWinBlock * d_segblocks = nullptr;
     int nsegblocks = 0, seg_tiles_per_block = 0, segwin_tiles = 0, segwin_slots = 0;

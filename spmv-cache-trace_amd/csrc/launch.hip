@@ -180,6 +180,17 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             // every tile belongs to the block-window kernel below: nothing for this launch to do
             const bool all_blockwin = c16 && (pl->d_blocks || pl->d_segblocks) && pl->blockwin_tiles == pl->ntiles;
             if (all_blockwin) {
+            } else if (c16 && (pl->d_blocks || pl->d_segblocks) && pl->d_rest_tiles && pl->nrest_tiles > 0 && pl->tile == 512 && !xcd) {
+                // the few tiles a window kernel did not take: a launch over exactly those
+                const dim3 grid((unsigned) ((pl->nrest_tiles + 3) / 4));
+                if (x32)
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, false, false, true>), grid, dim3(256), 0, s,
+                                       pl->nrest_tiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_rest_tiles);
+                else
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, false, false, false, true>), grid, dim3(256), 0, s,
+                                       pl->nrest_tiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                       spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_rest_tiles);
             } else
             // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants

@@ -148,6 +148,23 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
     pl->streamed_bytes = bytes;
+    // plans with block or segment windows: the list of tiles left to csr_wavetile_kernel (made once, right after marking)
+    if (compressed && (pl->d_blocks || pl->d_segblocks) && !pl->d_rest_tiles && pl->blockwin_tiles < pl->ntiles) {
+        std::vector<int32_t> rest;
+        rest.reserve((size_t) (pl->ntiles - pl->blockwin_tiles));
+        for (int w = 0; w < pl->ntiles; ++w)
+            if (!(d[(size_t) w].z & spmv::kTileMetaBlockWin))
+                rest.push_back(w);
+        rest.resize((rest.size() + 3) & ~(size_t) 3, rest.empty() ? 0 : rest.back()); // padded to whole workgroups (never read past nrest)
+        if (!rest.empty()) {
+            HIP_TRY(hipMalloc((void **) &pl->d_rest_tiles, rest.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(pl->d_rest_tiles, rest.data(), rest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            pl->meta_bytes += rest.size() * sizeof(int32_t);
+        }
+        pl->nrest_tiles = 0;
+        for (int w = 0; w < pl->ntiles; ++w)
+            pl->nrest_tiles += !(d[(size_t) w].z & spmv::kTileMetaBlockWin);
+    }
     return SPMV_HIP_OK;
 }
 
@@ -218,6 +235,11 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
     }
     pl->algorithm = algorithm;
 
+    int split_threshold = kSplitThreshold, split_chunk = kSplitChunk;
+#ifdef SPMV_HIP_EXPERIMENTS
+    if (const char * v = std::getenv("SPMV_HIP_SPLIT_THRESHOLD")) split_threshold = std::max(512, std::atoi(v)); // tools/ab.py
+    if (const char * v = std::getenv("SPMV_HIP_SPLIT_CHUNK")) split_chunk = std::max(64, std::atoi(v));
+#endif
     if (algorithm == SPMV_HIP_CSR_SCALAR) {
         pl->workgroups = grid_for(rows, kBlock);
     } else if (algorithm == SPMV_HIP_CSR_VECTOR) {
@@ -286,9 +308,9 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
             if (r1 == r) { // one row longer than a tile
                 const long long len = (long long) p[r + 1] - p[r];
                 pl->long_blocks++;
-                if (!exact && len > kSplitThreshold) {
+                if (!exact && len > split_threshold) {
                     pl->split_rows++;
-                    for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                    for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
                         desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
                 } else {
                     desc.push_back(make_int4(r, p[r], 0, 0));
@@ -337,9 +359,9 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                     if (r1 == r) { // one row longer than a tile
                         const long long len = (long long) p[r + 1] - p[r];
                         pl->long_blocks++;
-                        if (len > kSplitThreshold) {
+                        if (len > split_threshold) {
                             pl->split_rows++;
-                            for (long long k = p[r]; k < p[r + 1]; k += kSplitChunk)
+                            for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
                                 desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
                         } else {
                             desc.push_back(make_int4(r, p[r], 0, 0));
@@ -441,6 +463,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_blocks);
     if (pl->d_segblocks)
         (void) hipFree(pl->d_segblocks);
+    if (pl->d_rest_tiles)
+        (void) hipFree(pl->d_rest_tiles);
     if (pl->d_vidx)
         (void) hipFree(pl->d_vidx);
     if (pl->d_vtab)

@@ -67,7 +67,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk, bool enable)
 // their offset is clamped into x so that the (never used) gather stays in bounds.
 //
 // A row longer than TILE is a tile by itself (the wave strides it); rows longer than
-// kSplitThreshold (2048 entries) are cut into chunks spread over several waves (bit 31 of the row
+// kSplitThreshold (512 entries) are cut into chunks spread over several waves (bit 31 of the row
 // field), each adding its partial sum with one fp64 atomic.
 // ---------------------------------------------------------------------------------
 constexpr int kTileFlagPartial = (int) 0x80000000u;

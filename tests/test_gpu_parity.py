@@ -695,7 +695,7 @@ def test_shifted_tiles_bit_identical(name):
         "random": lambda: synth.random_uniform(50000, 50000, 9, seed=1),
         # rows stay below the split threshold: chunks of longer rows meet in atomics, whose order
         # (and therefore last bit) may change from launch to launch
-        "powerlaw": lambda: synth.powerlaw(60000, 60000, max_len=1500, seed=4),
+        "powerlaw": lambda: synth.powerlaw(60000, 60000, max_len=500, seed=4),
     }[name]()
     x = synth.x_vector(cols, seed=5)
     dev = torch.device("cuda:0")
