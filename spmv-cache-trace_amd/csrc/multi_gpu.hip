@@ -216,20 +216,22 @@ int multi_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
     if (rc != 0)
         return multi_upload_failed(c, rc);
     const size_t G = c->parts.size();
-    // block of a row: binary search over the G + 1 boundaries (blocks may be empty)
-    auto block_of = [&](int32_t r) {
-        return (size_t) (std::upper_bound(c->row_begin.begin() + 1, c->row_begin.end(), r) - (c->row_begin.begin() + 1));
-    };
+    // block of every ROW, once (rows form contiguous blocks; blocks may be empty), then one counting pass and one
+    // dealing pass over the entries: no search per entry
+    std::vector<uint8_t> block_of_row((size_t) rows);
+    for (size_t g = 0; g < G; ++g)
+        for (int32_t r = c->row_begin[g]; r < c->row_begin[g + 1]; ++r)
+            block_of_row[(size_t) r] = (uint8_t) g;
     std::vector<size_t> start(G + 1, 0);
     for (int32_t k = 0; k < nnz; ++k)
-        ++start[block_of(row_index[k]) + 1];
+        ++start[(size_t) block_of_row[(size_t) row_index[k]] + 1];
     for (size_t g = 0; g < G; ++g)
         start[g + 1] += start[g];
     std::vector<int32_t> ri((size_t) nnz), ci((size_t) nnz);
     std::vector<double> va((size_t) nnz);
     std::vector<size_t> fill(start.begin(), start.end() - 1);
     for (int32_t k = 0; k < nnz; ++k) {
-        const size_t g = block_of(row_index[k]);
+        const size_t g = block_of_row[(size_t) row_index[k]];
         const size_t at = fill[g]++;
         ri[at] = row_index[k] - c->row_begin[g];
         ci[at] = column_index[k];

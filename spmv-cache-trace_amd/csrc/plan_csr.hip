@@ -818,7 +818,8 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
         || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
         || (pl->flags & SPMV_HIP_FLAG_NO_VALUE_INDEX))
-        return pl->inner ? SPMV_HIP_OK : plan_account(pl, pl->d_col16 != nullptr);
+        return (pl->inner || before == 0) ? SPMV_HIP_OK // nothing was dropped: the account of plan / compress still holds
+                                          : plan_account(pl, pl->d_col16 != nullptr);
     if (!d_value)
         return fail(SPMV_HIP_ERR_INVALID, "null device pointer");
     unsigned long long * d_keys = nullptr;
@@ -884,6 +885,8 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
         drop_value_dictionary(pl);
         return rc;
     }
+    if (pl->nvalues == 0 && before == 0)
+        return SPMV_HIP_OK; // more than 128 distinct values and nothing dropped: the account is unchanged (no descriptor download)
     return plan_account(pl, pl->d_col16 != nullptr);
 }
 
