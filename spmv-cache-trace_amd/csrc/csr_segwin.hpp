@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kSegWinWaves * kWave, (W <= 2688 ? 6 : 4)) void csr
 static __global__ __launch_bounds__(kSegWinWaves * kWave) void csr_segwin_mark_kernel(
     int ntiles, int tile, int tiles_per_block, int4 * __restrict__ desc, const int32_t * __restrict__ j,
     uint16_t * __restrict__ j16, SegWinBlock * __restrict__ blocks, int * __restrict__ counts, int apply,
-    int shift, int max_slots)
+    int shift, int max_slots, int take_narrow_blocks)
 {
     constexpr int THREADS = kSegWinWaves * kWave;
     __shared__ unsigned bitmap[kSegWinBitmapWords];
@@ -292,7 +292,8 @@ static __global__ __launch_bounds__(kSegWinWaves * kWave) void csr_segwin_mark_k
     // more than 65536 apart -- which otherwise stream 4-byte indices and gather from all over x (KKT-like with
     // jittered stencils: 1510 -> 926 us).
     // (2) runs of set bits -> at most kSegWinMaxSegs segments (the closest runs merged first)
-    if (tid == 0 && s_ok && s_narrow < t1 - t0) {
+    // (take_narrow_blocks: the A/B switch of the experiments build that produced those numbers)
+    if (tid == 0 && s_ok && (take_narrow_blocks || s_narrow < t1 - t0)) {
         int n = 0, open = -1, prev = -2;
         bool fits = true;
         for (int w = 0; w < kSegWinBitmapWords && fits; ++w) {

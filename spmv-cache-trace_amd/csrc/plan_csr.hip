@@ -579,8 +579,9 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     // only if they are the majority mark them and rewrite their 16-bit column stream to window slots
     if (e == hipSuccess && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * 32
         && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
-        int per_block = 32, max_slots = 4096;
+        int per_block = 32, max_slots = 4096, take_narrow = 0;
 #ifdef SPMV_HIP_EXPERIMENTS
+        if (const char * v = std::getenv("SPMV_HIP_SEGWIN_NARROW")) take_narrow = std::atoi(v) != 0; // windows for blocks of narrow tiles too
         if (const char * v = std::getenv("SPMV_HIP_SEGWIN_TILES")) per_block = std::max(8, std::min(256, std::atoi(v)));
         if (const char * v = std::getenv("SPMV_HIP_SEGWIN_SLOTS")) max_slots = std::max(512, std::min(4096, std::atoi(v)));
 #endif
@@ -592,7 +593,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
         e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
-                               d_column_index, pl->d_col16, (spmv::SegWinBlock *) nullptr, d_count, 0, shift, max_slots);
+                               d_column_index, pl->d_col16, (spmv::SegWinBlock *) nullptr, d_count, 0, shift, max_slots, take_narrow);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
@@ -603,7 +604,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
             if (e == hipSuccess) e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
-                                   d_column_index, pl->d_col16, pl->d_segblocks, d_count, 1, shift, max_slots);
+                                   d_column_index, pl->d_col16, pl->d_segblocks, d_count, 1, shift, max_slots, take_narrow);
                 e = hipGetLastError();
             }
             std::vector<spmv::SegWinBlock> hb;
