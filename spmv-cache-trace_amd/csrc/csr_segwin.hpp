@@ -111,9 +111,9 @@ __device__ __forceinline__ void sw_load_tile(
     }
 }
 
-template <int TILE>
+template <int TILE, bool PEER>
 __device__ __forceinline__ void sw_compute_tile(
-    const SwTile<TILE / 256> & t, double * prod, const double * win, unsigned wlimit, double * y, int lane)
+    const SwTile<TILE / 256> & t, double * prod, const double * win, unsigned wlimit, double * y, const PeerY & peers, int lane)
 {
     constexpr int QUADS = TILE / 256;
 #pragma unroll
@@ -154,11 +154,11 @@ __device__ __forceinline__ void sw_compute_tile(
         }
     }
     if (sub < t.nrows && part == 0)
-        y[t.r0 + sub] = t.yv + z;
+        y_store<PEER, false>(y, peers, t.r0 + sub, t.yv + z);
     if (t.second) {
         const double zB = tile_row_sum<1>(prod, t.psB - t.kb, t.peB - t.kb, 0, t.maxlen);
         if (lane + kWave < t.nrows)
-            y[t.r0 + lane + kWave] = t.yvB + zB;
+            y_store<PEER, false>(y, peers, t.r0 + lane + kWave, t.yvB + zB);
     }
     // the product slice is reused by this wave's next tile: its reads above come first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -167,11 +167,12 @@ __device__ __forceinline__ void sw_compute_tile(
 }
 
 // W: window slots (doubles) the kernel variant holds; the plan launches the smallest variant its blocks fit.
-template <int TILE, int W>
+// PEER: every row sum is also stored into the other ranks' copies of y (csr_wavetile.hpp, PeerY).
+template <int TILE, int W, bool PEER = false>
 __global__ __launch_bounds__(kSegWinWaves * kWave, (W <= 2688 ? 6 : 4)) void csr_segwin_kernel(
     const int4 * __restrict__ desc, const SegWinBlock * __restrict__ blocks,
     const int32_t * __restrict__ p, const uint16_t * __restrict__ j16, const double * __restrict__ a,
-    const double * __restrict__ x, const double * y_in, double * y)
+    const double * __restrict__ x, const double * y_in, double * y, PeerY peers = PeerY{})
 {
     constexpr int THREADS = kSegWinWaves * kWave;
     constexpr int XS = (W + THREADS - 1) / THREADS; // window slots a thread loads
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kSegWinWaves * kWave, (W <= 2688 ? 6 : 4)) void csr
         const int tn = t + kSegWinWaves;
         if (tn < t_end)
             sw_load_tile<TILE>(nxt, tn, desc, p, j16, a, y_in, lane);
-        sw_compute_tile<TILE>(cur, prod, win, wlimit, y, lane);
+        sw_compute_tile<TILE, PEER>(cur, prod, win, wlimit, y, peers, lane);
         cur = nxt;
         t = tn;
     }

@@ -179,7 +179,15 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
 #endif
             // every tile belongs to the block-window kernel below: nothing for this launch to do
             const bool all_blockwin = c16 && (pl->d_blocks || pl->d_segblocks) && pl->blockwin_tiles == pl->ntiles;
+            // segment-window plans of a one-process-per-GPU operator: the window kernel and the launch over the leftover
+            // tiles both forward their row sums (x below 4 GiB, no split rows: their partial sums meet in atomics)
+            const bool rest_forwards = peers && c16 && x32 && pl->d_segblocks && pl->split_rows == 0 && pl->tile == 512 && !xcd
+                && (pl->blockwin_tiles == pl->ntiles || (pl->d_rest_tiles && pl->nrest_tiles > 0));
             if (all_blockwin) {
+            } else if (rest_forwards) {
+                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, false, true, true>), dim3((unsigned) ((pl->nrest_tiles + 3) / 4)),
+                                   dim3(256), 0, s, pl->nrest_tiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                   spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, *peers, pl->d_rest_tiles);
             } else if (c16 && (pl->d_blocks || pl->d_segblocks) && pl->d_rest_tiles && pl->nrest_tiles > 0 && pl->tile == 512 && !xcd) {
                 // the few tiles a window kernel did not take: a launch over exactly those
                 const dim3 grid((unsigned) ((pl->nrest_tiles + 3) / 4));
@@ -197,8 +205,14 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row
             if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
                 && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
-                hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
-                                   pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
+                if (peers && pl->split_rows == 0 && !pl->d_blocks && !pl->d_segblocks) { // one process per GPU: row sums forwarded (see below)
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256, false, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{},
+                                       (const uint8_t *) nullptr, (const double *) nullptr, 0, *peers);
+                    *fused = 1;
+                } else
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256>), dim3(pl->workgroups), dim3(256), 0, s,
+                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{});
             }
 #ifdef SPMV_HIP_EXPERIMENTS
             else if (abl && c16 && x32 && pl->tile == 512) {
@@ -243,7 +257,15 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             if (c16 && pl->d_segblocks) {
                 // segment windows: one workgroup of 8 waves per block of tiles, the smallest window variant the plan's blocks fit
                 // (2688 doubles + 8 product slices = 53.25 KB: three workgroups per CU; 4096: two)
-                if (pl->segwin_slots <= 2688)
+                if (rest_forwards) { // one process per GPU: both launches of this multiply forward their row sums
+                    if (pl->segwin_slots <= 2688)
+                        hipLaunchKernelGGL((spmv::csr_segwin_kernel<512, 2688, true>), dim3(pl->nsegblocks), dim3(512), 0, s, pl->d_tiles,
+                                           pl->d_segblocks, p, pl->d_col16, a, x, y_in, y, *peers);
+                    else
+                        hipLaunchKernelGGL((spmv::csr_segwin_kernel<512, 4096, true>), dim3(pl->nsegblocks), dim3(512), 0, s, pl->d_tiles,
+                                           pl->d_segblocks, p, pl->d_col16, a, x, y_in, y, *peers);
+                    *fused = 1;
+                } else if (pl->segwin_slots <= 2688)
                     hipLaunchKernelGGL((spmv::csr_segwin_kernel<512, 2688>), dim3(pl->nsegblocks), dim3(512), 0, s, pl->d_tiles,
                                        pl->d_segblocks, p, pl->d_col16, a, x, y_in, y);
                 else

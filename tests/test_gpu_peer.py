@@ -55,11 +55,13 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced):
         want = O.csr_spmv(rows, p, c, v, x, num_threads=2, runs=steps)
         scale = steps * np.bincount(np.repeat(np.arange(rows), np.diff(p)), weights=np.abs(v) * np.abs(x[c]), minlength=rows)
         ok = bool(np.all(np.abs(got - want) <= 1e-10 * np.maximum(scale, np.abs(want)) + 1e-300))
-        # the default kernel forwards its row sums itself; a plan with another kernel (balanced tiles for skewed rows,
-        # block windows, x windows, column panels) pushes the segment with a second launch -- and fused=False always does
+        # the wave-tile kernel (default, value dictionary, x windows) and the segment-window kernel forward their row sums
+        # themselves; the other plans (balanced tiles for skewed rows, the one-ring block window, column panels, split long
+        # rows) push the segment with a second launch -- and fused=False always does
         info = op.plan.info()
-        expect_fused = (fused and world > 1 and not info["balanced"] and info["blockwin_tiles"] == 0 and info["panel_tiles"] == 0
-                        and 2 * info["xwin_tiles"] <= info["row_blocks"])
+        ring_window = info["blockwin_tiles"] > 0 and info["segwin_tiles"] == 0
+        expect_fused = (fused and world > 1 and not info["balanced"] and not ring_window and info["panel_tiles"] == 0
+                        and info["long_blocks"] == 0)
         ok = ok and (op.fused == expect_fused)
         op.zero()
         ok = ok and float(op.y().abs().max().item()) == 0.0
@@ -88,6 +90,8 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced):
     (2, "synthetic:poisson2d:300", True, False),       # value dictionary + lane-per-row tiles, row sums forwarded by the kernel
     (3, "synthetic:poisson2d:300,1", True, False),     # the same without a dictionary, three ranks, a short last block
     (2, "synthetic:queen:20,15,10", True, False),      # narrow tiles, several lanes per row
+    (2, "synthetic:banded:60000,13", True, False),     # shifted tiles with x windows (the XW kernel variant)
+    (2, "synthetic:kkt:44,50", True, False),           # segment windows + the launch over the leftover tiles, both forwarding
     (2, "synthetic:poisson2d:300", False, False),      # pushed by a second launch
     (3, "synthetic:webbase:30000,100000,300,75", True, True),  # skewed rows: balanced tiles (no forwarding variant) + uneven blocks
 ])
