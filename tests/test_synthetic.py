@@ -174,3 +174,46 @@ def test_banded_and_random_families():
     for bad in ("synthetic:banded:10", "synthetic:random:10,11", "synthetic:banded:10,3000"):
         with pytest.raises(hostapi.HostError):
             hostapi.load(bad, "csr")
+
+
+@pytest.mark.parametrize("base,twin", [("synthetic:poisson2d:40", "synthetic:poisson2d:40,1"), ("synthetic:kkt:12", "synthetic:kkt:12,50"),
+                                       ("synthetic:kkt:12", "synthetic:kkt:12,100"), ("synthetic:queen:10,9,8", "synthetic:queen:10,9,8,6")])
+def test_pessimistic_twins_keep_the_shape_and_drop_the_friendly_structure(base, twin):
+    """The "worst plausible" companions of the stand-ins (profiles/r03_results.md): same size and row populations,
+    columns ascending and distinct in every row -- but hashed coefficients (no value dictionary), jittered stencil links
+    (no two rows shifted copies of each other), links moved further (wider clusters)."""
+    A, B = hostapi.load(base), hostapi.load(twin)
+    assert (A.rows, A.cols) == (B.rows, B.cols)
+    _check_sorted_unique(B)
+    assert B.column_index.min() >= 0 and B.column_index.max() < B.cols
+    la, lb = np.diff(A.row_ptr), np.diff(B.row_ptr)
+    if "queen" in base:
+        assert abs(int(lb.sum()) - int(la.sum())) < 0.05 * la.sum()  # jittered links may coincide at mesh borders
+    else:
+        assert np.array_equal(la, lb)  # the same row lengths exactly
+    if "poisson2d" in base:
+        assert np.array_equal(A.column_index, B.column_index)
+        assert len(np.unique(A.value)) == 2 and len(np.unique(B.value)) == len(B.value)
+    else:
+        assert not np.array_equal(A.column_index, B.column_index)
+    if "kkt" in base:  # interior rows are shifted copies in the base, not in the twin
+        def shifted_pairs(M):
+            n, hits = 0, 0
+            for r in range(200, 400):
+                a = M.column_index[M.row_ptr[r]:M.row_ptr[r + 1]]
+                b = M.column_index[M.row_ptr[r + 1]:M.row_ptr[r + 2]]
+                if len(a) == len(b):
+                    n += 1
+                    hits += int(np.array_equal(a + 1, b))
+            return hits / max(1, n)
+        assert shifted_pairs(A) > 0.7 and shifted_pairs(B) < 0.2
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("spec", ["synthetic:poisson2d:9999999999", "synthetic:queen:99999,99999,99999", "synthetic:kkt:99999999999",
+                                  "synthetic:webbase:99999999999", "synthetic:kkt:12,101", "synthetic:queen:10,9,8,2", "synthetic:poisson2d:4,1,1"])
+def test_out_of_range_specs_are_refused_before_any_arithmetic_on_them(spec):
+    """products of numbers parsed from the command line are formed only after each factor has been bounded."""
+    with pytest.raises(hostapi.HostError):
+        hostapi.load(spec)

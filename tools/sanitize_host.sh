@@ -32,4 +32,11 @@ run --threads 2 --csr "$OUT/k.mtx.gz" --profile 1 --expand-symmetric
 run --threads 2 --csr "$G/bus1138_like.mtx__RCM" --profile 1
 run --threads 1 --synthetic queen:5,4,6 --spmv-format csr --profile 1 --x uniform
 run --threads 2 --csr "$G/kat.json" --profile 1
+# the pessimistic twins and the specs whose products used to overflow before the friendly error
+run --threads 1 --synthetic kkt:8,50 --spmv-format csr --profile 1
+run --threads 1 --synthetic queen:5,4,6,6 --spmv-format csr --profile 1
+run --threads 1 --synthetic poisson2d:20,1 --spmv-format csr --profile 1
+run --synthetic poisson2d:9999999999 --spmv-format csr --profile 1
+run --synthetic queen:99999,99999,99999 --spmv-format csr --profile 1
+run --synthetic kkt:99999999999 --spmv-format csr --profile 1
 exit $bad
