@@ -24,6 +24,13 @@ constexpr int kViAblate = SPMV_VI_ABLATE;
 #else
 constexpr int kViAblate = 0;
 #endif
+// A dword at a WAVE-UNIFORM address through the scalar data cache (s_load_dword): the constant address space is how
+// the compiler is told that the load may go there; the data is read-only for the whole launch.
+__device__ __forceinline__ int scalar_load_i32(const int32_t * p)
+{
+    typedef const int32_t __attribute__((address_space(4))) * const_ptr;
+    return *reinterpret_cast<const_ptr>(reinterpret_cast<uintptr_t>(p));
+}
 template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_shifted(
     double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
@@ -80,8 +87,8 @@ __device__ __forceinline__ void tile_products_shifted(
 // tile_products_shifted (lane = four consecutive entries) lands the 64 lanes of every gather on all the
 // diagonals at once, ~35 different 64-byte pieces per instruction.  The counters of the value-dictionary launch
 // (71 M L1 accesses in 143 us: 0.85 per clock and CU, profiles/r02_prof_poisson_csr_vi_summary.md) say that this
-// look-up rate, not memory, was what it ran at.  first_row sits one entry per lane in a register and is
-// broadcast with v_readlane (len <= 64); the tile's index bytes go through the wave's LDS slice (two coalesced
+// look-up rate, not memory, was what it ran at.  first_row is read position by position with scalar loads
+// (wave-uniform address); the tile's index bytes go through the wave's LDS slice (two coalesced
 // dwords per lane in, the row's bytes out); the doubles come from the table and are added left to right from
 // +0.0: the reference's order, bit for bit.  Lanes own a second row 64 further on when the tile has more than 64.
 // A lane per row pays while the tile has rows for at least half the wave: rows of up to 16 entries (32+ rows per 512-entry
@@ -96,7 +103,10 @@ __device__ __forceinline__ void tile_rows_uniform_indexed(
     const uint8_t * __restrict__ vit, ValueLookup vtab, const double * __restrict__ x, int last, int lane,
     int len, int lead, int nrows, bool second, double & zA, double & zB)
 {
-    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
+    // The first row's columns come through the SCALAR data cache (their address is wave-uniform: a pattern record shared by
+    // every interior tile, or the tile's own first row): a scalar-cache hit returns sooner than the vector load from the
+    // L2 that round 2 used (one column per lane, broadcast with v_readlane), and the x gathers below wait for nothing
+    // else -- Poisson 4096^2 with its dictionary 119.3-120.1 -> 113.5-116.2 us in the same process (round 3).
     unsigned * vw = reinterpret_cast<unsigned *>(prod);
     unsigned vi[2];
 #pragma unroll
@@ -115,7 +125,7 @@ __device__ __forceinline__ void tile_rows_uniform_indexed(
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         if (i < len) { // wave-uniform
-            const int c = __builtin_amdgcn_readlane(fr, i);
+            const int c = scalar_load_i32(first_row + i) + first_row_base;
             xa[i] = gather_x<X32>(x, (kViAblate & 1) ? ((c + rowA) & 15) : c + rowA);
             if (second)
                 xb[i] = gather_x<X32>(x, (kViAblate & 1) ? ((c + rowB) & 15) : c + rowB);
@@ -133,7 +143,7 @@ __device__ __forceinline__ void tile_rows_uniform_indexed(
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (p0 + i < len) {
-                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
+                    const int c = scalar_load_i32(first_row + p0 + i) + first_row_base;
                     xa[i] = gather_x<X32>(x, c + rowA);
                     if (second)
                         xb[i] = gather_x<X32>(x, c + rowB);
@@ -160,7 +170,6 @@ __device__ __forceinline__ void tile_rows_uniform_values(
     double * prod, const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
     const double * __restrict__ x, int last, int lane, int len, int lead, int nrows, bool second, double & zA, double & zB)
 {
-    const int fr = first_row[lane < len ? lane : len - 1] + first_row_base;
     TileValues<QUADS, false> vals;
     vals.load(at, nullptr, last, lane);
     const int rowA = lane < nrows ? lane : nrows - 1;
@@ -172,7 +181,7 @@ __device__ __forceinline__ void tile_rows_uniform_values(
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         if (i < len) { // wave-uniform
-            const int c = __builtin_amdgcn_readlane(fr, i);
+            const int c = scalar_load_i32(first_row + i) + first_row_base; // scalar data cache, see tile_rows_uniform_indexed
             xa[i] = gather_x<X32>(x, c + rowA);
             if (second)
                 xb[i] = gather_x<X32>(x, c + rowB);
@@ -197,7 +206,7 @@ __device__ __forceinline__ void tile_rows_uniform_values(
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (p0 + i < len) {
-                    const int c = __builtin_amdgcn_readlane(fr, p0 + i);
+                    const int c = scalar_load_i32(first_row + p0 + i) + first_row_base;
                     xa[i] = gather_x<X32>(x, c + rowA);
                     if (second)
                         xb[i] = gather_x<X32>(x, c + rowB);
