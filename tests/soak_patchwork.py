@@ -87,6 +87,33 @@ def main():
                     ctx.upload_ell(rows, cols, L, ec.ravel(), ev.ravel())
                     ctx.set_x(x); ctx.set_y(y0); ctx.run(2)
                     assert_bitexact(ctx.get_y(), want2, "seed %d ELLPACK L=%d, exact order" % (seed, L))
+            if seed % 4 == 0:
+                # segment windows: a KKT-like matrix with jittered stencils (columns in clusters > 65536 apart), grid size
+                # and jitter varied by the seed; with and without the windows the bits must be the same
+                from spmv_amd import hostapi
+                K = hostapi.load("synthetic:kkt:%d,%d" % (41 + seed % 9, (25, 50, 75, 100)[(seed // 4) % 4]), "csr")
+                kr, kc, kp, kj, kv = K.rows, K.cols, np.array(K.row_ptr), np.array(K.column_index), np.array(K.value)
+                K.close()
+                kx = synth.x_vector(kc, seed=seed + 3)
+                kwant = oracle.csr_spmv(kr, kp, kj, kv, kx, num_threads=4)
+                ktp, ktc, ktv, ktx = (torch.from_numpy(t).to(dev) for t in (kp, kj, kv, kx))
+                got = {}
+                for f in (0, capi.FLAG_NO_SEGMENT_WINDOW | capi.FLAG_NO_COLUMN_PANELS):
+                    plan = capi.CsrPlan(kr, kc, kp, capi.CSR_AUTO, 0, f)
+                    plan.compress(ktc.data_ptr(), stream)
+                    plan.repack(ktp.data_ptr(), ktc.data_ptr(), ktv.data_ptr(), stream)
+                    info = plan.info()
+                    assert (info["segwin_tiles"] > 0.5 * info["row_blocks"]) == (f == 0), info
+                    ty = torch.zeros(kr, dtype=torch.float64, device=dev)
+                    plan.spmv(ktp.data_ptr(), ktc.data_ptr(), ktv.data_ptr(), ktx.data_ptr(), ty.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    got[f] = ty.cpu().numpy()
+                    plan.close()
+                    assert_close(got[f], kwant, abs_products(kr, kp, kj, kv, kx), what="seed %d kkt flags %x" % (seed, f))
+                    checked += 1
+                a, b = got.values()
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "seed %d: segment windows changed bits" % seed
+                del ktp, ktc, ktv, ktx
             os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
             with capi.Context(num_gpus=3, flags=capi.FLAG_PEER_GATHER | capi.FLAG_BALANCE_ENTRIES) as ctx:
                 ctx.upload_csr(rows, cols, p, c, v0)
