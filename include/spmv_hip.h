@@ -90,7 +90,9 @@ extern "C" {
 #define SPMV_HIP_FLAG_BIG_TILE 0x8u     /* wavetile: 1024-entry tiles instead of 512 */
 #define SPMV_HIP_FLAG_VERIFY_PLAN 0x8000u /* spmv_hip_csr_spmv: re-check on EVERY call that the column array still has the
                                              contents the plan was compressed from (one extra pass over it per multiply;
-                                             by default this is checked on the first multiply only, see spmv_hip_plan_verify) */
+                                             by default this is checked on the first multiply only, see spmv_hip_plan_verify).
+                                             On a spmv_hip_create_multi context also: spmv_hip_get_y fetches EVERY device's copy of
+                                             y and returns SPMV_HIP_ERR_STATE unless they are identical bit for bit */
 #define SPMV_HIP_FLAG_NO_BALANCED_TILES 0x40000u /* wavetile: never switch to tiles filled by entries (up to 512 in up to 256
                                              rows, row sums by segmented reduction: csr_segtile_kernel).  By default a matrix
                                              whose row-owned tiles come out less than half full because its rows are skewed

@@ -1,6 +1,10 @@
 // launch.hip -- the multiplies on caller-owned device arrays (Level 2 of include/spmv_hip.h): which kernel variant a
 // plan launches, and the COO / ELLPACK / triad entry points.  Every kernel template is instantiated here.
 #include "internal.hpp"
+#ifdef SPMV_HIP_EXPERIMENTS
+#include "csr_pipe.hpp"
+#include <cstdlib>
+#endif
 
 #include <algorithm>
 
@@ -178,6 +182,17 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             const int abl = (int) ((pl->flags >> 16) & 3); // timing experiments (kernel_sweep.py): wrong results by design
 #endif
             // every tile belongs to the block-window kernel below: nothing for this launch to do
+#ifdef SPMV_HIP_EXPERIMENTS
+            if (const char * pipe = std::getenv("SPMV_HIP_PIPE")) { // timing experiment (csr_pipe.hpp): persistent, software-pipelined narrow tiles
+                const int per_cu = std::max(1, std::atoi(pipe));
+                if (c16 && pl->tile == 512) {
+                    hipLaunchKernelGGL((spmv::csr_pipe_kernel<512>), dim3((unsigned) (cu_count() * per_cu)), dim3(256), 0, s, pl->ntiles, pl->d_tiles, p,
+                                       pl->d_col16, a, x, y_in, y, pl->cols);
+                    HIP_TRY(hipGetLastError());
+                    return SPMV_HIP_OK;
+                }
+            }
+#endif
             const bool all_blockwin = c16 && (pl->d_blocks || pl->d_segblocks) && pl->blockwin_tiles == pl->ntiles;
             // segment-window plans of a one-process-per-GPU operator: the window kernel and the launch over the leftover
             // tiles both forward their row sums (x below 4 GiB, no split rows: their partial sums meet in atomics)

@@ -5,7 +5,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 using namespace spmvi;
@@ -301,6 +303,28 @@ int multi_get_y(spmv_hip_ctx * c, double * y)
                                    part->stream));
     }
     HIP_TRY(hipStreamSynchronize(part->stream));
+    // SPMV_HIP_FLAG_VERIFY_PLAN on a multi-GPU context: after a gather EVERY device must hold the same y.  The other
+    // copies are fetched and compared with device 0's, slot by slot (SPMV_HIP_ERR_STATE names the first that differs).
+    if ((c->flags & SPMV_HIP_FLAG_VERIFY_PLAN) && c->rows > 0) {
+        int rc0 = multi_sync(c);
+        if (rc0 != 0)
+            return rc0;
+        std::vector<double> other((size_t) c->chunk);
+        for (size_t g = 1; g < c->parts.size(); ++g) {
+            HIP_TRY(hipSetDevice(c->parts[g]->device));
+            for (size_t h = 0; h < c->parts.size(); ++h) {
+                const int32_t b = c->row_begin[h], e = c->row_begin[h + 1];
+                if (e <= b)
+                    continue;
+                HIP_TRY(hipMemcpy(other.data(), c->yfull[g] + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost));
+                if (std::memcmp(other.data(), y + b, (size_t) (e - b) * sizeof(double)) != 0) {
+                    char msg[160];
+                    std::snprintf(msg, sizeof msg, "after the gather device %zu's copy of y differs from device 0's in the rows of block %zu", g, h);
+                    return fail(SPMV_HIP_ERR_STATE, msg);
+                }
+            }
+        }
+    }
     return SPMV_HIP_OK;
 }
 

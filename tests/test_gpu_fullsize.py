@@ -378,7 +378,8 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
     os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
     try:
         gflag = capi.FLAG_PEER_GATHER if gather == "push" else capi.FLAG_FUSED_PEER_STORE
-        with capi.Context(num_gpus=parts, flags=gflag | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
+        # VERIFY_PLAN on a multi-GPU context: get_y compares EVERY part's copy of y with part 0's, bit for bit
+        with capi.Context(num_gpus=parts, flags=gflag | capi.FLAG_VERIFY_PLAN | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
             ctx.upload_csr(rows, cols, p, c, v)
             ctx.set_x(x)
             ctx.set_y(y0)
