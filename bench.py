@@ -178,14 +178,16 @@ def host_cores():
     return n
 
 
-def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None, build=None):
+def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None, build=None, kernel_us=None):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_summary.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 + WRITE_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process,
     so the figure is only reported when the summary was taken (a) on the same kernel and workload --
     same algorithmic and streamed bytes -- and (b) with the same device code: the summary's bench
     line carries `build.source_sha256` (hash of csrc/ + include/spmv_hip.h) and it must equal the
-    running library's.  Returns (bytes, file name, lib hash equal too?) or None."""
+    running library's.  A profiled process runs several variants of one kernel template (the timed
+    plan and, e.g., the general-values companion): the variant is told by its average duration,
+    the one closest to `kernel_us`.  Returns (bytes, file name, lib hash equal too?, variant, its avg us) or None."""
     import glob
     best = None
     seq = -1
@@ -202,10 +204,16 @@ def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None, b
             theirs = bl.get("build") or {}
             if not build or not theirs.get("source_sha256") or theirs["source_sha256"] != build.get("source_sha256"):
                 continue  # another binary (or a summary from before the stamp existed): not evidence for this one
-            for k in d["kernels"]:
-                if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k and d.get("sequence", 0) > seq:
-                    seq = d.get("sequence", 0)
-                    best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f), theirs.get("lib_sha256") == build.get("lib_sha256"))
+            if d.get("sequence", 0) <= seq:
+                continue
+            cands = [k for k in d["kernels"] if kernel_name in k["kernel"] and "hbm_traffic_bytes_per_launch" in k and k.get("avg_us")]
+            if not cands:
+                continue
+            k = min(cands, key=lambda q: abs(q["avg_us"] - kernel_us)) if kernel_us else cands[0]
+            if kernel_us and abs(k["avg_us"] - kernel_us) > 0.25 * kernel_us:
+                continue  # no variant of that duration in the profile: not this launch
+            seq = d.get("sequence", 0)
+            best = (k["hbm_traffic_bytes_per_launch"], os.path.basename(f), theirs.get("lib_sha256") == build.get("lib_sha256"), k["kernel"], k["avg_us"])
         except (OSError, ValueError, KeyError):
             continue
     return best
@@ -814,13 +822,17 @@ def main():
             if not gather_check["pass"]:
                 code, message = 1, "bench.py: gathered y does not match the owning rank's rows"
         out["build"] = build
-        tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build)
+        tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build, kern_s * 1e6)
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_over_bytes"] = round(tr[0] / max(1, int(streamed)), 3)
-            out["roofline"]["traffic_source"] = ("profiles/%s (rocprofv3 PMC passes of the same command on the same device code: "
-                                                 "source_sha256 %s matches%s)" % (tr[1], build["source_sha256"],
-                                                                                  "" if tr[2] else "; the .so was rebuilt from it since"))
+            out["roofline"]["traffic_source"] = ("profiles/%s, kernel %s (%.1f us average under rocprofv3; PMC passes of the same command on the "
+                                                 "same device code: source_sha256 %s matches%s)" % (tr[1], tr[3], tr[4], build["source_sha256"],
+                                                                                                    "" if tr[2] else "; the .so was rebuilt from it since"))
+            if general is not None:  # the companion launch was profiled in the same process
+                tg = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build, general["kernel_us"])
+                if tg and tg[3] != tr[3]:
+                    general["traffic"] = tg[0]
         else:
             out["roofline"]["traffic_source"] = ("none: no committed profiles/*_summary.json of this workload was taken with device "
                                                  "sources %s" % build["source_sha256"])
