@@ -15,14 +15,25 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 template <int MODE> // 0: values only; 1: + columns as 2 x 8 B per lane; 2: + columns as 1 x 16 B per lane; 3: + columns as 32-bit (2 x 16 B)
+                    // 4: like 1, but where the tile starts comes out of a 16-byte descriptor first (a dependent scalar load, as in the real kernel)
+                    // 5: like 4, plus y read and written (8 rows per tile) and the products parked in LDS and read back once
 __global__ __launch_bounds__(256, 8) void tile_stream_kernel(long long ntiles, const double * __restrict__ a, const uint16_t * __restrict__ j16,
-                                                              const int32_t * __restrict__ j32, double * out)
+                                                              const int32_t * __restrict__ j32, double * out, const int4 * __restrict__ desc = nullptr,
+                                                              double * y = nullptr)
 {
-    const long long w = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double prod_all[4][516];
+    long long w = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= ntiles)
         return;
     const int lane = threadIdx.x & 63;
+    if (MODE >= 4) {
+        const int4 d0 = desc[w], d1 = desc[w + 1];
+        w = __builtin_amdgcn_readfirstlane(d0.y) / 512 + (__builtin_amdgcn_readfirstlane(d1.y) & 0); // = w, but only known once the loads are back
+    }
     const double * at = a + w * 512;
+    double yv = 0.0;
+    if (MODE == 5)
+        yv = y[w * 8 + (lane >> 3)];
     v2d va[2], vb[2];
     unsigned acc = 0;
 #pragma unroll
@@ -30,7 +41,7 @@ __global__ __launch_bounds__(256, 8) void tile_stream_kernel(long long ntiles, c
         const int o = 256 * q + 4 * lane;
         va[q] = *reinterpret_cast<const v2d *>(at + o);
         vb[q] = *reinterpret_cast<const v2d *>(at + o + 2);
-        if (MODE == 1) {
+        if (MODE == 1 || MODE >= 4) {
             const v2u c = *reinterpret_cast<const v2u *>(j16 + w * 512 + o);
             acc += c.x ^ c.y;
         }
@@ -43,7 +54,25 @@ __global__ __launch_bounds__(256, 8) void tile_stream_kernel(long long ntiles, c
         const v4u c = *reinterpret_cast<const v4u *>(j16 + w * 512 + 8 * lane);
         acc += c.x ^ c.y ^ c.z ^ c.w;
     }
-    const double s = va[0].x + va[0].y + vb[0].x + vb[0].y + va[1].x + va[1].y + vb[1].x + vb[1].y + (double) acc;
+    double s = va[0].x + va[0].y + vb[0].x + vb[0].y + va[1].x + va[1].y + vb[1].x + vb[1].y + (double) acc;
+    if (MODE == 5) {
+        double * prod = prod_all[threadIdx.x >> 6];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            v2d * dst = reinterpret_cast<v2d *>(prod + 256 * q + 4 * lane);
+            dst[0] = va[q];
+            dst[1] = vb[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double z = 0.0;
+        for (int t = 0; t < 8; ++t)
+            z += prod[(lane >> 3) * 64 + (lane & 7) + 8 * t];
+        if ((lane & 7) == 0)
+            y[w * 8 + (lane >> 3)] = yv + z;
+        s += z;
+    }
     if (s == 1.2345e300)
         out[blockIdx.x] = s; // keeps the loads alive, never taken
 }
@@ -93,6 +122,21 @@ int main()
     us[1] = time_us([&] { hipLaunchKernelGGL(tile_stream_kernel<1>, dim3(grid), dim3(256), 0, 0, ntiles, a, j16, j32, out); }, 10);
     us[2] = time_us([&] { hipLaunchKernelGGL(tile_stream_kernel<2>, dim3(grid), dim3(256), 0, 0, ntiles, a, j16, j32, out); }, 10);
     us[3] = time_us([&] { hipLaunchKernelGGL(tile_stream_kernel<3>, dim3(grid), dim3(256), 0, 0, ntiles, a, j16, j32, out); }, 10);
+    {
+        int4 * desc;
+        double * y;
+        CHECK(hipMalloc((void **) &desc, (ntiles + 1) * sizeof(int4)));
+        CHECK(hipMalloc((void **) &y, ntiles * 8 * sizeof(double)));
+        CHECK(hipMemset(y, 0, ntiles * 8 * sizeof(double)));
+        int4 * h = (int4 *) std::malloc((ntiles + 1) * sizeof(int4));
+        for (long long t = 0; t <= ntiles; ++t)
+            h[t] = make_int4((int) (t * 8), (int) (t * 512), 0, 0);
+        CHECK(hipMemcpy(desc, h, (ntiles + 1) * sizeof(int4), hipMemcpyHostToDevice));
+        const double u4 = time_us([&] { hipLaunchKernelGGL(tile_stream_kernel<4>, dim3(grid), dim3(256), 0, 0, ntiles, a, j16, j32, out, desc, y); }, 10);
+        const double u5 = time_us([&] { hipLaunchKernelGGL(tile_stream_kernel<5>, dim3(grid), dim3(256), 0, 0, ntiles, a, j16, j32, out, desc, y); }, 10);
+        std::printf("%-62s %8.1f us  %7.1f GB/s\n", "values + 16-bit columns behind a 16-byte descriptor load", u4, (10.0 * n + 16.0 * ntiles) / u4 / 1e3);
+        std::printf("%-62s %8.1f us  %7.1f GB/s\n", "... + y read / written, products through LDS, 8-lane sums", u5, (10.0 * n + 16.0 * ntiles + 128.0 * ntiles) / u5 / 1e3);
+    }
     for (int m = 0; m < 4; ++m)
         std::printf("%-62s %8.1f us  %7.1f GB/s\n", what[m], us[m], bytes[m] / us[m] / 1e3);
     return 0;
