@@ -55,6 +55,27 @@ def test_plan_argument_validation_needs_no_device():
     assert lib.spmv_hip_ell_spmv(70000, 40000, None, None, None, None, None) == capi.ERR_OVERFLOW
 
 
+def test_peer_entry_points_validate_their_arguments_without_a_device():
+    """The one-process-per-GPU entry points (spmv_hip_ipc_*, spmv_hip_peer_push, spmv_hip_csr_spmv_out_peers) refuse bad
+    arguments with a code before they touch HIP -- and, like everything else, never fall back to anything on a box
+    without a GPU."""
+    lib = capi.load()
+    p = C.c_void_p()
+    assert lib.spmv_hip_ipc_alloc(C.byref(p), 0, C.create_string_buffer(64)) == capi.ERR_INVALID  # zero bytes
+    assert lib.spmv_hip_ipc_alloc(None, 64, C.create_string_buffer(64)) == capi.ERR_INVALID
+    assert lib.spmv_hip_ipc_open(None, C.byref(p)) == capi.ERR_INVALID
+    assert lib.spmv_hip_ipc_close(None) == 0 and lib.spmv_hip_ipc_free(None) == 0  # nothing to close / free
+    assert lib.spmv_hip_peer_push(None, None, -1, 8, None) == capi.ERR_INVALID
+    assert lib.spmv_hip_peer_push(None, None, 0, 8, None) == 0  # no peers: nothing to do
+    assert lib.spmv_hip_peer_push(None, None, 2, 8, None) == capi.ERR_INVALID  # peers but no pointers
+    fused = C.c_int(7)
+    assert lib.spmv_hip_csr_spmv_out_peers(None, None, None, None, None, None, None, None, 3, C.byref(fused), None) == capi.ERR_INVALID
+    assert lib.spmv_hip_csr_spmv_out_peers(None, None, None, None, None, None, None, None, 0, C.byref(fused), None) == capi.ERR_INVALID  # null plan
+    if capi.device_count() == 0:
+        assert lib.spmv_hip_ipc_alloc(C.byref(p), 4096, C.create_string_buffer(64)) in (capi.ERR_NO_DEVICE, capi.ERR_HIP)
+        assert not p.value
+
+
 def test_no_gpu_means_failure_not_fallback():
     if capi.device_count() > 0:
         pytest.skip("a GPU is present; this test covers the no-device behaviour")
