@@ -94,6 +94,9 @@ def parse_args():
                          "the multiply kernel stores its row sums into every rank's vector (inter-process device memory); "
                          "peer-push = the multiply, then one kernel that pushes the segment; auto (default) = time a few steps "
                          "of each scheme that can be set up and take the fastest")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the companion measurement of BASELINE configs[3] (the nlpkkt200-like KKT matrix, the configuration "
+                         "BASELINE.json partitions over 8 GPUs) that the default workload's line carries as `config3_kkt`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N > 1 on a box with one GPU")
     ap.add_argument("--share-gpu", action="store_true",
@@ -731,6 +734,63 @@ def main():
         deferred = {"steps": args.steps, "all_gathers": 1, "ms_total": round(dt.item() * 1e3, 4),
                     "gflops": round(2.0 * nnz * args.steps / dt.item() / 1e9, 2)}
 
+    # ---- companion: BASELINE configs[3] on the same ranks ----------------------------------------------------------------
+    # The headline workload (configs[1], Poisson: 5 entries per row) cannot scale strongly with a replicated y; the
+    # configuration BASELINE.json partitions over 8 GPUs is nlpkkt200 (27 entries per row).  So that a run at N = 1, 2, 4, 8
+    # also says what THAT matrix does on the same ranks with the same gather scheme, the default line carries a short
+    # measurement of its stand-in (10 timed steps after 3 warm-up steps; never part of `value`).
+    config3 = None
+    if fmt == "csr" and args.matrix is None and args.workload == "poisson2d" and args.grid == 4096 and not args.no_config3:
+        import argparse as _ap
+        a3 = _ap.Namespace(**vars(args))
+        a3.matrix, a3.expand_symmetric, a3.partition = "synthetic:kkt:200", False, "rows"
+        t3 = time.perf_counter()
+        rows3, cols3, nnz3, p3, c3, v3, b3, e3, _, keep3 = load_csr(a3, rank, world)
+        if nnz3 is None:
+            tt = torch.tensor([float(p3[-1])], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt)
+            nnz3 = int(tt.item())
+        x3 = synth.x_vector(cols3, "uniform", seed=12345)
+        scheme3 = chosen if (use_dist and schemes is not None) else None
+        if scheme3 in ("peer-fused", "peer-push"):
+            from spmv_amd.peer import PeerCsrSpmv
+            op3 = PeerCsrSpmv.on_gpu(rows3, cols3, rank, world, device, p3, c3, v3, x3, algo, args.lanes, flags, fused=(scheme3 == "peer-fused"))
+        else:
+            op3 = DistributedCsrSpmv.on_gpu(rows3, cols3, rank, world, device, p3, c3, v3, x3, algo, args.lanes, flags,
+                                            overlap=use_dist and not args.no_overlap)
+
+        def steps3(n):
+            for _ in range(n):
+                op3.multiply_local()
+                if use_dist and op3.collective:
+                    op3.gather_async() if op3.overlap else op3.gather()
+            op3.finish()
+        steps3(3)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        c0 = time.perf_counter()
+        steps3(10)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el3 = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+        i3 = op3.plan.info()
+        config3 = {"workload": "kkt-27pt-200^3 (nlpkkt200-like), csr, %s" % ("rows/%d static chunks" % world if use_dist else "single GPU"),
+                   "rows": rows3, "nnz": nnz3, "steps": 10, "warmup": 3, "gather": scheme3 or ("rccl" if use_dist else None),
+                   "ms_per_step": round(el3.item() / 10 * 1e3, 5), "gflops": round(2.0 * nnz3 * 10 / el3.item() / 1e9, 2),
+                   "frac_algorithmic_whole_step": round(synth.csr_bytes(rows3, cols3, nnz3) / (el3.item() / 10) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                   "local_tiles": i3["row_blocks"], "local_shifted_tiles": i3["shifted_tiles"], "local_x_window_tiles": i3["xwin_tiles"],
+                   "setup_s": round(time.perf_counter() - t3 - el3.item(), 1),
+                   "note": "whole-job GFLOP/s of BASELINE configs[3]'s stand-in on these ranks; parity of this matrix and path: "
+                           "tests/test_gpu_fullsize.py, tests/test_gpu_peer.py"}
+        if not op3.collective:
+            op3.close()
+        del op3, keep3, p3, c3, v3
+        torch.cuda.empty_cache()
+
     code, message = 0, None
     if rank == 0:
         from spmv_amd import buildinfo
@@ -817,6 +877,8 @@ def main():
                                 "note": "all_gather_us: blocking collective alone, median of 5 after the timed region; schemes: t_total = a "
                                         "whole step (max over ranks) timed before the warm-up, `gather` = the one the timed region ran",
                                 "one_all_gather_after_the_k_multiplies": deferred}
+        if config3 is not None:
+            out["config3_kkt"] = config3
         if gather_check:
             out["gather_check"] = gather_check
             if not gather_check["pass"]:
