@@ -30,16 +30,27 @@ def one(spec, sched, events):
         ctx.set_x(synth.x_vector(A.cols))
         ctx.run(20)
         run, sync, h = lib.spmv_hip_run, lib.spmv_hip_sync, ctx.h
+        poll = os.environ.get("SYNC_PROBE_POLL") == "1"
+        if poll:  # the caller's own stream, polled with hipStreamQuery instead of a blocking hipStreamSynchronize
+            st = C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(st), C.c_uint(1)) == 0
+            ctx.set_stream(st.value)
+            hip.hipStreamQuery.argtypes = [C.c_void_p]
+            query = hip.hipStreamQuery
         t = []
         for _ in range(300):
             t0 = time.perf_counter_ns()
             run(h)
-            sync(h)
+            if poll:
+                while query(st) != 0:
+                    pass
+            else:
+                sync(h)
             t.append(time.perf_counter_ns() - t0)
         t = np.sort(np.array(t)) / 1e3
         dev = ctx.last_run_ns() / 1e3 if events else float("nan")
-        print("%-28s sched %-8s events %d   wall median %7.1f us  min %7.1f  p90 %7.1f   device %7.1f us" % (
-            spec[10:], sched, events, t[len(t) // 2], t[0], t[int(len(t) * 0.9)], dev), flush=True)
+        print("%-28s sched %-8s events %d %s  wall median %7.1f us  min %7.1f  p90 %7.1f   device %7.1f us" % (
+            spec[10:], sched, events, "poll" if poll else "sync", t[len(t) // 2], t[0], t[int(len(t) * 0.9)], dev), flush=True)
 
 
 if __name__ == "__main__":
