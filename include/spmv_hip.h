@@ -154,8 +154,9 @@ void spmv_hip_destroy(spmv_hip_ctx *ctx);
  * and then assembles y everywhere with ONE in-place ncclAllGather (RCCL over xGMI) issued for all
  * devices inside a group call; spmv_hip_sync waits for all of them; spmv_hip_get_y reads device 0's y.
  * spmv_hip_upload_ell cuts the row-major ELLPACK arrays into the same row blocks, spmv_hip_upload_coo deals the
- * triplets (any order) to the blocks of their rows by a stable pass and rebases the row indices; a
- * hybrid upload returns SPMV_HIP_ERR_STATE.  spmv_hip_set_stream is refused.  librccl.so is loaded at run time, and only when num_gpus > 1 (or SPMV_HIP_FORCE_RCCL=1
+ * triplets (any order) to the blocks of their rows by a stable pass and rebases the row indices;
+ * spmv_hip_upload_hybrid does both (ELLPACK part by rows, remainder dealt to the blocks) and every device merges its two
+ * parts into one row-major matrix like a single-device hybrid upload.  spmv_hip_set_stream is refused.  librccl.so is loaded at run time, and only when num_gpus > 1 (or SPMV_HIP_FORCE_RCCL=1
  * is set, which runs the collective with one device too); num_gpus = 1 is an ordinary context with
  * the same calling sequence.
  * With SPMV_HIP_FLAG_PEER_GATHER the gather is done without RCCL: every device pushes its slot into the other

@@ -458,7 +458,8 @@ int spmv_hip_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t
     if (!c)
         return fail(SPMV_HIP_ERR_INVALID, "ctx is null");
     if (c->multi)
-        return fail(SPMV_HIP_ERR_STATE, "a multi-GPU context takes CSR, COO or ELLPACK (row blocks: src/matrix/csr-matrix.cpp:77-95)");
+        return multi_upload_hybrid(c, rows, cols, ell_row_length, ell_column_index, ell_value, num_coo_entries, coo_row_index, coo_column_index,
+                                   coo_value);
     if (num_coo_entries < 0 || (num_coo_entries > 0 && (!coo_row_index || !coo_column_index || !coo_value)))
         return fail(SPMV_HIP_ERR_INVALID, "bad hybrid COO arguments");
     // the ELL part is uploaded (validated) exactly like a plain ELLPACK matrix ...

@@ -194,6 +194,8 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
 int multi_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length, const int32_t * column_index, const double * value);
 int multi_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, const int32_t * row_index, const int32_t * column_index,
                      const double * value);
+int multi_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length, const int32_t * ell_col, const double * ell_val,
+                        int32_t ncoo, const int32_t * coo_row, const int32_t * coo_col, const double * coo_val);
 int multi_set_x(spmv_hip_ctx * c, const double * x);
 int multi_set_y(spmv_hip_ctx * c, const double * y);
 int multi_get_y(spmv_hip_ctx * c, double * y);

@@ -194,6 +194,67 @@ int multi_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_l
     return SPMV_HIP_OK;
 }
 
+// Hybrid ELLPACK + COO across the devices: the ELLPACK part is cut by rows like a plain ELLPACK matrix, the remainder's
+// triplets are dealt to the blocks of their rows (stably: a row keeps its remainder in file order), and every device
+// merges its two parts into one row-major matrix exactly like a single-device hybrid upload (spmv_hip_upload_hybrid).
+int multi_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_length, const int32_t * ell_col, const double * ell_val,
+                        int32_t ncoo, const int32_t * coo_row, const int32_t * coo_col, const double * coo_val)
+{
+    if (rows < 0 || cols < 0 || row_length < 0 || ncoo < 0 || ((long long) rows * row_length > 0 && (!ell_col || !ell_val))
+        || (ncoo > 0 && (!coo_row || !coo_col || !coo_val)))
+        return fail(SPMV_HIP_ERR_INVALID, "bad hybrid arguments");
+    if ((long long) rows * row_length > INT32_MAX)
+        return fail(SPMV_HIP_ERR_OVERFLOW, "Integer overflow when computing number of non-zeros");
+    for (int32_t k = 0; k < ncoo; ++k)
+        if (coo_row[k] < 0 || coo_row[k] >= rows)
+            return fail(SPMV_HIP_ERR_INVALID, "row or column index out of range");
+    std::vector<long long> before;
+    if (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) { // stored entries in front of every row: its ELLPACK slots + its remainder
+        before.assign((size_t) rows + 1, 0);
+        for (int32_t k = 0; k < ncoo; ++k)
+            ++before[(size_t) coo_row[k] + 1];
+        for (int32_t r = 0; r < rows; ++r)
+            before[(size_t) r + 1] += before[(size_t) r] + row_length;
+    }
+    int rc = multi_layout(c, rows, before.empty() ? nullptr : before.data());
+    if (rc != 0)
+        return multi_upload_failed(c, rc);
+    const size_t G = c->parts.size();
+    std::vector<uint8_t> block_of_row((size_t) rows);
+    for (size_t g = 0; g < G; ++g)
+        for (int32_t r = c->row_begin[g]; r < c->row_begin[g + 1]; ++r)
+            block_of_row[(size_t) r] = (uint8_t) g;
+    std::vector<size_t> start(G + 1, 0);
+    for (int32_t k = 0; k < ncoo; ++k)
+        ++start[(size_t) block_of_row[(size_t) coo_row[k]] + 1];
+    for (size_t g = 0; g < G; ++g)
+        start[g + 1] += start[g];
+    std::vector<int32_t> ri((size_t) ncoo), ci((size_t) ncoo);
+    std::vector<double> va((size_t) ncoo);
+    std::vector<size_t> fill(start.begin(), start.end() - 1);
+    for (int32_t k = 0; k < ncoo; ++k) {
+        const size_t g = block_of_row[(size_t) coo_row[k]];
+        const size_t at = fill[g]++;
+        ri[at] = coo_row[k] - c->row_begin[g];
+        ci[at] = coo_col[k];
+        va[at] = coo_val[k];
+    }
+    for (size_t g = 0; g < G; ++g) {
+        const int32_t b = c->row_begin[g], e = c->row_begin[g + 1];
+        const size_t eoff = (size_t) b * (size_t) row_length, off = start[g], cnt = start[g + 1] - start[g];
+        rc = spmv_hip_upload_hybrid(c->parts[g], e - b, cols, row_length, ell_col ? ell_col + eoff : nullptr, ell_val ? ell_val + eoff : nullptr,
+                                    (int32_t) cnt, cnt ? ri.data() + off : nullptr, cnt ? ci.data() + off : nullptr, cnt ? va.data() + off : nullptr);
+        if (rc != 0)
+            return multi_upload_failed(c, rc);
+    }
+    c->rows = rows;
+    c->cols = cols;
+    c->nnz = (int32_t) ((long long) rows * row_length);
+    c->nnz2 = ncoo;
+    c->format = 4;
+    return SPMV_HIP_OK;
+}
+
 // COO across the devices ("split the row-sorted stream at row boundaries"): the triplets may come in any
 // order (file order: src/matrix/coo-matrix.cpp:220-243); they are dealt to the row blocks by a stable counting pass --
 // every device gets its rows' triplets in their original relative order, row indices rebased to the block -- and

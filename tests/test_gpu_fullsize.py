@@ -400,7 +400,8 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
         os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
 
 
-@pytest.mark.parametrize("fmt,parts,balance", [("coo", 3, False), ("coo", 8, True), ("ell", 2, False), ("ell", 5, False)])
+@pytest.mark.parametrize("fmt,parts,balance", [("coo", 3, False), ("coo", 8, True), ("ell", 2, False), ("ell", 5, False),
+                                               ("hybrid", 3, False), ("hybrid", 4, True)])
 def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
     """COO and ELLPACK through spmv_hip_create_multi (SURVEY 8e: "COO: split the row-sorted stream at row boundaries;
     ELL: row range"), rehearsed with every block on this box's one device: the triplets come shuffled, are dealt to
@@ -408,7 +409,7 @@ def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
     matrix, two accumulating runs from a given y."""
     import os
     rng = np.random.default_rng(5)
-    if fmt == "coo":
+    if fmt in ("coo", "hybrid"):
         rows, cols, p, c, v = synth.powerlaw(20011, 20011, seed=21)
         i, j, a = synth.csr_to_coordinate(rows, p, c, v)
         perm = rng.permutation(len(a))
@@ -424,6 +425,11 @@ def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
         with capi.Context(num_gpus=parts, flags=capi.FLAG_PEER_GATHER | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
             if fmt == "coo":
                 ctx.upload_coo(rows, cols, i, j, a)
+            elif fmt == "hybrid":
+                # the reference's hybrid converter (src/matrix/hybrid-matrix.cpp:316-417) on the whole matrix; the context cuts
+                # the ELLPACK part by rows, deals the remainder to the blocks of its rows, and every part merges its two
+                H = oracle.hybrid_from_coordinate(rows, i + 1, j + 1, a)
+                ctx.upload_hybrid(rows, cols, H["row_length"], H["ell_col"], H["ell_val"], H["coo_row"], H["coo_col"], H["coo_val"])
             else:
                 # row-major ELLPACK like ell_matrix::from_matrix_market (src/matrix/ell-matrix.cpp:190-238): zero
                 # padding whose column repeats the row's last real one
@@ -444,7 +450,7 @@ def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
             ctx.run(2)
             assert_close(ctx.get_y(), want, scale, what="%s over %d blocks" % (fmt, parts))
             info = ctx.info()
-            assert info["devices"] == parts and info["format"] == (2 if fmt == "coo" else 3) and info["rows"] == rows
+            assert info["devices"] == parts and info["format"] == {"coo": 2, "ell": 3, "hybrid": 4}[fmt] and info["rows"] == rows
             with pytest.raises(capi.SpmvHipError) as e:  # a bad row index is refused before anything is dealt
                 ctx.upload_coo(rows, cols, np.array([rows], dtype=np.int32), np.array([0], dtype=np.int32), np.array([1.0]))
             assert e.value.code == capi.ERR_INVALID
