@@ -6,7 +6,8 @@ first one's.
     python tools/ab.py --matrix synthetic:queen  base=0  nowin=0x800  "tiles16=0;SPMV_HIP_SEGWIN_TILES=16"
 
 A variant is NAME=FLAGS[;ENV=VALUE...]; the environment entries are set while its plan is built
-(libspmv_hip_experiments.so reads them at plan time; the product library ignores them).
+(libspmv_hip_experiments.so reads them at plan time; the product library ignores them).  The pseudo entry
+OUT=1 times the variant as y_out = y_in + A x between two vectors that swap after every launch.
 """
 import argparse
 import json
@@ -42,11 +43,14 @@ def main():
     tx = torch.from_numpy(synth.x_vector(cols, "uniform", seed=12345)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
     plans, ys = {}, {}
+    out_of_place = set()
     for spec in args.variants:
         name, rest = spec.split("=", 1)
         parts = rest.split(";")
         flags = int(parts[0], 0)
         env = dict(e.split("=", 1) for e in parts[1:])
+        if env.pop("OUT", None):  # y_out = y_in + A x into a second vector, the two swapped after every launch
+            out_of_place.add(name)
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
@@ -66,13 +70,20 @@ def main():
         ys[name] = ty.cpu().numpy()
         del ty
     ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+    ty2 = torch.zeros(rows, dtype=torch.float64, device=dev) if out_of_place else None
     times = {k: [] for k in plans}
     for rnd in range(args.rounds + 1):
         for k, plan in plans.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.reps):
-                plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            if k in out_of_place:
+                a, b = ty.data_ptr(), ty2.data_ptr()
+                for _ in range(args.reps):
+                    plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), a, b, stream)
+                    a, b = b, a
+            else:
+                for _ in range(args.reps):
+                    plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
