@@ -46,6 +46,19 @@ __global__ void reference_kernel(long long n, long long chunk_len, int nwg, int 
     }
 }
 
+// what scattered fp64 atomic adds into global memory cost (x-stationary alternative: x slice in LDS, y by global atomics):
+// GATHER false: x is not read at all
+template <bool GATHER>
+__global__ __launch_bounds__(256) void atomics_kernel(long long n, long long chunk_len, int nwg, int rows_per_wg, const int32_t * col, const double * val,
+                                                       const uint16_t * rowoff, const double * x, double * y)
+{
+    for (long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long) gridDim.x * blockDim.x) {
+        // rows scattered over the whole of y: the workgroup block from the column hash instead of the entry's place
+        const long long g = GATHER ? (k / chunk_len) % nwg : (long long) ((unsigned) col[k] * 2654435761u % (unsigned) nwg);
+        unsafeAtomicAdd(y + g * rows_per_wg + rowoff[k], GATHER ? val[k] * x[col[k]] : val[k]);
+    }
+}
+
 // MODE 0: as described; 1: no gather (x[lane]); 2: no LDS atomics (plain sum into a register); 3: streams only
 template <int THREADS, int MODE>
 __global__ __launch_bounds__(THREADS) void ystat_kernel(int nwg, int npanels, int rows_per_wg, long long chunk_len, const int32_t * __restrict__ col,
@@ -171,6 +184,27 @@ int main(int argc, char ** argv)
             scale = std::fmax(scale, std::fabs(hr[(size_t) i]));
         }
         std::printf("%d panels of %lld KB of x: max |y - y_ref| / max |y_ref| = %.2e\n", npanels, width * 8 / 1024, worst / scale);
+        if (variant == 0) {
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            float ms;
+            hipLaunchKernelGGL(atomics_kernel<false>, dim3(8192), dim3(256), 0, 0, n, chunk_len, nwg, rows_per_wg, col, val, rowoff, x, yref);
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < 3; ++i)
+                hipLaunchKernelGGL(atomics_kernel<false>, dim3(8192), dim3(256), 0, 0, n, chunk_len, nwg, rows_per_wg, col, val, rowoff, x, yref);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::printf("global fp64 atomic adds, rows scattered over all of y, no x:        %9.1f us for %lld entries = %.1f G/s\n", ms * 1e3 / 3, n, n / (ms * 1e3 / 3) / 1e3);
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < 3; ++i)
+                hipLaunchKernelGGL(atomics_kernel<true>, dim3(8192), dim3(256), 0, 0, n, chunk_len, nwg, rows_per_wg, col, val, rowoff, x, yref);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::printf("global gather + global atomic add, rows within one 16 K block at a time: %9.1f us = %.1f G/s\n", ms * 1e3 / 3, n / (ms * 1e3 / 3) / 1e3);
+        }
         run<1024, 0>("y in LDS, x from L2, LDS atomics", nwg, npanels, rows_per_wg, chunk_len, col, val, rowoff, x, y, reps);
         run<1024, 3>("  streams only", nwg, npanels, rows_per_wg, chunk_len, col, val, rowoff, x, y, reps);
     }
