@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
     double * prod = prod_all[wave];
     uint16_t * rowat = rowat_all[wave];
 
-    const int4 d0 = desc[w];
-    const int4 d1 = desc[w + 1];
+    const TilePair dp = load_tile_pair(desc, w);
+    const int4 d0 = dp.d0, d1 = dp.d1;
     const int r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int partial = __builtin_amdgcn_readfirstlane(d0.x & kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);

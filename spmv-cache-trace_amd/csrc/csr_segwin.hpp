@@ -62,8 +62,8 @@ __device__ __forceinline__ void sw_load_tile(
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     constexpr int QUADS = TILE / 256;
-    const int4 d0 = desc[w];
-    const int4 d1 = desc[w + 1];
+    const TilePair dp = load_tile_pair(desc, w);
+    const int4 d0 = dp.d0, d1 = dp.d1;
     const int meta = __builtin_amdgcn_readfirstlane(d0.z);
     t.r0 = __builtin_amdgcn_readfirstlane(d0.x & ~kTileFlagPartial);
     const int k0 = __builtin_amdgcn_readfirstlane(d0.y);

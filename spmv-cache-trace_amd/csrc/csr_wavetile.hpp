@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
 
     // (VI: waves past the last tile read its descriptor and leave after the table barrier)
     const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
-    const int4 d0 = desc[wd];
-    const int4 d1 = desc[wd + 1];
+    const TilePair dp = load_tile_pair(desc, wd);
+    const int4 d0 = dp.d0, d1 = dp.d1;
     ValueLookup vtab{vtab_lds, false, 0.0, 0.0};
     if (VI) {
         vtab.tiny = nvalues <= 2; // kernel-uniform

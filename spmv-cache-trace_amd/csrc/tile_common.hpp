@@ -103,6 +103,25 @@ constexpr int kMaxPatterns = 64;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// A tile's descriptor and its successor's (row / entry bounds come from the pair) at a WAVE-UNIFORM index through the
+// scalar data cache, eight dwords at once: the constant address space tells the compiler that the load may go there (the
+// descriptors are read-only for the whole launch).  As `desc[w]`, `desc[w + 1]` the compiler issued VECTOR loads and, in the
+// kernels with an early exit between the uses of the two, fetched the pair in two dependent round trips (round 3:
+// tools/wave_trace.py showed 1.55 us of a 4.9 us wave lifetime waiting for the descriptor).
+struct TilePair {
+    int4 d0, d1;
+};
+__device__ __forceinline__ TilePair load_tile_pair(const int4 * __restrict__ desc, int w)
+{
+    typedef int v8i_a16 __attribute__((ext_vector_type(8), aligned(16)));
+    typedef const v8i_a16 __attribute__((address_space(4))) * const_ptr;
+    const v8i_a16 v = *reinterpret_cast<const_ptr>(reinterpret_cast<uintptr_t>(desc + w));
+    TilePair t;
+    t.d0 = make_int4(v[0], v[1], v[2], v[3]);
+    t.d1 = make_int4(v[4], v[5], v[6], v[7]);
+    return t;
+}
+
 template <typename T, bool NT>
 __device__ __forceinline__ T stream_load(const T * ptr)
 {
