@@ -816,7 +816,8 @@ def main():
                            "tiles_with_16bit_columns": info["narrow_tiles"], "uniform_tiles": info["uniform_tiles"],
                            "shifted_tiles": info["shifted_tiles"], "tiles_with_x_window": info["xwin_tiles"],
                            "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"],
-                           "balanced_tiles": bool(info["balanced"]), "value_dictionary_size": info["indexed_values"]})
+                           "balanced_tiles": bool(info["balanced"]), "value_dictionary_size": info["indexed_values"],
+                           "tiles_reading_no_value_stream": info.get("value_row_tiles", 0)})
         else:
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],

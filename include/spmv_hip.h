@@ -290,7 +290,8 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, cons
  * the stored entries: pattern / graph matrices, constant-coefficient stencils, meshes of identical
  * elements): the plan keeps the distinct values in a table and one BYTE per entry saying which, and the
  * default kernel then streams 1 instead of 8 bytes of value per entry, taking the double itself from the
- * table -- the stored bits, so y is unchanged bit for bit.  Does nothing (returns 0, plan_info[20] == 0)
+ * table -- the stored bits, so y is unchanged bit for bit.  Stencil tiles whose rows all carry the first row's values
+ * (plan_info[23]) read those few bytes only.  Does nothing (returns 0, plan_info[20] == 0)
  * when the matrix has more distinct values or the plan uses another kernel.  BY CALLING THIS THE CALLER
  * PROMISES that d_value keeps its contents while the plan lives, or that
  * spmv_hip_plan_csr_refresh_values follows every change; the promise is checked like the one for the
@@ -322,7 +323,9 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES)
  *        [20] size of the value dictionary (0 = none; see spmv_hip_plan_csr_index_values)
  *        [21] tiles multiplied by the segment-window kernel (a subset of [12]; x staged through LDS per block of 32 tiles
- *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles */
+ *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles
+ *        [23] with a value dictionary: tiles whose rows all repeat the first row's values (constant-coefficient stencils) --
+ *             they read no index stream at all, only the first row's bytes */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

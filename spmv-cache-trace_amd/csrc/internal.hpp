@@ -115,6 +115,7 @@ struct spmv_hip_plan {
     uint8_t * d_vidx = nullptr;
     double * d_vtab = nullptr;            // kMaxIndexedValues doubles
     int nvalues = 0;                      // 0 = no dictionary
+    int value_row_tiles = 0; // tiles of the dictionary kernel that read no index stream (kTileMetaValueRows)
     const double * values_from = nullptr; // the value array it was made from
     unsigned long long value_checksum = 0;
     mutable std::atomic<bool> verify_values_pending{false}; // claimed (exchange) by the one multiply that re-checks

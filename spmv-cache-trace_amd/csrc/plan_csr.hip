@@ -144,7 +144,9 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         if (uniform)
             pl->uniform_rows += rows;
         // with a value dictionary the stream tiles of the default kernel read one byte per entry
-        const long long val_bytes = (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
+        const bool value_rows = pl->nvalues > 0 && stream_tile && (meta & spmv::kTileMetaValueRows);
+        const long long val_bytes = value_rows ? (meta & 0xFFFF) // only the first row's index bytes are read
+            : (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
         bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
     pl->streamed_bytes = bytes;
@@ -866,6 +868,23 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
         if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (d_table) (void) hipFree(d_table);
+        pl->value_row_tiles = 0;
+        if (e == hipSuccess && state[1] == 0) {
+            // tiles whose rows all repeat the first row's indices (constant-coefficient stencils) need no index stream
+            unsigned long long * d_count = nullptr;
+            unsigned long long count[2] = {0, 0};
+            e = hipMalloc((void **) &d_count, sizeof(count));
+            if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(count), s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(spmv::value_rows_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->d_tiles,
+                                   pl->d_vidx, spmv::kLanePerRowMaxLen, d_count);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (d_count) (void) hipFree(d_count);
+            pl->value_row_tiles = (int) count[0];
+        }
         if (e == hipSuccess && state[1] == 0) {
             pl->nvalues = (int) table.size();
             pl->values_from = d_value;
@@ -921,13 +940,13 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[23] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[24] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
-                           pl->segwin_tiles, pl->segwin_slots};
-    for (int i = 0; i < n && i < 23; ++i)
+                           pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0};
+    for (int i = 0; i < n && i < 24; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -74,6 +74,10 @@ constexpr int kTileFlagPartial = (int) 0x80000000u;
 constexpr int kTileMetaLanesShift = 16;
 constexpr int kTileMetaBlockWin = 1 << 20; // the tile belongs to csr_blockwin_kernel; csr_wavetile_kernel skips it
 constexpr int kTileMetaPattern = 1 << 19; // shifted tile: desc.w is a pattern number (first-row columns = first row + pattern)
+// value dictionary only: every row of this (uniform, shifted, one-lane-per-row) tile carries the FIRST row's dictionary
+// indices -- a constant-coefficient stencil -- so the tile's index bytes are not read at all (set / cleared for every tile
+// by value_rows_mark_kernel whenever a dictionary is built; kernels without a dictionary never look at it)
+constexpr int kTileMetaValueRows = 1 << 22;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries

@@ -134,6 +134,44 @@ static __global__ __launch_bounds__(256) void value_index_kernel(
     }
 }
 
+// value_rows_mark_kernel: one wave per tile.  A tile the dictionary kernel multiplies a lane per row (fast, uniform, shifted,
+// one lane per row, rows of at most max_len entries) whose rows all repeat the first row's index bytes gets
+// kTileMetaValueRows; every other tile loses the bit.  count[0] = tiles marked, count[1] = their entries.
+static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
+    int ntiles, int4 * __restrict__ desc, const uint8_t * __restrict__ idx, int max_len, unsigned long long * __restrict__ count)
+{
+    const int w = (int) blockIdx.x * 4 + (int) (threadIdx.x >> 6);
+    const int lane = (int) (threadIdx.x & 63);
+    if (w >= ntiles)
+        return;
+    const int4 d0 = desc[w];
+    const int k0 = d0.y, k1 = desc[w + 1].y;
+    const int meta = d0.z;
+    const int len = meta & 0xFFFF;
+    const bool candidate = !(d0.x & kTileFlagPartial) && (meta & kTileMetaFast) && (meta & kTileMetaUniform) && (meta & kTileMetaShifted)
+        && ((meta >> kTileMetaLanesShift) & 0x7) == 0 && len >= 1 && len <= max_len && k1 > k0;
+    bool same = candidate;
+    if (candidate) {
+        int pos = lane % len; // position of entry k0 + lane within its row
+        const int step = kWave % len;
+        for (int k = k0 + lane; k < k1; k += kWave) {
+            same = same && idx[k] == idx[k0 + pos];
+            pos += step;
+            pos -= pos >= len ? len : 0;
+        }
+        same = __all(same);
+    }
+    if (lane == 0) {
+        const int now = same ? (meta | kTileMetaValueRows) : (meta & ~kTileMetaValueRows);
+        if (now != meta)
+            desc[w].z = now;
+        if (same) {
+            atomicAdd(count, 1ull);
+            atomicAdd(count + 1, (unsigned long long) (k1 - k0));
+        }
+    }
+}
+
 static __global__ __launch_bounds__(256) void value_checksum_kernel(
     long long n, const double * __restrict__ a, unsigned long long * __restrict__ out)
 {

@@ -374,6 +374,71 @@ def test_lane_per_row_stencil_tiles_fuzz(oracle):
     assert took_path >= 20  # the cases did exercise dictionary + shifted + uniform tiles
 
 
+def test_constant_row_tiles_read_no_value_stream(oracle):
+    """Stencil tiles whose rows all carry the first row's dictionary indices (a constant-coefficient stencil) read only
+    the first row's bytes (plan_info[23], kTileMetaValueRows).  Same bits as the indexed path and as the reference's
+    loop; a single differing coefficient sends ITS tile back to the indexed path; refresh_values re-marks the tiles;
+    a plan without a dictionary ignores the marks."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, (rows, cols, p, c, v) in (("5-point", synth.poisson2d(300)),
+                                        ("9 diagonals, one value", synth.banded(40000, [-900, -301, -300, -1, 0, 1, 300, 301, 900], seed=3)),
+                                        ("13 diagonals, three values", synth.banded(50000, [-2000, -700, -300, -2, -1, 0, 1, 2, 5, 300, 700, 2000, 2500], seed=4))):
+        if name == "9 diagonals, one value":
+            v = np.full(len(v), 0.375)
+        elif name != "5-point":
+            # the value depends on the position within the row only (interior rows are equally long): constant coefficients
+            pool = np.array([-1.5, 2.0, 0.25])
+            pos = np.arange(len(v)) - np.repeat(p[:-1], np.diff(p))
+            v = pool[pos % 3]
+        x = synth.x_vector(cols, seed=5)
+        y0 = synth.x_vector(rows, seed=6)
+        tp, tc, tx = (torch.from_numpy(t).to(dev) for t in (p, c, x))
+        tv = torch.from_numpy(v).to(dev)
+
+        def multiply(plan, values):
+            ty = torch.from_numpy(y0.copy()).to(dev)
+            for _ in range(2):
+                plan.spmv(tp.data_ptr(), tc.data_ptr(), values.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            torch.cuda.synchronize()
+            return ty.cpu().numpy()
+
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, 0)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        info = plan.info()
+        assert info["indexed_values"] == len(np.unique(v)), (name, info)
+        assert 0.8 * info["shifted_tiles"] < info["value_row_tiles"] <= info["shifted_tiles"], (name, info)
+        got = multiply(plan, tv)
+        assert_bitexact(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), name)
+        # one coefficient in the middle of the matrix takes another value of the dictionary: its tile reads its index bytes again
+        k = int(p[rows // 2 + (150 if name == "5-point" else 7)]) + 1  # (5-point: the middle of a grid line, away from its 4-entry rows)
+        other = np.unique(v)[0] if v[k] != np.unique(v)[0] else (np.unique(v)[-1] if len(np.unique(v)) > 1 else 9.0)
+        v2 = v.copy()
+        v2[k] = other
+        tv2 = torch.from_numpy(v2).to(dev)
+        plan.refresh_values(tp.data_ptr(), tc.data_ptr(), tv2.data_ptr(), stream)
+        info2 = plan.info()
+        assert info2["value_row_tiles"] == info["value_row_tiles"] - 1, (name, info, info2)
+        assert info2["streamed_bytes"] > info["streamed_bytes"]
+        assert_bitexact(multiply(plan, tv2), oracle.csr_spmv(rows, p, c, v2, x, y=y0, num_threads=4, runs=2), name + ", one coefficient changed")
+        # ... and back
+        plan.refresh_values(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        assert plan.info()["value_row_tiles"] == info["value_row_tiles"]
+        assert np.array_equal(multiply(plan, tv), got)
+        plan.close()
+        # the marks mean nothing to a plan without a dictionary
+        plain = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_NO_VALUE_INDEX)
+        plain.compress(tc.data_ptr(), stream)
+        plain.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plain.index_values(tv.data_ptr(), stream)
+        assert plain.info()["value_row_tiles"] == 0 and plain.info()["indexed_values"] == 0
+        assert np.array_equal(multiply(plain, tv), got), name
+        plain.close()
+
+
 def test_value_dictionary_out_of_place(oracle):
     """y_out = y_in + A x (what the partitioned multiply uses) through the lane-per-row path with a two-value dictionary
     held in registers and with a seven-value one in the LDS table: y_out bit for bit, y_in untouched."""
