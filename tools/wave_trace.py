@@ -3,8 +3,9 @@
 tools/probes/wave_trace.patch (experiments build, -DSPMV_WAVE_TRACE) every wave of the lane-per-row dictionary path
 writes seven time stamps of the chip's 100 MHz constant clock:
 
-    0 wave started   1 descriptor pair back   2 index bytes back   3 first round of x back
-    4 all products added   5 old y back   6 y stores issued
+    0 wave started   1 descriptor pair back   2 (indexed stencil tiles) index bytes back
+    3 (indexed stencil tiles) first round of x back / (general path) products parked in LDS: streams and x are back
+    4 all products added / row sums done   5 old y back   6 y stores issued
 
     SPMV_HIP_EXPERIMENTS=tools/ablate/wave_trace.so python tools/wave_trace.py [--matrix synthetic:poisson2d:4096]
 """
@@ -54,7 +55,7 @@ def main():
     plan.spmv(*ptrs, stream)
     e1.record()
     torch.cuda.synchronize()
-    n = min(ntiles, 1 << 18)
+    n = min(ntiles, 1 << 20)
     out = np.zeros((n, 8), dtype=np.uint64)
     assert fn(out.ctypes.data, n, 0) == 0
     t = out[:, :7].astype(np.int64)
@@ -62,7 +63,7 @@ def main():
     t = t[ok]
     tick = 10.0  # ns per tick of the 100 MHz clock
     t0 = t[:, 0].min()
-    names = ["descriptor back", "index bytes back", "first x round back", "products added", "old y back", "stores issued"]
+    names = ["descriptor back", "index bytes back", "x back / products parked", "products added / row sums done", "old y back", "stores issued"]
     print("%s: %d tiles, %d traced waves, launch %.1f us by events, first wave start to last store %.1f us" % (
         args.matrix, ntiles, len(t), e0.elapsed_time(e1) * 1e3, (t[:, 6].max() - t0) * tick / 1e3))
     life = (t[:, 6] - t[:, 0]) * tick / 1e3
@@ -72,11 +73,15 @@ def main():
     res["lifetime_us"] = {"mean": float(life.mean()), "median": float(np.median(life))}
     prev = t[:, 0]
     for i, name in enumerate(names, start=1):
-        since_start = (t[:, i] - t[:, 0]) * tick / 1e3
-        step = (t[:, i] - prev) * tick / 1e3
-        print("  %-20s mean %.2f us after start (median %.2f)   %+.2f us after the stamp before" % (name, since_start.mean(), np.median(since_start), step.mean()))
+        have = t[:, i] > 0
+        if not have.any():
+            continue
+        since_start = (t[have, i] - t[have, 0]) * tick / 1e3
+        step = (t[have, i] - prev[have]) * tick / 1e3
+        print("  %-32s mean %.2f us after start (median %.2f)   %+.2f us after the stamp before   (%d waves)" % (
+            name, since_start.mean(), np.median(since_start), step.mean(), int(have.sum())))
         res[name] = float(since_start.mean())
-        prev = np.maximum(prev, t[:, i])
+        prev = np.where(have, np.maximum(prev, t[:, i]), prev)
     # how many traced waves are alive at a time
     starts, ends = np.sort(t[:, 0]), np.sort(t[:, 6])
     grid = np.linspace(t0, t[:, 6].max(), 200)
