@@ -446,6 +446,62 @@ __device__ __forceinline__ void y_store(double * y, const PeerY & peers, long lo
     }
 }
 
+// Constant-row tiles with a lane owning two ADJACENT rows (2l, 2l + 1): x, old y and new y move as ONE 16-byte access per lane
+// instead of two 8-byte ones -- half the vector-memory instructions of the tile (the wave traces show a stencil wave spending
+// the first and the last microsecond of its life issuing those into a full memory pipeline); every row is still added left to
+// right by one lane: same bits.  The accesses are 8-byte aligned only (a stencil row has odd and even columns): global memory
+// takes that.  A tile with an odd number of rows: the lane that would start at the last row starts one row earlier and
+// stores only its second sum.  Poisson 4096^2: 106.8-107.3 -> 98.9-100.7 us on three boxes (round 3; the same idea on the
+// indexed path, before the constant rows, had been -3 % ... +7 % depending on the box).
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <bool X32, bool PEER>
+__device__ __forceinline__ void tile_rows_pairs_constant(
+    const int32_t * __restrict__ first_row, int first_row_base, const uint8_t * __restrict__ vit, ValueLookup vtab,
+    const double * __restrict__ x, const double * y_in, double * y, const PeerY & peers, int r0, int lane, int len, int lead, int nrows)
+{
+    const int top = nrows - 2; // nrows >= 2
+    const int base = 2 * lane < top ? 2 * lane : top;
+    const bool both = 2 * lane <= top, only_second = 2 * lane == nrows - 1;
+    const v2d_a8 yv = __builtin_nontemporal_load(reinterpret_cast<const v2d_a8 *>(y_in + r0 + base));
+    constexpr int CH = 5;
+    v2d_a8 xv[CH];
+    double zA = 0.0, zB = 0.0;
+    for (int p0 = 0; p0 < len; p0 += CH) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (p0 + i < len) {
+                const int c = scalar_load_i32(first_row + p0 + i) + first_row_base;
+                xv[i] = X32 ? *reinterpret_cast<const v2d_a8 *>(reinterpret_cast<const char *>(x) + ((unsigned) (c + base) << 3))
+                            : *reinterpret_cast<const v2d_a8 *>(x + c + base);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (p0 + i < len) {
+                const int bi = lead + p0 + i;
+                const int dw = scalar_load_i32(reinterpret_cast<const int32_t *>(vit) + (bi >> 2));
+                const double val = vtab[(unsigned) (dw >> ((bi & 3) * 8)) & 0x7Fu];
+                zA += val * xv[i].x;
+                zB += val * xv[i].y;
+            }
+        }
+    }
+    if (both) {
+        v2d_a8 out = {yv.x + zA, yv.y + zB};
+        __builtin_nontemporal_store(out, reinterpret_cast<v2d_a8 *>(y + r0 + base));
+        if (PEER) {
+#pragma unroll
+            for (int k = 0; k < kMaxPeers; ++k)
+                if (k < peers.n) {
+                    peers.y[k][r0 + base] = out.x;
+                    peers.y[k][r0 + base + 1] = out.y;
+                }
+        }
+    } else if (only_second) {
+        y_store<PEER, true>(y, peers, r0 + base + 1, yv.y + zB);
+    }
+}
+
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
@@ -529,6 +585,13 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     // arrays, i.e. everything but long rows, tiles of empty rows and the ragged end of the matrix
     if (meta & kTileMetaFast) {
         // ---- stream tile, fast path ----------------------------------------------------
+        if (VI && !kViAblate && C16 && TILE == 512 && !PANELS && (meta & kTileMetaValueRows) && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
+            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen && nrows >= 2) {
+            const bool pattern = (meta & kTileMetaPattern) != 0;
+            tile_rows_pairs_constant<X32, PEER>(pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
+                                                vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);
+            return;
+        }
         // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row
         const int sub = lane >> lanes_log2;
         const int part = lane & ((1 << lanes_log2) - 1);
