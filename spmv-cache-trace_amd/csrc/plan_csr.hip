@@ -283,6 +283,23 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
                 if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
                     break;
                 const int len = p[r1 + 1] - p[r1];
+                // A long run of equally long rows (the interior of a stencil line) starts its own tile: the rows in front of it
+                // (a grid line's boundary rows) would make the run's first tile non-uniform and send it down the general path --
+                // Poisson 4096^2: 2.5 % of the tiles, each holding its wave slot twice as long as a stencil tile.  "Long" = at
+                // least four full tiles of such rows, so that a matrix cannot fall apart into small tiles; only for rows short
+                // enough for the one-lane-per-row stencil path (with 27 entries per row a tile is 18 rows: cutting in front of every
+                // run leaves a partly filled tile per grid line -- KKT-like 758 -> 750 us, but its twin without shifted rows
+                // 927 -> 956 us: not done there).
+                if (r1 > r && len != p[r1] - p[r1 - 1] && len > 0 && len <= spmv::kLanePerRowMaxLen) {
+                    const long long need = 4LL * std::max(1, std::min(row_cap, tile / len));
+                    if (r1 + need <= rows) {
+                        bool run = true;
+                        for (long long q = r1 + 1; q < r1 + need && run; ++q)
+                            run = p[q + 1] - p[q] == len;
+                        if (run)
+                            break;
+                    }
+                }
                 if (!exact && r1 > r) {
                     const int l = lanes_for(std::max(maxlen, len));
                     if (l > 0 && ((r1 - r + 1) << l) > 64)
