@@ -817,7 +817,8 @@ def main():
                            "shifted_tiles": info["shifted_tiles"], "tiles_with_x_window": info["xwin_tiles"],
                            "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"],
                            "balanced_tiles": bool(info["balanced"]), "value_dictionary_size": info["indexed_values"],
-                           "tiles_reading_no_value_stream": info.get("value_row_tiles", 0)})
+                           "tiles_reading_no_value_stream": info.get("value_row_tiles", 0),
+                           "tiles_of_the_dictionary_launch": info.get("dictionary_launch_tiles", 0)})
         else:
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],

@@ -325,7 +325,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [21] tiles multiplied by the segment-window kernel (a subset of [12]; x staged through LDS per block of 32 tiles
  *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles
  *        [23] with a value dictionary: tiles whose rows all repeat the first row's values (constant-coefficient stencils) --
- *             they read no index stream at all, only the first row's bytes */
+ *             they read no index stream at all, only the first row's bytes
+ *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3]) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

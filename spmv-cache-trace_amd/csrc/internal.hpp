@@ -116,6 +116,8 @@ struct spmv_hip_plan {
     double * d_vtab = nullptr;            // kMaxIndexedValues doubles
     int nvalues = 0;                      // 0 = no dictionary
     int value_row_tiles = 0; // tiles of the dictionary kernel that read no index stream (kTileMetaValueRows)
+    int4 * d_tiles_vi = nullptr; // the dictionary launch's own descriptors: runs of constant-row tiles re-cut into tiles of 128 rows
+    int ntiles_vi = 0;           // (0 = it uses d_tiles)
     const double * values_from = nullptr; // the value array it was made from
     unsigned long long value_checksum = 0;
     mutable std::atomic<bool> verify_values_pending{false}; // claimed (exchange) by the one multiply that re-checks

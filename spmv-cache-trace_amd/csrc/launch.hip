@@ -193,6 +193,10 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                 }
             }
 #endif
+            // the dictionary launch has its own descriptors when runs of constant-row tiles were re-cut (plan_csr.hip)
+            const int4 * vi_tiles = pl->d_tiles_vi ? pl->d_tiles_vi : pl->d_tiles;
+            const int vi_ntiles = pl->d_tiles_vi ? pl->ntiles_vi : pl->ntiles;
+            const unsigned vi_groups = (unsigned) ((vi_ntiles + 3) / 4);
             const bool all_blockwin = c16 && (pl->d_blocks || pl->d_segblocks) && pl->blockwin_tiles == pl->ntiles;
             // segment-window plans of a one-process-per-GPU operator: the window kernel and the launch over the leftover
             // tiles both forward their row sums (x below 4 GiB, no split rows: their partial sums meet in atomics)
@@ -243,8 +247,8 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                 // into the other ranks' copies of y as well (split long rows add partial sums atomically and keep the
                 // separate push; so do the plans whose tiles are shared with a window kernel)
                 if (pl->nvalues > 0 && pl->values_from == a)
-                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true, true>), dim3(pl->workgroups), dim3(256), 0, s,
-                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true, true>), dim3(vi_groups), dim3(256), 0, s,
+                                       vi_ntiles, vi_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues, *peers);
                 else
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
@@ -254,12 +258,12 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             } else if (c16 && x32 && pl->nvalues > 0 && pl->values_from == a) {
                 // the default kernel with the value dictionary: one byte per entry instead of eight
                 if (xcd)
-                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, true, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
-                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, true, 0, 0, false, true>), dim3(vi_groups), dim3(256), 0, s,
+                                       vi_ntiles, vi_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues);
                 else
-                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
-                                       pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                    hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 0, false, true>), dim3(vi_groups), dim3(256), 0, s,
+                                       vi_ntiles, vi_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, pl->d_vidx, pl->d_vtab, pl->nvalues);
             } else {
                 if (xcd) SPMV_WT_C(512, true); else SPMV_WT_C(512, false);

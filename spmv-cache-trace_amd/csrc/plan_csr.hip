@@ -488,6 +488,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_vidx);
     if (pl->d_vtab)
         (void) hipFree(pl->d_vtab);
+    if (pl->d_tiles_vi)
+        (void) hipFree(pl->d_tiles_vi);
     if (pl->inner)
         spmv_hip_plan_destroy(pl->inner);
     if (pl->d_vrow_ptr)
@@ -812,12 +814,91 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     return SPMV_HIP_OK;
 }
 
+// The dictionary launch's own descriptor array: consecutive constant-row tiles (kTileMetaValueRows) of one stencil -- same row
+// length, same first-row columns relative to the first row (one pattern) -- are re-cut into tiles of 128 rows.  Such a tile reads
+// nothing but its first row's columns / index bytes, x and y, so the 512-entry limit of the LDS slice does not bind it, and with
+// two adjacent rows per lane 128 rows keep all 64 lanes busy (a 5-point tile of 512 entries has 102 rows: 51 lanes).  Every
+// other tile is copied as it is.  Only tiles that refer to a shared pattern are merged (their first-row columns are known to be
+// the same without looking at the column array).
+static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl)
+{
+    std::vector<int4> d((size_t) pl->ntiles + 1);
+    hipError_t e = hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return e;
+    std::vector<int32_t> pat;
+    if (pl->d_patterns && pl->npatterns > 0) {
+        pat.resize((size_t) pl->npatterns * spmv::kPatStride);
+        e = hipMemcpy(pat.data(), pl->d_patterns, pat.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return e;
+    }
+    const int want = spmv::kTileMetaValueRows | spmv::kTileMetaPattern | spmv::kTileMetaFast | spmv::kTileMetaUniform | spmv::kTileMetaShifted;
+    auto mergeable = [&](int w) {
+        return !(d[(size_t) w].x & spmv::kTileFlagPartial) && (d[(size_t) w].z & want) == want && d[(size_t) w].w >= 0
+            && d[(size_t) w].w < pl->npatterns;
+    };
+    auto same_stencil = [&](int a, int b) { // same row length and the same first-row columns relative to the first row
+        const int len = d[(size_t) a].z & 0xFFFF;
+        if (len != (d[(size_t) b].z & 0xFFFF))
+            return false;
+        const int32_t * pa = pat.data() + (size_t) d[(size_t) a].w * spmv::kPatStride + spmv::kPatRel;
+        const int32_t * pb = pat.data() + (size_t) d[(size_t) b].w * spmv::kPatStride + spmv::kPatRel;
+        return d[(size_t) a].w == d[(size_t) b].w || std::equal(pa, pa + len, pb);
+    };
+    std::vector<int4> out;
+    out.reserve(d.size());
+    int merged_runs = 0;
+    for (int w = 0; w < pl->ntiles;) {
+        if (!mergeable(w)) {
+            out.push_back(d[(size_t) w++]);
+            continue;
+        }
+        int e_run = w + 1;
+        while (e_run < pl->ntiles && mergeable(e_run) && same_stencil(w, e_run))
+            ++e_run;
+        const int len = d[(size_t) w].z & 0xFFFF;
+        const long long r_begin = d[(size_t) w].x, r_end = d[(size_t) e_run].x & 0x7FFFFFFF, k_begin = d[(size_t) w].y;
+        if (e_run - w < 2 || (long long) d[(size_t) e_run].y - k_begin != (r_end - r_begin) * len) { // (uniform rows: cannot fail)
+            for (; w < e_run; ++w)
+                out.push_back(d[(size_t) w]);
+            continue;
+        }
+        ++merged_runs;
+        std::vector<long long> starts;
+        for (long long r = r_begin; r < r_end; r += 128)
+            starts.push_back(r);
+        if (starts.size() >= 2 && r_end - starts.back() == 1)
+            starts.back() -= 1; // a last tile of one row would miss the two-rows-per-lane path: 127 + 2 rows instead of 128 + 1
+        for (long long r : starts)
+            out.push_back(make_int4((int) r, (int) (k_begin + (r - r_begin) * len), d[(size_t) w].z, d[(size_t) w].w));
+        w = e_run;
+    }
+    if (merged_runs == 0 || out.size() >= (size_t) pl->ntiles)
+        return hipSuccess; // nothing gained: the launch keeps the plan's tiles
+    const int n = (int) out.size();
+    out.push_back(d[(size_t) pl->ntiles]); // the sentinel: {rows, nnz}
+    e = hipMalloc((void **) &pl->d_tiles_vi, out.size() * sizeof(int4));
+    if (e == hipSuccess)
+        e = hipMemcpy(pl->d_tiles_vi, out.data(), out.size() * sizeof(int4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (pl->d_tiles_vi) (void) hipFree(pl->d_tiles_vi);
+        pl->d_tiles_vi = nullptr;
+        return e;
+    }
+    pl->ntiles_vi = n;
+    return hipSuccess;
+}
+
 static void drop_value_dictionary(spmv_hip_plan * pl)
 {
     if (pl->d_vidx) (void) hipFree(pl->d_vidx);
     if (pl->d_vtab) (void) hipFree(pl->d_vtab);
+    if (pl->d_tiles_vi) (void) hipFree(pl->d_tiles_vi);
     pl->d_vidx = nullptr;
     pl->d_vtab = nullptr;
+    pl->d_tiles_vi = nullptr;
+    pl->ntiles_vi = 0;
     pl->nvalues = 0;
     pl->values_from = nullptr;
     pl->verify_values_pending = false;
@@ -901,6 +982,8 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (d_count) (void) hipFree(d_count);
             pl->value_row_tiles = (int) count[0];
+            if (e == hipSuccess && count[0] > 0)
+                e = merge_constant_row_tiles(pl);
         }
         if (e == hipSuccess && state[1] == 0) {
             pl->nvalues = (int) table.size();
@@ -957,13 +1040,14 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[24] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[25] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
-                           pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0};
-    for (int i = 0; i < n && i < 24; ++i)
+                           pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
+                           pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0};
+    for (int i = 0; i < n && i < 25; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

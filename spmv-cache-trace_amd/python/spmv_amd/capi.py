@@ -307,12 +307,12 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(24, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 24))
+        out = np.zeros(25, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 25))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
                 "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
-                "segwin_tiles", "segwin_slots", "value_row_tiles"]
+                "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

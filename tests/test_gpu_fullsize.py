@@ -331,7 +331,7 @@ def test_cli_synthetic_full_size_gpus_and_check():
     d = json.loads(r.stdout)
     assert d["kernel"]["name"] == "hip-csr-spmv" and d["kernel"]["rows"] == 16777216 and d["kernel"]["nonzeros"] == 83869696
     assert d["kernel"]["device"]["gpus"] == 1 and "last_run_all_gather_ns" in d["kernel"]["device"]
-    assert d["execution_time"]["samples"] == 5 and 100_000 < d["execution_time"]["median"] < 2_000_000
+    assert d["execution_time"]["samples"] == 5 and 50_000 < d["execution_time"]["median"] < 2_000_000
     assert d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
     # SPMV_DEVICE=hip flips the default of the README spelling; NaN in the result fails the gate (not hides in it)
     r = subprocess.run([hostlib.CLI, "--synthetic", "webbase:20000,62000,300,75", "--spmv-format", "coo", "--threads", "1", "--profile", "2",
