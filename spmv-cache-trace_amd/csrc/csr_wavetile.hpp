@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     if (meta & kTileMetaFast) {
         // ---- stream tile, fast path ----------------------------------------------------
         if (VI && !kViAblate && C16 && TILE == 512 && !PANELS && (meta & kTileMetaValueRows) && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen && nrows >= 2) {
+            && (maxlen <= kLanePerRowMaxLen ? (lanes_log2 == 0 && nrows >= 2) : nrows >= kConstantRowMinRows)) {
             const bool pattern = (meta & kTileMetaPattern) != 0;
             tile_rows_pairs_constant<X32, PEER>(pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                 vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);

@@ -223,7 +223,8 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants
             // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row
             if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
-                && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles) {
+                && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles
+                && !(pl->nvalues > 0 && pl->values_from == a) /* a dictionary kept in spite of the windows: constant-row tiles (plan_csr.hip) */) {
                 if (peers && pl->split_rows == 0 && !pl->d_blocks && !pl->d_segblocks) { // one process per GPU: row sums forwarded (see below)
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256, false, false, true>), dim3(pl->workgroups), dim3(256), 0, s,
                                        pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns, spmv::PanelInfo{},

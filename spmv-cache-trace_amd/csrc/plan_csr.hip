@@ -122,10 +122,13 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
     pl->shifted_entries = pl->narrow_entries = pl->uniform_rows = 0;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->ntiles == 0)
         return SPMV_HIP_OK;
-    std::vector<int4> d((size_t) pl->ntiles + 1);
-    HIP_TRY(hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost));
+    // (the dictionary launch may have its own descriptors: runs of constant-row tiles re-cut into tiles of 128 rows)
+    const bool vi_tiles = pl->nvalues > 0 && pl->d_tiles_vi;
+    const int ntiles = vi_tiles ? pl->ntiles_vi : pl->ntiles;
+    std::vector<int4> d((size_t) ntiles + 1);
+    HIP_TRY(hipMemcpy(d.data(), vi_tiles ? pl->d_tiles_vi : pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost));
     long long bytes = 8LL * pl->cols;
-    for (int w = 0; w < pl->ntiles; ++w) {
+    for (int w = 0; w < ntiles; ++w) {
         const long long entries = (long long) d[(size_t) w + 1].y - d[(size_t) w].y;
         const long long rows = (long long) (d[(size_t) w + 1].x & 0x7FFFFFFF) - (d[(size_t) w].x & 0x7FFFFFFF);
         const int meta = d[(size_t) w].z;
@@ -144,14 +147,16 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         if (uniform)
             pl->uniform_rows += rows;
         // with a value dictionary the stream tiles of the default kernel read one byte per entry
-        const bool value_rows = pl->nvalues > 0 && stream_tile && (meta & spmv::kTileMetaValueRows);
+        const int len = meta & 0xFFFF;
+        const bool value_rows = pl->nvalues > 0 && stream_tile && (meta & spmv::kTileMetaValueRows) && shifted && uniform // as the kernel decides
+            && (len <= spmv::kLanePerRowMaxLen ? (((meta >> spmv::kTileMetaLanesShift) & 7) == 0 && rows >= 2) : rows >= spmv::kConstantRowMinRows);
         const long long val_bytes = value_rows ? (meta & 0xFFFF) // only the first row's index bytes are read
             : (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
         bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
     pl->streamed_bytes = bytes;
     // plans with block or segment windows: the list of tiles left to csr_wavetile_kernel (made once, right after marking)
-    if (compressed && (pl->d_blocks || pl->d_segblocks) && !pl->d_rest_tiles && pl->blockwin_tiles < pl->ntiles) {
+    if (!vi_tiles && compressed && (pl->d_blocks || pl->d_segblocks) && !pl->d_rest_tiles && pl->blockwin_tiles < pl->ntiles) {
         std::vector<int32_t> rest;
         rest.reserve((size_t) (pl->ntiles - pl->blockwin_tiles));
         for (int w = 0; w < pl->ntiles; ++w)
@@ -822,6 +827,9 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
 // the same without looking at the column array).
 static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl)
 {
+#if defined(SPMV_HIP_EXPERIMENTS) && defined(SPMV_VI_ABLATE)
+    return hipSuccess; // the ablation builds switch the constant-row path off: every tile has to fit the general path
+#endif
     std::vector<int4> d((size_t) pl->ntiles + 1);
     hipError_t e = hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost);
     if (e != hipSuccess)
@@ -865,13 +873,23 @@ static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl)
             continue;
         }
         ++merged_runs;
-        std::vector<long long> starts;
-        for (long long r = r_begin; r < r_end; r += 128)
-            starts.push_back(r);
-        if (starts.size() >= 2 && r_end - starts.back() == 1)
-            starts.back() -= 1; // a last tile of one row would miss the two-rows-per-lane path: 127 + 2 rows instead of 128 + 1
-        for (long long r : starts)
+        // n tiles of as equal a number of rows as possible, none above 128: a run of 130 rows becomes 65 + 65, not 128 + 2
+        // (rows longer than the one-lane-per-row limit need kConstantRowMinRows rows per tile to take the constant-row path at
+        // all, and a shorter re-cut tile of such rows would not even fit the general path's LDS slice: runs that cannot give
+        // every tile that many rows are left alone)
+        const long long run_rows = r_end - r_begin;
+        const long long n = (run_rows + 127) / 128;
+        if (len > spmv::kLanePerRowMaxLen && run_rows / n < spmv::kConstantRowMinRows) {
+            --merged_runs;
+            for (; w < e_run; ++w)
+                out.push_back(d[(size_t) w]);
+            continue;
+        }
+        long long r = r_begin;
+        for (long long i = 0; i < n; ++i) {
             out.push_back(make_int4((int) r, (int) (k_begin + (r - r_begin) * len), d[(size_t) w].z, d[(size_t) w].w));
+            r += run_rows / n + (i < run_rows % n ? 1 : 0);
+        }
         w = e_run;
     }
     if (merged_runs == 0 || out.size() >= (size_t) pl->ntiles)
@@ -914,8 +932,9 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     pl->meta_bytes -= std::min(pl->meta_bytes, before);
     // only the default kernel reads the dictionary (row-owned wave tiles with 16-bit-capable plans, x below 4 GiB)
     // (not with column panels, block windows or a majority of x-window tiles: those launches have their own variants)
-    const bool other_variant = pl->inner || pl->d_blocks || pl->d_segblocks
-        || (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles);
+    // (a majority of x-window tiles: the dictionary is kept only if nearly all entries then sit in constant-row tiles, below)
+    const bool xwin_majority = !(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles;
+    const bool other_variant = pl->inner || pl->d_blocks || pl->d_segblocks;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
         || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
         || (pl->flags & SPMV_HIP_FLAG_NO_VALUE_INDEX))
@@ -975,7 +994,7 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(count), s);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::value_rows_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->d_tiles,
-                                   pl->d_vidx, spmv::kLanePerRowMaxLen, d_count);
+                                   pl->d_vidx, spmv::kConstantRowMaxLen, d_count);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
@@ -984,6 +1003,10 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             pl->value_row_tiles = (int) count[0];
             if (e == hipSuccess && count[0] > 0)
                 e = merge_constant_row_tiles(pl);
+            // a plan whose launch stages x through LDS (27-point stencils, bands) gives that up for the dictionary launch only
+            // where it wins clearly: at least 80 % of the entries in re-cut constant-row tiles, which read neither values nor LDS
+            if (e == hipSuccess && xwin_majority && !(pl->d_tiles_vi && 10 * count[1] >= 8 * (unsigned long long) pl->nnz))
+                state[1] = 2; // ... otherwise no dictionary, as before
         }
         if (e == hipSuccess && state[1] == 0) {
             pl->nvalues = (int) table.size();

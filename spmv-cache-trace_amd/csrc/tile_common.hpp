@@ -78,6 +78,10 @@ constexpr int kTileMetaPattern = 1 << 19; // shifted tile: desc.w is a pattern n
 // indices -- a constant-coefficient stencil -- so the tile's index bytes are not read at all (set / cleared for every tile
 // by value_rows_mark_kernel whenever a dictionary is built; kernels without a dictionary never look at it)
 constexpr int kTileMetaValueRows = 1 << 22;
+// ... rows of up to this many entries; rows longer than the one-lane-per-row limit (16) take the constant-row path only in tiles of
+// at least kConstantRowMinRows rows (the dictionary launch's re-cut tiles of 128): a plan tile of 18 rows of 27 would leave 55 lanes idle
+constexpr int kConstantRowMaxLen = 64;
+constexpr int kConstantRowMinRows = 64;
 constexpr int kTileMetaNarrow = 1 << 24;
 constexpr int kTileMetaFast = 1 << 25;
 constexpr int kTileMetaUniform = 1 << 26; // every row of the tile has exactly `longest row` entries

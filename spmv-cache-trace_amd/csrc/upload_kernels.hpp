@@ -134,8 +134,8 @@ static __global__ __launch_bounds__(256) void value_index_kernel(
     }
 }
 
-// value_rows_mark_kernel: one wave per tile.  A tile the dictionary kernel multiplies a lane per row (fast, uniform, shifted,
-// one lane per row, rows of at most max_len entries) whose rows all repeat the first row's index bytes gets
+// value_rows_mark_kernel: one wave per tile.  A stencil tile (fast, uniform, shifted, rows of at most max_len entries)
+// whose rows all repeat the first row's index bytes gets
 // kTileMetaValueRows; every other tile loses the bit.  count[0] = tiles marked, count[1] = their entries.
 static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
     int ntiles, int4 * __restrict__ desc, const uint8_t * __restrict__ idx, int max_len, unsigned long long * __restrict__ count)
@@ -149,7 +149,7 @@ static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
     const int meta = d0.z;
     const int len = meta & 0xFFFF;
     const bool candidate = !(d0.x & kTileFlagPartial) && (meta & kTileMetaFast) && (meta & kTileMetaUniform) && (meta & kTileMetaShifted)
-        && ((meta >> kTileMetaLanesShift) & 0x7) == 0 && len >= 1 && len <= max_len && k1 > k0;
+        && len >= 1 && len <= max_len && k1 > k0;
     bool same = candidate;
     if (candidate) {
         int pos = lane % len; // position of entry k0 + lane within its row

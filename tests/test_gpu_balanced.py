@@ -441,6 +441,71 @@ def test_constant_row_tiles_read_no_value_stream(oracle):
         plain.close()
 
 
+def test_constant_rows_of_long_stencils_in_recut_tiles(oracle):
+    """Constant-coefficient stencils with MORE than 16 entries per row (27-point, 27 plain diagonals): the dictionary launch
+    re-cuts their runs of constant-row tiles into tiles of 64 ... 128 rows that read neither values nor LDS, a lane adding
+    two adjacent rows left to right -- the reference's order, so bit for bit its result, although the plan would otherwise
+    stage x through LDS and sum such rows with two lanes.  Runs too short for 64-row tiles, and the same structure with
+    values that differ from row to row, keep the x-window launch without a dictionary."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(rows, cols, p, c, v, x, y0, flags=0):
+        tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        for _ in range(2):
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        info = plan.info()
+        plan.close()
+        return ty.cpu().numpy(), info
+
+    n = 24
+    stencil = [dz * n * n + dy * n + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    for name, N, offs in (("27-point 24^3", n ** 3, stencil), ("27 diagonals", 30000, list(range(-13, 14))),
+                          ("27 diagonals, 300 rows", 300, list(range(-13, 14))), ("27 diagonals, 150 rows", 150, list(range(-13, 14))),
+                          ("33 diagonals, odd run", 64 * 3 + 33 + 32, list(range(-16, 17)))):
+        rows, cols, p, c, v = synth.banded(N, offs, seed=9)
+        r = np.repeat(np.arange(rows, dtype=np.int64), np.diff(p))
+        v = np.where(c == r, float(len(offs) - 1), -1.0)
+        x = synth.x_vector(cols, seed=10)
+        y0 = synth.x_vector(rows, seed=11)
+        want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
+        got, info = run(rows, cols, p, c, v, x, y0)
+        assert_close(got, want, 2 * abs_products(rows, p, c, v, x) + np.abs(y0), what=name)
+        if info["indexed_values"] == 0:
+            # small matrices: with under 80 % of the entries in re-cut tiles the plan keeps its x windows and no dictionary
+            assert rows <= 300 and info["dictionary_launch_tiles"] == 0, (name, info)
+            continue
+        assert info["indexed_values"] == 2 and info["value_row_tiles"] > 0, (name, info)
+        assert 0 < info["dictionary_launch_tiles"] < info["row_blocks"], (name, info)
+        # interior rows are summed by one lane in the reference's order: bit-identical there (the few boundary rows keep the
+        # general path, which gives a 27-entry row two lanes)
+        reach = max(abs(o) for o in offs) + 64  # (rows within reach of the ends are shorter; the tile around each end of the run is mixed)
+        inner = slice(reach, rows - reach)
+        assert inner.stop - inner.start > 20 or rows < 300, name
+        assert np.array_equal(got[inner].view(np.uint64), want[inner].view(np.uint64)), name
+        # the same structure, values drawn per entry from a dictionary of three: no constant rows -> no dictionary, x windows as before
+        rng = np.random.default_rng(12)
+        v3 = np.array([-1.0, 2.5, 0.125])[rng.integers(0, 3, size=len(v))]
+        got3, info3 = run(rows, cols, p, c, v3, x, y0)
+        if info3["xwin_tiles"] * 2 > info3["row_blocks"]:
+            assert info3["indexed_values"] == 0 and info3["dictionary_launch_tiles"] == 0, (name, info3)
+        assert_close(got3, oracle.csr_spmv(rows, p, c, v3, x, y=y0, num_threads=4, runs=2), 2 * abs_products(rows, p, c, v3, x) + np.abs(y0), what=name + ", three values")
+    # a run of 60 interior rows of 27 cannot give a 64-row tile: left alone
+    rows, cols, p, c, v = synth.banded(86, list(range(-13, 14)), seed=9)
+    v = np.where(c == np.repeat(np.arange(rows), np.diff(p)), 26.0, -1.0)
+    x, y0 = synth.x_vector(cols, seed=10), synth.x_vector(rows, seed=11)
+    got, info = run(rows, cols, p, c, v, x, y0)
+    assert info["dictionary_launch_tiles"] == 0, info
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), 2 * abs_products(rows, p, c, v, x) + np.abs(y0), what="short run")
+
+
 def test_value_dictionary_out_of_place(oracle):
     """y_out = y_in + A x (what the partitioned multiply uses) through the lane-per-row path with a two-value dictionary
     held in registers and with a seven-value one in the LDS table: y_out bit for bit, y_in untouched."""
