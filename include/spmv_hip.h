@@ -292,8 +292,7 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, cons
  * default kernel then streams 1 instead of 8 bytes of value per entry, taking the double itself from the
  * table -- the stored bits, so y is unchanged bit for bit.  Stencil tiles whose rows all carry the first row's values
  * (plan_info[23]) read those few bytes only, and the dictionary launch re-cuts runs of them into tiles of up to 128 rows
- * (plan_info[24]); a plan whose launch would stage x through LDS keeps the dictionary only if at least 80 % of its entries
- * end up in such tiles.  Does nothing (returns 0, plan_info[20] == 0)
+ * (plan_info[24]).  A plan whose launch would stage x through LDS runs the dictionary launch instead (measured faster).  Does nothing (returns 0, plan_info[20] == 0)
  * when the matrix has more distinct values or the plan uses another kernel.  BY CALLING THIS THE CALLER
  * PROMISES that d_value keeps its contents while the plan lives, or that
  * spmv_hip_plan_csr_refresh_values follows every change; the promise is checked like the one for the

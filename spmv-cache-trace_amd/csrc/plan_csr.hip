@@ -932,8 +932,9 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     pl->meta_bytes -= std::min(pl->meta_bytes, before);
     // only the default kernel reads the dictionary (row-owned wave tiles with 16-bit-capable plans, x below 4 GiB)
     // (not with column panels, block windows or a majority of x-window tiles: those launches have their own variants)
-    // (a majority of x-window tiles: the dictionary is kept only if nearly all entries then sit in constant-row tiles, below)
-    const bool xwin_majority = !(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && 2 * (long long) pl->xwin_tiles > pl->ntiles;
+    // (a plan whose launch would stage x through LDS gives that up for the dictionary launch: one byte instead of eight per entry --
+    // or none at all in constant-row tiles -- is worth more than the window: 27-point stencil with 100 distinct values 196.7 ->
+    // 175.6 us, 27 diagonals 180.3 -> 129.5 us, constant coefficients 187.5 -> 43.1 us; round 3, tools/constant_stencil.py)
     const bool other_variant = pl->inner || pl->d_blocks || pl->d_segblocks;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
         || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
@@ -1003,10 +1004,6 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             pl->value_row_tiles = (int) count[0];
             if (e == hipSuccess && count[0] > 0)
                 e = merge_constant_row_tiles(pl);
-            // a plan whose launch stages x through LDS (27-point stencils, bands) gives that up for the dictionary launch only
-            // where it wins clearly: at least 80 % of the entries in re-cut constant-row tiles, which read neither values nor LDS
-            if (e == hipSuccess && xwin_majority && !(pl->d_tiles_vi && 10 * count[1] >= 8 * (unsigned long long) pl->nnz))
-                state[1] = 2; // ... otherwise no dictionary, as before
         }
         if (e == hipSuccess && state[1] == 0) {
             pl->nvalues = (int) table.size();

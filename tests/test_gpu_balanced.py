@@ -445,8 +445,8 @@ def test_constant_rows_of_long_stencils_in_recut_tiles(oracle):
     """Constant-coefficient stencils with MORE than 16 entries per row (27-point, 27 plain diagonals): the dictionary launch
     re-cuts their runs of constant-row tiles into tiles of 64 ... 128 rows that read neither values nor LDS, a lane adding
     two adjacent rows left to right -- the reference's order, so bit for bit its result, although the plan would otherwise
-    stage x through LDS and sum such rows with two lanes.  Runs too short for 64-row tiles, and the same structure with
-    values that differ from row to row, keep the x-window launch without a dictionary."""
+    stage x through LDS and sum such rows with two lanes.  Runs too short for 64-row tiles stay with the plan's tiles; the same
+    structure with values that differ from row to row takes the indexed path."""
     import torch
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
@@ -478,10 +478,6 @@ def test_constant_rows_of_long_stencils_in_recut_tiles(oracle):
         want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
         got, info = run(rows, cols, p, c, v, x, y0)
         assert_close(got, want, 2 * abs_products(rows, p, c, v, x) + np.abs(y0), what=name)
-        if info["indexed_values"] == 0:
-            # small matrices: with under 80 % of the entries in re-cut tiles the plan keeps its x windows and no dictionary
-            assert rows <= 300 and info["dictionary_launch_tiles"] == 0, (name, info)
-            continue
         assert info["indexed_values"] == 2 and info["value_row_tiles"] > 0, (name, info)
         assert 0 < info["dictionary_launch_tiles"] < info["row_blocks"], (name, info)
         # interior rows are summed by one lane in the reference's order: bit-identical there (the few boundary rows keep the
@@ -490,12 +486,11 @@ def test_constant_rows_of_long_stencils_in_recut_tiles(oracle):
         inner = slice(reach, rows - reach)
         assert inner.stop - inner.start > 20 or rows < 300, name
         assert np.array_equal(got[inner].view(np.uint64), want[inner].view(np.uint64)), name
-        # the same structure, values drawn per entry from a dictionary of three: no constant rows -> no dictionary, x windows as before
+        # the same structure, values drawn per entry from a dictionary of three: no constant rows, the indexed path (one byte per entry)
         rng = np.random.default_rng(12)
         v3 = np.array([-1.0, 2.5, 0.125])[rng.integers(0, 3, size=len(v))]
         got3, info3 = run(rows, cols, p, c, v3, x, y0)
-        if info3["xwin_tiles"] * 2 > info3["row_blocks"]:
-            assert info3["indexed_values"] == 0 and info3["dictionary_launch_tiles"] == 0, (name, info3)
+        assert info3["indexed_values"] == 3 and info3["dictionary_launch_tiles"] == 0, (name, info3)
         assert_close(got3, oracle.csr_spmv(rows, p, c, v3, x, y=y0, num_threads=4, runs=2), 2 * abs_products(rows, p, c, v3, x) + np.abs(y0), what=name + ", three values")
     # a run of 60 interior rows of 27 cannot give a 64-row tile: left alone
     rows, cols, p, c, v = synth.banded(86, list(range(-13, 14)), seed=9)

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--pool", type=int, default=0, help="draw every entry's value from a pool of this many (no constant rows)")
     args = ap.parse_args()
     import torch
     from spmv_amd import capi, synth
@@ -42,7 +43,13 @@ def main():
         tx = torch.from_numpy(synth.x_vector(cols, "uniform", seed=12345)).to(dev)
         res = {}
         ys = {}
-        for label, flags in (("dictionary + constant rows", 0), ("8-byte values", capi.FLAG_NO_VALUE_INDEX)):
+        plans = [("dictionary + constant rows", 0), ("8-byte values", capi.FLAG_NO_VALUE_INDEX)]
+        if args.pool:  # the same structure, every entry's value drawn from a pool: no constant rows
+            rng = np.random.default_rng(5)
+            v = rng.uniform(-1, 1, size=args.pool)[rng.integers(0, args.pool, size=nnz)]
+            tv = torch.from_numpy(v).to(dev)
+            plans = [("default plan", 0), ("no x window (dictionary, indexed)", capi.FLAG_NO_X_WINDOW), ("8-byte values", capi.FLAG_NO_VALUE_INDEX)]
+        for label, flags in plans:
             plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
             plan.compress(tc.data_ptr(), stream)
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
@@ -63,14 +70,15 @@ def main():
             us = e0.elapsed_time(e1) / args.reps * 1e3
             info = plan.info()
             res[label] = {"us": round(us, 2), "gflops": round(2 * nnz / us / 1e3, 1), "streamed_bytes": info["streamed_bytes"],
-                          "tiles": info["row_blocks"], "constant_row_tiles": info["value_row_tiles"], "launch_tiles": info["dictionary_launch_tiles"]}
+                          "tiles": info["row_blocks"], "constant_row_tiles": info["value_row_tiles"], "launch_tiles": info["dictionary_launch_tiles"],
+                          "dictionary": info["indexed_values"], "xwin_tiles": info["xwin_tiles"]}
             plan.close()
             del ty
-        a, b = ys["dictionary + constant rows"], ys["8-byte values"]
+        a, b = ys[plans[0][0]], ys["8-byte values"]
         same = bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)))
         rel = float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
         print("%-16s rows %9d entries %10d: %s" % (name, rows, nnz, "; ".join(
-            "%s %.1f us %.0f GFLOP/s (%d tiles launched)" % (k, r["us"], r["gflops"], r["launch_tiles"] or r["tiles"]) for k, r in res.items())),
+            "%s %.1f us %.0f GFLOP/s (%d tiles launched, dictionary %d, x-window tiles %d)" % (k, r["us"], r["gflops"], r["launch_tiles"] or r["tiles"], r["dictionary"], r["xwin_tiles"]) for k, r in res.items())),
             "bit-identical" if same else "max rel diff %.1e" % rel)
         out[name] = {"rows": rows, "nnz": nnz, "results": res, "bit_identical": same, "max_rel_diff": rel}
         del tp, tc, tv, tx
