@@ -293,7 +293,8 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, cons
  * table -- the stored bits, so y is unchanged bit for bit.  Stencil tiles whose rows all carry the first row's values
  * (plan_info[23]) read those few bytes only, and the dictionary launch re-cuts runs of them into tiles of up to 128 rows
  * (plan_info[24]).  A plan whose launch would stage x through LDS runs the dictionary launch instead (measured faster).  Does nothing (returns 0, plan_info[20] == 0)
- * when the matrix has more distinct values or the plan uses another kernel.  BY CALLING THIS THE CALLER
+ * when the matrix has more distinct values or the plan uses another kernel (column panels, block / segment windows; balanced
+ * tiles have their own dictionary variant).  BY CALLING THIS THE CALLER
  * PROMISES that d_value keeps its contents while the plan lives, or that
  * spmv_hip_plan_csr_refresh_values follows every change; the promise is checked like the one for the
  * columns (checksum on the first multiply, on every multiply with SPMV_HIP_FLAG_VERIFY_PLAN: a changed

@@ -30,16 +30,19 @@ namespace spmv {
 constexpr int kSegMaxRows = 256;
 constexpr int kTileMetaSeg = 1 << 21;
 
-template <bool C16, bool X32, bool XCD>
+// VI: the plan holds a value dictionary (a pattern / graph matrix: all ones; few distinct weights): the stream tiles read one index
+// byte per entry instead of eight bytes of value (see csr_wavetile_kernel); long rows keep reading the values themselves.
+template <bool C16, bool X32, bool XCD, bool VI = false>
 __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in, double * y,
-    int nnz_total, int cols)
+    int nnz_total, int cols, const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0)
 {
     constexpr int TILE = 512, QUADS = 2, RPL = kSegMaxRows / kWave; // rows per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ __attribute__((aligned(16))) uint16_t rowat_all[4][TILE];
+    __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int lane = (int) __lane_id();
@@ -47,10 +50,24 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
     // tiles, so that the x entries its rows refer to (a web graph links mostly within the neighbourhood
     // of the row) collect in ONE L2 instead of being fetched over the fabric into all eight
     const int w = (XCD ? xcd_remap((int) blockIdx.x, (ntiles + 3) >> 2, true) : (int) blockIdx.x) * 4 + wave;
-    if (w >= ntiles)
-        return; // whole wave leaves; no workgroup barrier in this kernel
+    if (!VI && w >= ntiles)
+        return; // whole wave leaves; no workgroup barrier in the kernel without a value dictionary
     double * prod = prod_all[wave];
     uint16_t * rowat = rowat_all[wave];
+    ValueLookup vtab{vtab_lds, false, 0.0, 0.0};
+    if (VI) {
+        vtab.tiny = nvalues <= 2; // kernel-uniform
+        if (vtab.tiny) {
+            vtab.t0 = vtable[0];
+            vtab.t1 = vtable[1];
+        } else {
+            if (threadIdx.x < kMaxIndexedValues)
+                vtab_lds[threadIdx.x] = vtable[threadIdx.x];
+            __syncthreads(); // the only workgroup barrier; passed by every wave before any can leave
+        }
+        if (w >= ntiles)
+            return;
+    }
 
     const TilePair dp = load_tile_pair(desc, w);
     const int4 d0 = dp.d0, d1 = dp.d1;
@@ -81,9 +98,9 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
         // (2) the tile's column/value quads, gather x, park the rounded products
         const int last = (k1 - 1 - kb) & ~3;
         if (C16 && (meta & kTileMetaNarrow))
-            tile_products_narrow<QUADS, 0>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane);
+            tile_products_narrow<QUADS, 0, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);
         else
-            tile_products_wide<QUADS, X32>(prod, j + kb, a + kb, x, last, lane);
+            tile_products_wide<QUADS, X32, VI>(prod, j + kb, a + kb, x, last, lane, vidx + kb, vtab);
         // (3) every non-empty row marks the slot of its first entry
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         *reinterpret_cast<v4u *>(rowat + 8 * lane) = v4u{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};

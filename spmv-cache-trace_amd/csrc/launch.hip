@@ -162,7 +162,11 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
     hipLaunchKernelGGL((spmv::csr_segtile_kernel<C, X, R>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols)
 #define SPMV_SEG_X(C, R) do { if (x32) SPMV_SEG_LAUNCH(C, true, R); else SPMV_SEG_LAUNCH(C, false, R); } while (0)
 #define SPMV_SEG_C(R) do { if (c16) SPMV_SEG_X(true, R); else SPMV_SEG_X(false, R); } while (0)
-            if (xcd) SPMV_SEG_C(true); else SPMV_SEG_C(false);
+            if (c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a)
+                // a value dictionary (pattern / graph matrices): one index byte per entry instead of eight bytes of value
+                hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16,
+                                   a, x, y_in, y, pl->nnz, pl->cols, pl->d_vidx, pl->d_vtab, pl->nvalues);
+            else if (xcd) SPMV_SEG_C(true); else SPMV_SEG_C(false);
 #undef SPMV_SEG_C
 #undef SPMV_SEG_X
 #undef SPMV_SEG_LAUNCH

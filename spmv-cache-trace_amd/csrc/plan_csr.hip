@@ -151,7 +151,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         const bool value_rows = pl->nvalues > 0 && stream_tile && (meta & spmv::kTileMetaValueRows) && shifted && uniform // as the kernel decides
             && (len <= spmv::kLanePerRowMaxLen ? (((meta >> spmv::kTileMetaLanesShift) & 7) == 0 && rows >= 2) : rows >= spmv::kConstantRowMinRows);
         const long long val_bytes = value_rows ? (meta & 0xFFFF) // only the first row's index bytes are read
-            : (pl->nvalues > 0 && stream_tile && !pl->balanced) ? entries : 8 * entries;
+            : (pl->nvalues > 0 && stream_tile) ? entries : 8 * entries;
         bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
     pl->streamed_bytes = bytes;
@@ -936,7 +936,8 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     // or none at all in constant-row tiles -- is worth more than the window: 27-point stencil with 100 distinct values 196.7 ->
     // 175.6 us, 27 diagonals 180.3 -> 129.5 us, constant coefficients 187.5 -> 43.1 us; round 3, tools/constant_stencil.py)
     const bool other_variant = pl->inner || pl->d_blocks || pl->d_segblocks;
-    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0 || pl->balanced
+    if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->nnz == 0 || pl->ntiles == 0
+        || (pl->balanced && (pl->flags & SPMV_HIP_FLAG_XCD_REMAP)) /* the balanced-tile kernel's dictionary variant has no XCD deal */
         || !pl->d_col16 || other_variant || pl->cols >= (1 << 29)
         || (pl->flags & SPMV_HIP_FLAG_NO_VALUE_INDEX))
         return (pl->inner || before == 0) ? SPMV_HIP_OK // nothing was dropped: the account of plan / compress still holds

@@ -374,6 +374,44 @@ def test_lane_per_row_stencil_tiles_fuzz(oracle):
     assert took_path >= 20  # the cases did exercise dictionary + shifted + uniform tiles
 
 
+def test_balanced_tiles_with_a_value_dictionary(oracle):
+    """A graph as a pattern matrix (all ones) or with a few distinct weights: the balanced-tile kernel reads one index byte per
+    entry (csr_segtile_kernel<VI>); 1e-10 against the oracle like the 8-byte path, and bit-identical to it where no row is cut
+    into atomically added chunks."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, max_len in (("web graph", 3000), ("web graph without split rows", 400)):
+        rows, cols, p, c, v = synth.powerlaw(40000, 40000, max_len=max_len, seed=21)
+        lens = np.diff(p)
+        for what, vals in (("pattern", np.ones(len(v))), ("five weights", np.array([0.5, 1.0, -2.0, 0.125, 3.0])[np.arange(len(v)) % 5]),
+                           ("1/degree", np.repeat(1.0 / np.minimum(np.maximum(lens, 1), 90), lens))):
+            x = synth.x_vector(cols, seed=22)
+            y0 = synth.x_vector(rows, seed=23)
+            tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, vals, x))
+            got = {}
+            for flags in (0, capi.FLAG_NO_VALUE_INDEX):
+                plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+                plan.compress(tc.data_ptr(), stream)
+                plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+                plan.index_values(tv.data_ptr(), stream)
+                info = plan.info()
+                assert info["balanced"] == 1, (name, info)
+                assert info["indexed_values"] == (0 if flags else len(np.unique(vals))), (name, what, info)
+                ty = torch.from_numpy(y0.copy()).to(dev)
+                for _ in range(2):
+                    plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+                torch.cuda.synchronize()
+                got[flags] = ty.cpu().numpy()
+                if not flags:
+                    assert info["streamed_bytes"] < 12 * len(v) + 28 * rows, (name, info)
+                plan.close()
+            want = oracle.csr_spmv(rows, p, c, vals, x, y=y0, num_threads=4, runs=2)
+            assert_close(got[0], want, 2 * abs_products(rows, p, c, vals, x) + np.abs(y0), what="%s, %s" % (name, what))
+            if max_len <= 512:
+                assert np.array_equal(got[0].view(np.uint64), got[capi.FLAG_NO_VALUE_INDEX].view(np.uint64)), (name, what)
+
+
 def test_constant_row_tiles_read_no_value_stream(oracle):
     """Stencil tiles whose rows all carry the first row's dictionary indices (a constant-coefficient stencil) read only
     the first row's bytes (plan_info[23], kTileMetaValueRows).  Same bits as the indexed path and as the reference's
