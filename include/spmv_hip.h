@@ -76,7 +76,8 @@ extern "C" {
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
                                                 kernel (bit-exact for any row length).  Default: the row-major arrays in
                                                 place as uniform wave tiles; with SPMV_HIP_FLAG_EXACT_ORDER the
-                                                column-major kernel takes rows of more than 80 entries */
+                                                column-major kernel takes rows of more than 80 entries.  Which path an
+                                                upload took: spmv_hip_ctx_info [17] */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
@@ -236,7 +237,9 @@ int spmv_hip_last_run_times(spmv_hip_ctx *ctx, uint64_t *kernel_ns, uint64_t *ga
  * [11] shifted tiles  [12] tiles with an x window  [13] block-window tiles  [14] tiles of the
  * column-panel copy (see spmv_hip_plan_info)  [15] bytes one run streams with the tile classes in
  * use (see spmv_hip_plan_info [14]; formats without tiles: their algorithmic bytes)
- * [16] devices (1, or the num_gpus of spmv_hip_create_multi: [6..15] are then sums over the devices) */
+ * [16] devices (1, or the num_gpus of spmv_hip_create_multi: [6..15] are then sums over the devices)
+ * [17] ELLPACK path of the upload: 0 = not ELLPACK, 1 = the row-major arrays in place (wave tiles), 2 = column-major
+ *      copy (one lane per row, the reference's order) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 /* =================================================================================

@@ -712,11 +712,12 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
     if (c->multi) {
         // the whole matrix: sizes from the front, tile counts / bytes summed over the devices, [16] = devices
-        int64_t v[17] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (int64_t) c->parts.size()};
+        int64_t v[18] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (int64_t) c->parts.size(), 0};
         for (size_t g = 0; g < c->parts.size(); ++g) {
-            int64_t w[16] = {0};
+            int64_t w[18] = {0};
             if (c->parts[g]->format != 0)
-                spmv_hip_ctx_info(c->parts[g], w, 16);
+                spmv_hip_ctx_info(c->parts[g], w, 18);
+            v[17] = w[17] ? w[17] : v[17];
             v[4] = w[4] ? w[4] : v[4];
             v[5] = w[5];
             for (int i : {6, 7, 8, 9, 10, 11, 12, 13, 14, 15})
@@ -724,11 +725,12 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
             if (c->yfull[g])
                 v[9] += (int64_t) c->chunk * (int64_t) c->parts.size() * 8;
         }
-        for (int i = 0; i < n && i < 17; ++i)
+        for (int i = 0; i < n && i < 18; ++i)
             out[i] = v[i];
         return SPMV_HIP_OK;
     }
-    int64_t v[17] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0, 1};
+    int64_t v[18] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0, 1,
+                     c->format == 3 ? (c->ell_as_tiles ? 1 : 2) : 0};
     // [15] bytes one run streams: the plan's count where tiles are used, else the format's algorithmic bytes
     switch (c->format) {
     case 2: v[15] = 16LL * c->nnz + 16LL * c->rows + 8LL * c->cols; break;
@@ -752,7 +754,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
     }
     if (c->d_prow)
         v[14] += c->coo_panel_blocks; // COO (part) in column panels: workgroups per panel
-    for (int i = 0; i < n && i < 17; ++i)
+    for (int i = 0; i < n && i < 18; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -53,6 +53,10 @@ int spmv_hip_ipc_alloc(void ** d_ptr, size_t bytes, void * handle64)
     void * p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     hipError_t e = hipMemset(p, 0, bytes);
+    // a device memset may return before it has run: nothing orders another rank's stores (other process, other device)
+    // behind it, so the zeroes must be in memory before the handle exists -- "the memory comes back zeroed"
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
     hipIpcMemHandle_t h;
     if (e == hipSuccess)
         e = hipIpcGetMemHandle(&h, p);

@@ -825,13 +825,18 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
 // two adjacent rows per lane 128 rows keep all 64 lanes busy (a 5-point tile of 512 entries has 102 rows: 51 lanes).  Every
 // other tile is copied as it is.  Only tiles that refer to a shared pattern are merged (their first-row columns are known to be
 // the same without looking at the column array).
-static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl)
+static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl, const uint8_t * d_same_prev)
 {
 #if defined(SPMV_HIP_EXPERIMENTS) && defined(SPMV_VI_ABLATE)
     return hipSuccess; // the ablation builds switch the constant-row path off: every tile has to fit the general path
 #endif
     std::vector<int4> d((size_t) pl->ntiles + 1);
     hipError_t e = hipMemcpy(d.data(), pl->d_tiles, d.size() * sizeof(int4), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return e;
+    // same_prev[w]: tile w's first row carries the dictionary bytes of tile w - 1's (value_rows_mark_kernel, byte by byte)
+    std::vector<uint8_t> same_prev((size_t) pl->ntiles, 0);
+    e = hipMemcpy(same_prev.data(), d_same_prev, same_prev.size(), hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         return e;
     std::vector<int32_t> pat;
@@ -863,7 +868,10 @@ static hipError_t merge_constant_row_tiles(spmv_hip_plan * pl)
             continue;
         }
         int e_run = w + 1;
-        while (e_run < pl->ntiles && mergeable(e_run) && same_stencil(w, e_run))
+        // (a run also ends where the COEFFICIENTS change: two constant-row tiles next to each other may carry different sets --
+        // a piecewise-constant stencil whose jump falls on a tile boundary -- and a re-cut tile multiplies all its rows with
+        // its own first row's)
+        while (e_run < pl->ntiles && mergeable(e_run) && same_stencil(w, e_run) && same_prev[(size_t) e_run])
             ++e_run;
         const int len = d[(size_t) w].z & 0xFFFF;
         const long long r_begin = d[(size_t) w].x, r_end = d[(size_t) e_run].x & 0x7FFFFFFF, k_begin = d[(size_t) w].y;
@@ -991,12 +999,14 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
         if (e == hipSuccess && state[1] == 0) {
             // tiles whose rows all repeat the first row's indices (constant-coefficient stencils) need no index stream
             unsigned long long * d_count = nullptr;
+            uint8_t * d_same_prev = nullptr;
             unsigned long long count[2] = {0, 0};
             e = hipMalloc((void **) &d_count, sizeof(count));
+            if (e == hipSuccess) e = hipMalloc((void **) &d_same_prev, (size_t) pl->ntiles);
             if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(count), s);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::value_rows_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->d_tiles,
-                                   pl->d_vidx, spmv::kConstantRowMaxLen, d_count);
+                                   pl->d_vidx, spmv::kConstantRowMaxLen, d_count, d_same_prev);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
@@ -1004,7 +1014,8 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             if (d_count) (void) hipFree(d_count);
             pl->value_row_tiles = (int) count[0];
             if (e == hipSuccess && count[0] > 0)
-                e = merge_constant_row_tiles(pl);
+                e = merge_constant_row_tiles(pl, d_same_prev);
+            if (d_same_prev) (void) hipFree(d_same_prev);
         }
         if (e == hipSuccess && state[1] == 0) {
             pl->nvalues = (int) table.size();

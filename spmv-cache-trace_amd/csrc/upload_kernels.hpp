@@ -137,8 +137,14 @@ static __global__ __launch_bounds__(256) void value_index_kernel(
 // value_rows_mark_kernel: one wave per tile.  A stencil tile (fast, uniform, shifted, rows of at most max_len entries)
 // whose rows all repeat the first row's index bytes gets
 // kTileMetaValueRows; every other tile loses the bit.  count[0] = tiles marked, count[1] = their entries.
+// same_prev[w] (if asked for) = 1 when tile w's first row carries exactly the index bytes of tile w - 1's first `len`
+// entries: two constant-row tiles may only be merged into one (merge_constant_row_tiles: the re-cut tile reads ITS first
+// row's bytes for all its rows) when their coefficient sets are the same -- a piecewise-constant stencil whose coefficients
+// jump exactly on a tile boundary has two constant tiles with different sets next to each other.  Compared byte by byte,
+// not hashed: a wrong "same" would be a wrong y.
 static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
-    int ntiles, int4 * __restrict__ desc, const uint8_t * __restrict__ idx, int max_len, unsigned long long * __restrict__ count)
+    int ntiles, int4 * __restrict__ desc, const uint8_t * __restrict__ idx, int max_len, unsigned long long * __restrict__ count,
+    uint8_t * __restrict__ same_prev)
 {
     const int w = (int) blockIdx.x * 4 + (int) (threadIdx.x >> 6);
     const int lane = (int) (threadIdx.x & 63);
@@ -160,6 +166,19 @@ static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
             pos -= pos >= len ? len : 0;
         }
         same = __all(same);
+    }
+    if (same_prev) {
+        // (only .y of the neighbour's descriptor is read: .z is being rewritten by the neighbour's wave)
+        bool eq = candidate && w > 0;
+        if (eq) {
+            const int kp = desc[w - 1].y;
+            eq = k0 - kp >= len; // the neighbour holds at least one row of this length (the host checks that it is such a tile)
+            for (int pos = lane; eq && pos < len; pos += kWave)
+                eq = idx[k0 + pos] == idx[kp + pos];
+            eq = __all(eq);
+        }
+        if (lane == 0)
+            same_prev[w] = eq ? 1 : 0;
     }
     if (lane == 0) {
         const int now = same ? (meta | kTileMetaValueRows) : (meta & ~kTileMetaValueRows);

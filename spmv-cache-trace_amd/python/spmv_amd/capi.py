@@ -277,11 +277,11 @@ class Context:
         return k.value, g.value
 
     def info(self):
-        out = np.zeros(17, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 17))
+        out = np.zeros(18, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 18))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
                 "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles",
-                "blockwin_tiles", "panel_tiles", "streamed_bytes", "devices"]
+                "blockwin_tiles", "panel_tiles", "streamed_bytes", "devices", "ell_path"]
         return dict(zip(keys, out.tolist()))
 
 

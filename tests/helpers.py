@@ -62,9 +62,45 @@ def abs_products(rows, row_ptr, col, val, x):
     return np.bincount(r, weights=np.abs(val) * np.abs(x[col]), minlength=rows)
 
 
-def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what=""):
-    """Tolerance of BASELINE.json (1e-10 relative): norm-wise, and per row against
-    the magnitude of the products that were summed."""
+# Rows that needed the second clause of assert_close (below): appended to $SPMV_TOLERANCE_REPORT (default
+# gpurun_out/tolerance_report.jsonl when that directory exists) so that a run says which tests passed on the contract's
+# formula alone and which needed the summation bound, and by how much.
+_REPORT = os.environ.get("SPMV_TOLERANCE_REPORT") or (
+    os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out", "tolerance_report.jsonl")
+    if os.path.isdir(os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")) else None)
+
+
+def _report(entry):
+    if not _REPORT:
+        return
+    entry["test"] = os.environ.get("PYTEST_CURRENT_TEST", "")
+    try:
+        with open(_REPORT, "a") as f:
+            f.write(json.dumps(entry) + "\n")
+    except OSError:
+        pass
+
+
+def row_tolerance(y_cpu, rtol=RTOL):
+    """SURVEY section 8(d), verbatim: per row |y_gpu - y_cpu| <= 1e-10 * max(|y_cpu_i|, 1e-6 * ||y_cpu||_inf)."""
+    y_cpu = np.asarray(y_cpu)
+    ninf = np.max(np.abs(y_cpu)) if y_cpu.size else 0.0
+    return rtol * np.maximum(np.abs(y_cpu), 1e-6 * ninf)
+
+
+def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what="", nterms=4096):
+    """The contract's tolerance (BASELINE.json "within 1e-10 relative"):
+
+      * inf-norm and 2-norm of the error <= 1e-10 of the reference's;
+      * per row |y_gpu_i - y_cpu_i| <= 1e-10 * max(|y_cpu_i|, 1e-6 * ||y_cpu||_inf).
+
+    The per-row floor is 1e-16 * ||y||_inf -- below one unit in the last place of the largest element -- so a row whose
+    products cancel can miss it by rounding alone whenever its sum is formed in another order than the reference's (several
+    lanes per row, segmented sums).  For exactly those rows, and only when the caller hands over `scale` = (|A||x|)_i (times
+    the runs, plus |y0_i|), a second clause applies: the a-priori bound on the difference of two summation orders of the
+    same products, 2 * nterms * 2^-53 * scale_i (nterms >= the row's products; default 4096) -- six orders of magnitude
+    tighter than the 1e-10 * (|A||x|)_i that rounds 1-3 allowed.  Whatever needs the second clause is reported (see
+    _report) with the largest ratio to the contract's bound."""
     y_gpu = np.asarray(y_gpu)
     y_cpu = np.asarray(y_cpu)
     assert y_gpu.shape == y_cpu.shape, what
@@ -76,11 +112,21 @@ def assert_close(y_gpu, y_cpu, scale=None, rtol=RTOL, what=""):
         "%s: inf-norm rel err %.3e" % (what, np.max(err) / max(ninf, 1e-300))
     n2 = np.linalg.norm(y_cpu)
     assert np.linalg.norm(y_gpu - y_cpu) <= rtol * max(n2, np.finfo(float).tiny), what
-    if scale is not None:
-        bound = rtol * np.maximum(scale, np.abs(y_cpu)) + 1e-300
-        bad = np.nonzero(err > bound)[0]
-        assert bad.size == 0, "%s: %d rows off, first %d: gpu=%r cpu=%r" % (
-            what, bad.size, bad[0], y_gpu[bad[0]], y_cpu[bad[0]])
+    contract = row_tolerance(y_cpu, rtol) + 1e-300
+    over = np.nonzero(err > contract)[0]
+    if over.size == 0:
+        return
+    if scale is None:
+        raise AssertionError("%s: %d rows outside 1e-10*max(|y_i|, 1e-6*||y||inf), first %d: gpu=%r cpu=%r" % (
+            what, over.size, over[0], y_gpu[over[0]], y_cpu[over[0]]))
+    scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), y_cpu.shape)
+    summation = 2.0 * nterms * 2.0 ** -53 * np.maximum(scale[over], np.abs(y_cpu[over])) + 1e-300
+    bad = over[err[over] > summation]
+    _report({"what": what, "rows": int(y_cpu.size), "rows_needing_summation_bound": int(over.size),
+             "worst_ratio_to_contract": float(np.max(err[over] / contract[over])),
+             "worst_ratio_to_summation_bound": float(np.max(err[over] / summation)), "failed": int(bad.size)})
+    assert bad.size == 0, "%s: %d rows off (contract AND summation bound), first %d: gpu=%r cpu=%r" % (
+        what, bad.size, bad[0], y_gpu[bad[0]], y_cpu[bad[0]])
 
 
 def assert_ell(y_gpu, y_cpu, L, flags, ell_col, ell_val, x, y0=None, runs=1, what=""):

@@ -539,6 +539,44 @@ def test_constant_rows_of_long_stencils_in_recut_tiles(oracle):
     assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), 2 * abs_products(rows, p, c, v, x) + np.abs(y0), what="short run")
 
 
+def test_constant_row_tiles_with_a_coefficient_jump_on_a_tile_boundary(oracle):
+    """A piecewise-constant stencil: rows < b carry one coefficient set, rows >= b another.  Wherever b falls on a plan tile
+    boundary both neighbours are constant-row tiles (each against its OWN first row) with different sets, and the
+    dictionary launch must not merge them into one re-cut tile, which would multiply the second tile's rows with the first
+    tile's coefficients (round 3 did: ADVICE r03).  Every b in a window of 128 consecutive rows -- 9-entry rows give plan
+    tiles of 56 rows, so the window holds at least two tile boundaries -- bit for bit against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rows, cols, p, c, v = synth.banded(12000, [-900, -301, -300, -1, 0, 1, 300, 301, 900], seed=3)
+    pos = np.arange(len(v)) - np.repeat(p[:-1], np.diff(p))
+    r = np.repeat(np.arange(rows, dtype=np.int64), np.diff(p))
+    pool1, pool2 = np.array([-1.5, 2.0, 0.25]), np.array([2.0, -1.5, 0.75])  # (shared values: the sets differ by position)
+    x = synth.x_vector(cols, seed=5)
+    y0 = synth.x_vector(rows, seed=6)
+    tp, tc, tx = (torch.from_numpy(t).to(dev) for t in (p, c, x))
+    merged_somewhere = 0
+    marked = []
+    for b in range(6000, 6128):
+        vb = np.where(r < b, pool1[pos % 3], pool2[pos % 3])
+        tv = torch.from_numpy(vb).to(dev)
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, 0)
+        plan.compress(tc.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        info = plan.info()
+        assert info["indexed_values"] == 4, info
+        merged_somewhere += info["dictionary_launch_tiles"] > 0
+        marked.append(info["value_row_tiles"])
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        plan.close()
+        assert_bitexact(ty.cpu().numpy(), oracle.csr_spmv(rows, p, c, vb, x, y=y0, num_threads=4), "jump at row %d" % b)
+    assert merged_somewhere == 128, "the runs on either side of the jump are still re-cut into 128-row tiles"
+    # the jump is on a tile boundary exactly when no tile lost its mark to it (one marked tile more than otherwise)
+    assert max(marked) == min(marked) + 1 and 2 <= marked.count(max(marked)) <= 4, marked
+
+
 def test_value_dictionary_out_of_place(oracle):
     """y_out = y_in + A x (what the partitioned multiply uses) through the lane-per-row path with a two-value dictionary
     held in registers and with a seven-value one in the LDS table: y_out bit for bit, y_in untouched."""

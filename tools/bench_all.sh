@@ -36,8 +36,10 @@ run poisson_csr_hashed --matrix synthetic:poisson2d:4096,1
 run kkt_csr_noshift --workload kkt --flags 0x400
 run kkt_csr_jitter50 --matrix synthetic:kkt:200,50
 run queen_csr_jitter6 --matrix synthetic:queen:110,71,177,6
-# the performance floor table of tests/test_gpu_perf_floor.py: the slower of the committed figure and this box's survives
-python3 tools/perf_floor.py --write > gpurun_out/${TAG}_perf_floor.log 2>&1 && cp tests/golden/perf_floor.json gpurun_out/${TAG}_perf_floor.json
+# the launches of tests/test_gpu_perf_floor.py measured on this box -- measured and logged only: updating the committed table
+# (tests/golden/perf_floor.json) is an explicit, reviewed step (python3 tools/perf_floor.py --write), never a side effect of a
+# sweep, or a regressed build run through this script would loosen the very floor that exists to catch it
+python3 tools/perf_floor.py > gpurun_out/${TAG}_perf_floor.log 2>&1
 # the SuiteSparse files themselves, where a box has them (same switch as tests/test_gpu_realfiles.py)
 if [ -n "$SPMV_SUITESPARSE_DIR" ]; then
   for name in 1138_bus Queen_4147 nlpkkt200 webbase-1M; do
