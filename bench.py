@@ -18,15 +18,21 @@ With N > 1 GPUs the SAME matrix is row-partitioned (ceil(rows/N) rows per rank, 
 static chunk rule), x is replicated, and every step ends with ONE all-gather of the y segments
 (RCCL): total work is fixed, so scaling is "strong".
 
-Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).  `roofline` prices
-the local SpMV kernel: the bytes its plan streams per launch divided by the launch's mean duration
-measured with HIP events on the launch stream (`frac`, never above what HBM delivered); beside it
-`frac_algorithmic` (the algorithmic bytes of BASELINE.md section 3 -- what a plain CSR kernel would
-move; above `frac` exactly where the plan found a cheaper encoding), `frac_of_triad` (against the
-STREAM triad measured in the same process) and, when the matrix has a value dictionary,
-`general_values`: the same workload timed in the same process with its values read as doubles.  `cpu_baseline` (rank 0, N = 1 only) times the
-reference's own OpenMP kernel (oracle/_ref, kind "reference") or the C oracle (kind "port") on
-the host cores; the same leg is the parity gate (whole vector, 1e-10 relative).
+Prints ONE JSON line on rank 0.  `value` = 2*Z*K / t in GFLOP/s (whole job).
+
+The timed launch READS THE VALUE ARRAY (plan flag SPMV_HIP_FLAG_NO_VALUE_INDEX: what the kernel does for a matrix of this
+structure with arbitrary values), and `roofline` follows SURVEY section 8(d) to the letter: `achieved` = ALGORITHMIC bytes
+per launch (CSR 12 Z + 4 (N+1) + 16 N + 8 M) / the launch's mean duration measured with HIP events on the launch stream,
+`frac` = achieved / 8 TB/s, `traffic` = PMC bytes of a committed profile of the same device code.  Beside it, as
+information: `streamed` (the bytes the plan's tile classes really move, their fraction of the peak and of the STREAM triad
+timed in the same process), `cold` (the same launch with L2 and Infinity Cache evicted before every run), `plan_ms` (what
+building the plan cost, stage by stage) and `compressed`: the launch the product runs BY DEFAULT for a matrix with at most
+128 distinct values (value dictionary, constant-row tiles -- bit-identical y, far fewer bytes than the algorithmic figure:
+its own us, GFLOP/s, streamed bytes, cold time and plan cost; `--headline product` makes that launch the timed one).
+Companions on the default workload (never part of `value`): `config2_queen`, `config3_kkt`, `config4_webbase` -- the
+stand-ins of BASELINE configs[2..4] at full size, each with ms per step, the section-8(d) fraction and a whole-vector
+parity check against the CPU kernel.  `cpu_baseline` (rank 0, N = 1 only) times the reference's own OpenMP kernel
+(oracle/_ref, kind "reference") or the C oracle (kind "port") on the host cores; the same leg is the parity gate.
 """
 import argparse
 import json
@@ -94,6 +100,13 @@ def parse_args():
                          "the multiply kernel stores its row sums into every rank's vector (inter-process device memory); "
                          "peer-push = the multiply, then one kernel that pushes the segment; auto (default) = time a few steps "
                          "of each scheme that can be set up and take the fastest")
+    ap.add_argument("--headline", choices=["general", "product"], default="general",
+                    help="which plan the timed region runs.  general (default): SPMV_HIP_FLAG_NO_VALUE_INDEX, the launch reads the "
+                         "value array -- the roofline row of SURVEY 8(d); product: the plan the library builds by default (a value "
+                         "dictionary where the matrix has <= 128 distinct values: fewer bytes than the algorithmic figure)")
+    ap.add_argument("--no-companions", action="store_true",
+                    help="skip config2_queen / config4_webbase (the stand-ins of BASELINE configs[2] and [4]) on the default workload")
+    ap.add_argument("--no-cold", action="store_true", help="skip the flushed-cache timing of the headline launch")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the companion measurement of BASELINE configs[3] (the nlpkkt200-like KKT matrix, the configuration "
                          "BASELINE.json partitions over 8 GPUs) that the default workload's line carries as `config3_kkt`")
@@ -234,14 +247,14 @@ def format_bytes(fmt, rows, cols, nnz, stored=None, coo_entries=0):
     return 12 * stored + 16 * coo_entries + 16 * rows + 8 * cols  # hybrid: ELL part + COO remainder
 
 
-def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None):
+def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
     """The reference's OpenMP kernel (or the C oracle) on the host cores, bounded sample.  Also the
     parity gate: one CPU multiply from y = 0 is compared with the GPU's (y_gpu), whole vector,
     tolerance 1e-10 relative (BASELINE.json).  A = dict of the format's arrays.  Returns (cpu_baseline, parity)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     threads = args.cpu_threads or host_cores()
-    budget = args.cpu_seconds
+    budget = args.cpu_seconds if budget is None else budget
     nnz = A["nnz"]
     if fmt == "csr":
         p, c, v = A["p"], A["c"], A["v"]
@@ -252,7 +265,7 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None):
         if not args.cpu_threads:
             # the box may expose more CPUs than it grants: probe a few team sizes briefly
             best = None
-            for cand in sorted({min(threads, 16), min(threads, 32), min(threads, 64), threads}):
+            for cand in sorted({min(threads, 16), min(threads, 32), min(threads, 64), threads} if budget >= 8 else {threads}):
                 ns, _ = R.csr_spmv_timed(M, x, cand, 2)
                 if best is None or np.median(ns) < best[0]:
                     best = (float(np.median(ns)), cand)
@@ -305,8 +318,14 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None):
         diff = np.abs(y_gpu - y_cpu)
         finite = bool(np.isfinite(y_gpu).all())
         err = float(np.max(diff) / max(float(np.max(np.abs(y_cpu))), 1e-300)) if finite else float("nan")
+        # per row |y_gpu - y_cpu| <= 1e-10 * max(|y_cpu_i|, 1e-6 * ||y_cpu||_inf); norm-wise 1e-10
+        ninf = float(np.max(np.abs(y_cpu))) if rows else 0.0
+        row_bound = 1e-10 * np.maximum(np.abs(y_cpu), 1e-6 * ninf) + 1e-300
+        worst_row = float(np.max(diff / row_bound)) if (finite and rows) else float("nan")
         parity = {"against": "cpu_baseline kernel (%s), one multiply from y = 0" % kind, "rows_checked": int(rows),
                   "max_rel_err": err if finite else "nan", "tolerance": 1e-10, "pass": bool(finite and err <= 1e-10),
+                  "worst_row_over_8d_bound": round(worst_row, 4) if finite else "nan",
+                  "rows_outside_8d_bound": int(np.count_nonzero(diff > row_bound)) if finite else None,
                   "bitexact": bool(np.array_equal(y_gpu, y_cpu))}
     return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
             "sample": "full workload (%s), %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
@@ -380,6 +399,150 @@ class ContextOperator:
         return self.ctx.get_y()
 
 
+def time_launches(torch, fn, steps, warmup):
+    """Mean duration of one launch in seconds: `warmup` launches, then ONE HIP event pair on torch's current stream (the
+    stream the launches go to) around `steps` back-to-back launches."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / steps
+
+
+class CacheFlusher:
+    """What --flush-caches does between two timed runs (src/profile-kernel.cpp:181-192: flush_cache of 10 x the largest
+    cache), on the device: a read-modify-write pass over 1 GiB -- four times the 256 MiB Infinity Cache, 32 times the
+    L2s -- so that the next launch finds neither its matrix nor its vectors on the chip."""
+
+    def __init__(self, torch, device):
+        self.buf = torch.zeros(128 * 1024 * 1024, dtype=torch.float64, device=device)
+
+    def __call__(self):
+        self.buf.add_(1.0)
+
+
+def cold_launches(torch, fn, flusher, n=10):
+    """`n` launches, each after a cache flush, each with its own event pair: (median, min) seconds."""
+    t = []
+    for _ in range(n):
+        flusher()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t.append(e0.elapsed_time(e1) * 1e-3)
+    return float(np.median(t)), float(np.min(t))
+
+
+def build_plan_timed(torch, capi, rows, cols, p, tp, tc, tv, algo, lanes, flags, stream, first_multiply=None):
+    """A Level-2 plan built stage by stage with the device idle at both ends of every stage: what the plan costs, in ms.
+    `first_multiply(plan)`: one multiply (the first one re-checks the plan's checksums: one pass + a stream sync)."""
+    ms = {}
+
+    def stage(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        ms[name] = round((time.perf_counter() - t0) * 1e3, 3)
+        return out
+    plan = stage("tiles_from_host_row_ptr", lambda: capi.CsrPlan(rows, cols, p, algo, lanes, flags))
+    if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
+        stage("compress (tile classes, 16-bit columns, patterns, windows)", lambda: plan.compress(tc.data_ptr(), stream))
+        stage("repack (column panels, where the matrix is scattered)", lambda: plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream))
+        stage("index_values (dictionary, constant-row marks, re-cut tiles)", lambda: plan.index_values(tv.data_ptr(), stream))
+    if first_multiply is not None:
+        stage("first_multiply (checksum verification + launch)", lambda: first_multiply(plan))
+    ms["total"] = round(sum(ms.values()), 3)
+    return plan, ms
+
+
+def companion(torch, capi, hostapi, synth, args, device, stream, spec, fmt, name, flags, algo, steps=10, warmup=3):
+    """One of BASELINE's other configurations at full size on this GPU, short: whole-step time (host clock around `steps`
+    steps, device idle at both ends), the launch by HIP events, the section-8(d) fraction, and the whole vector of one
+    multiply against the CPU kernel (the reference library for CSR, the C oracle for the other formats).  Never `value`."""
+    t_all = time.perf_counter()
+    M = hostapi.load(spec, fmt)
+    rows, cols, nnz = M.rows, M.cols, M.num_entries
+    x = synth.x_vector(cols, "uniform", seed=12345)
+    if fmt == "csr":
+        p, c, v = M.row_ptr, M.column_index, M.value
+        tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (p, c, v, x))
+        ty = torch.zeros(rows, dtype=torch.float64, device=device)
+        plan, plan_ms = build_plan_timed(torch, capi, rows, cols, p, tp, tc, tv, algo, args.lanes, flags, stream)
+        ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr())
+        step = lambda: plan.spmv(*ptrs, stream)
+        step()
+        torch.cuda.synchronize()
+        y_check = ty.cpu().numpy()
+        ty.zero_()
+        info = plan.info()
+        alg_bytes = synth.csr_bytes(rows, cols, nnz)
+        host_arrays = {"p": p, "c": c, "v": v}
+        extra = {"tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"], "shifted_tiles": info["shifted_tiles"],
+                 "segment_window_tiles": info["segwin_tiles"], "block_row_tiles": info.get("block_tiles", 0), "balanced_tiles": bool(info["balanced"]),
+                 "value_dictionary_size": info["indexed_values"], "plan_ms": plan_ms}
+    else:
+        op = ContextOperator(fmt, M, x, device.index or 0, flags | capi.FLAG_NO_RUN_EVENTS, stream)
+        step = op.step
+        step()
+        torch.cuda.synchronize()
+        y_check = op.y()
+        op.zero_y()
+        info = op.ctx.info()
+        alg_bytes = format_bytes(fmt, rows, cols, nnz, M.stored, M.num_coo_entries)
+        if fmt == "coo":
+            host_arrays = {"r": M.row_index, "c": M.column_index, "v": M.value}
+        elif fmt == "ell":
+            host_arrays = {"L": M.row_length, "c": M.column_index, "v": M.value}
+        else:
+            host_arrays = {"L": M.row_length, "c": M.column_index, "v": M.value, "cr": M.coo_row_index,
+                           "cc": M.coo_column_index, "cv": M.coo_value}
+        extra = {"tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"], "column_panel_tiles": info["panel_tiles"],
+                 "ell_row_length": getattr(M, "row_length", None) if fmt != "coo" else None,
+                 "coo_remainder_entries": M.num_coo_entries if fmt == "hybrid" else None}
+    streamed = int(info["streamed_bytes"])
+    for _ in range(warmup):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - c0) / steps
+    kern = e0.elapsed_time(e1) * 1e-3 / steps
+    host_arrays.update(nnz=nnz, bytes=alg_bytes)
+    cpu, parity = (None, None)
+    if not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline(args, fmt, rows, cols, host_arrays, x, y_check, budget=1.5)
+    out = {"workload": name, "format": fmt, "rows": rows, "cols": cols, "nnz": nnz, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(wall * 1e3, 5), "gflops": round(2.0 * nnz / wall / 1e9, 2),
+           "kernel_us": round(kern * 1e6, 2), "gflops_kernel_only": round(2.0 * nnz / kern / 1e9, 1),
+           "algorithmic_bytes_per_launch": int(alg_bytes), "frac_algorithmic": round(alg_bytes / kern / 1e9 / HBM_PEAK_GBS, 4),
+           "streamed_bytes_per_launch": streamed, "frac_streamed": round(streamed / kern / 1e9 / HBM_PEAK_GBS, 4),
+           "parity": parity, "cpu_gflops": cpu["value"] if cpu else None, "cpu_cores": cpu["cores"] if cpu else None,
+           "cpu_kind": cpu["kind"] if cpu else None}
+    out.update(extra)
+    if fmt == "csr":
+        plan.close()
+        del tp, tc, tv, tx, ty
+    else:
+        op.ctx.close()
+    M.close()
+    torch.cuda.empty_cache()
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -431,6 +594,8 @@ def main():
     algo = {"auto": capi.CSR_AUTO, "scalar": capi.CSR_SCALAR, "vector": capi.CSR_VECTOR,
             "adaptive": capi.CSR_ADAPTIVE, "wavetile": capi.CSR_WAVETILE}[args.algorithm]
     flags = (capi.FLAG_XCD_REMAP if args.xcd_remap else 0) | args.flags
+    # the timed plan: by default one that READS THE VALUE ARRAY (SURVEY 8(d)'s launch); `flags` alone = the product's default plan
+    hflags = flags | (capi.FLAG_NO_VALUE_INDEX if args.headline == "general" else 0)
     stream = torch.cuda.current_stream().cuda_stream
     host_arrays = None  # what the cpu_baseline leg multiplies
     if fmt == "csr":
@@ -440,7 +605,7 @@ def main():
             dist.all_reduce(t)
             nnz = int(t.item())
         x = synth.x_vector(cols, "uniform", seed=12345)
-        op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
+        op = DistributedCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, hflags,
                                        overlap=not args.no_overlap, ranges=ranges, pingpong=not args.snapshot)
         ops = {"rccl": op}
         peer_note = None
@@ -450,10 +615,14 @@ def main():
             try:
                 for name, fused in (("peer-fused", True), ("peer-push", False)):
                     if args.gather in ("auto", name):
-                        ops[name] = PeerCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, flags,
+                        ops[name] = PeerCsrSpmv.on_gpu(rows, cols, rank, world, device, p, c, v, x, algo, args.lanes, hflags,
                                                        ranges=ranges, fused=fused, uploaded=op.uploaded)
             except PeerUnavailable as e:
+                # (the construction is collective: every rank lands here together) whatever was already set up is closed -- its
+                # inter-process mappings before their owners free the memory -- and the run goes on with RCCL alone
                 peer_note = "peer stores not available: %s" % e
+                for name in [k for k in ops if k != "rccl"]:
+                    ops.pop(name).close()
                 ops = {"rccl": op}
         local_rows, local_nnz = end - begin, int(p[-1])
         local_bytes = synth.csr_bytes(local_rows, cols, local_nnz)
@@ -605,45 +774,64 @@ def main():
     except (RuntimeError, capi.SpmvHipError):
         triad_gbs = None
 
-    # ---- the same workload with its values read as 8-byte doubles (VERDICT r02 task 2) ------------------
-    # A value dictionary (<= 128 distinct values: this Poisson operator has two) lets the default plan stream one
-    # byte per entry instead of eight, so its time says little about how the kernel does on a matrix of the same
-    # shape with arbitrary values.  Same process, same device arrays, same K and warm-up: a second plan built with
-    # SPMV_HIP_FLAG_NO_VALUE_INDEX, timed with its own event pair, checked bit for bit against the default plan.
-    general = None
-    if fmt == "csr" and world == 1 and not use_dist and info["indexed_values"] > 0:
+    # ---- beside the headline launch: its cold time, what its plan cost, and the product's default plan --------------------
+    # The timed plan reads the value array.  For a matrix with <= 128 distinct values (this Poisson operator has two) the
+    # library by default builds a value dictionary and the launch streams one index byte per entry -- or, in constant-row
+    # tiles, none -- instead of eight: far fewer bytes than SURVEY 8(d) prices, so that launch is reported BESIDE the
+    # roofline row, as `compressed`: same process, same device arrays, same K and warm-up, bit-identical y.
+    cold = plan_ms = compressed = None
+    single = fmt == "csr" and world == 1 and not use_dist
+    flusher = None
+    if single and not args.no_cold:
+        flusher = CacheFlusher(torch, device)
         tp, tc, tv, tx = op._keep
-        plan_g = capi.CsrPlan(local_rows, cols, p, algo, args.lanes, flags | capi.FLAG_NO_VALUE_INDEX)
-        plan_g.compress(tc.data_ptr(), stream)
-        plan_g.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
-        plan_g.index_values(tv.data_ptr(), stream)  # a no-op under the flag; keeps the call sequence of on_gpu
+        yc = torch.zeros(local_rows, dtype=torch.float64, device=device)
+        hp = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), yc.data_ptr())
+        med, mn = cold_launches(torch, lambda: op.plan.spmv(*hp, stream), flusher)
+        cold = {"kernel_us_median": round(med * 1e6, 2), "kernel_us_min": round(mn * 1e6, 2), "launches": 10,
+                "frac": round(local_bytes / med / 1e9 / HBM_PEAK_GBS, 4),
+                "flush": "before every launch a read-modify-write pass over 1 GiB (4 x the Infinity Cache), one event pair per launch"}
+        del yc
+    if single:
+        tp, tc, tv, tx = op._keep
         yg = torch.zeros(local_rows, dtype=torch.float64, device=device)
         ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), yg.data_ptr())
-        plan_g.spmv(*ptrs, stream)
-        torch.cuda.synchronize()
-        same = bool(y_check is not None and np.array_equal(yg.cpu().numpy(), y_check))
-        for _ in range(args.warmup):
-            plan_g.spmv(*ptrs, stream)
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        g0.record()
-        for _ in range(args.steps):
-            plan_g.spmv(*ptrs, stream)
-        g1.record()
-        torch.cuda.synchronize()
-        g_s = g0.elapsed_time(g1) * 1e-3 / args.steps
-        ginfo = plan_g.info()
-        general = {"flag": "SPMV_HIP_FLAG_NO_VALUE_INDEX", "kernel_us": round(g_s * 1e6, 2),
-                   "gflops": round(2.0 * local_nnz / g_s / 1e9, 1),
-                   "frac_algorithmic": round(local_bytes / g_s / 1e9 / HBM_PEAK_GBS, 4),
-                   "streamed_bytes_per_launch": int(ginfo["streamed_bytes"]),
-                   "frac": round(ginfo["streamed_bytes"] / g_s / 1e9 / HBM_PEAK_GBS, 4),
-                   "frac_of_triad": round(ginfo["streamed_bytes"] / g_s / 1e9 / triad_gbs, 4) if triad_gbs else None,
-                   "value_dictionary_size": int(ginfo["indexed_values"]),
-                   "bitexact_vs_default_plan": same if y_check is not None else None,
-                   "events": "one pair around the %d timed launches, after %d warm-up launches" % (args.steps, args.warmup)}
-        plan_g.close()
+        first = lambda pl: pl.spmv(*ptrs, stream)
+        # what the timed plan cost: the same plan built once more, stage by stage (never inside the timed region)
+        plan_h, plan_ms = build_plan_timed(torch, capi, local_rows, cols, p, tp, tc, tv, algo, args.lanes, hflags, stream, first)
+        plan_h.close()
+        other = flags if args.headline == "general" else (flags | capi.FLAG_NO_VALUE_INDEX)
+        yg.zero_()
+        plan_o, plan_o_ms = build_plan_timed(torch, capi, local_rows, cols, p, tp, tc, tv, algo, args.lanes, other, stream, first)
+        oinfo = plan_o.info()
+        differs = oinfo["indexed_values"] != info["indexed_values"]
+        if differs:
+            torch.cuda.synchronize()
+            same = bool(y_check is not None and np.array_equal(yg.cpu().numpy(), y_check))
+            o_s = time_launches(torch, lambda: plan_o.spmv(*ptrs, stream), args.steps, args.warmup)
+            o_cold = cold_launches(torch, lambda: plan_o.spmv(*ptrs, stream), flusher) if flusher else None
+            ob = int(oinfo["streamed_bytes"])
+            compressed = {"plan": "the library's default (value dictionary of %d values; %d tiles read no value stream at all)" % (
+                              oinfo["indexed_values"], oinfo.get("value_row_tiles", 0)) if args.headline == "general"
+                          else "SPMV_HIP_FLAG_NO_VALUE_INDEX (values read as doubles)",
+                          "kernel_us": round(o_s * 1e6, 2), "gflops": round(2.0 * local_nnz / o_s / 1e9, 1),
+                          "streamed_bytes_per_launch": ob,
+                          "streamed_over_algorithmic_bytes": round(ob / local_bytes, 4),
+                          "frac_streamed": round(ob / o_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_streamed_of_triad": round(ob / o_s / 1e9 / triad_gbs, 4) if triad_gbs else None,
+                          "frac_algorithmic": round(local_bytes / o_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "speedup_over_headline_launch": round(kern_ms_max * 1e-3 / o_s, 3),
+                          "cold_kernel_us_median": round(o_cold[0] * 1e6, 2) if o_cold else None,
+                          "value_dictionary_size": int(oinfo["indexed_values"]),
+                          "tiles_reading_no_value_stream": int(oinfo.get("value_row_tiles", 0)),
+                          "tiles_of_the_dictionary_launch": int(oinfo.get("dictionary_launch_tiles", 0)),
+                          "plan_ms": plan_o_ms,
+                          "bitexact_vs_headline_plan": same if y_check is not None else None,
+                          "events": "one pair around the %d timed launches, after %d warm-up launches" % (args.steps, args.warmup)}
+        plan_o.close()
         del yg
+    del flusher
+    torch.cuda.empty_cache()
 
     # N > 1: the collective on its own (after the timed region, not part of `value`): a few
     # blocking all-gathers, max over ranks, so the line shows where a step's time goes.
@@ -791,6 +979,18 @@ def main():
         del op3, keep3, p3, c3, v3
         torch.cuda.empty_cache()
 
+    # ---- companions: BASELINE configs[2] and [4] on this GPU (default workload, one GPU) -------------------------------------
+    companions = {}
+    if (fmt == "csr" and args.matrix is None and args.workload == "poisson2d" and args.grid == 4096 and world == 1 and not use_dist
+            and not args.no_companions):
+        companions["config2_queen"] = companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:queen", "csr",
+                                                "queen-like 110x71x177 mesh x 3 dof (Queen_4147-like), csr", flags, algo)
+        companions["config4_webbase"] = {
+            f: companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:webbase", f,
+                         "webbase-like power law, 75%% host-local links (webbase-1M-like), %s" % f, flags, algo, steps=50, warmup=10)
+            for f in ("coo", "hybrid", "csr")}
+        companions["config4_webbase"]["ell"] = "not representable: rows x longest row overflows int32, the converter throws like the reference's (ell-matrix.cpp:201-205)"
+
     code, message = 0, None
     if rank == 0:
         from spmv_amd import buildinfo
@@ -823,26 +1023,32 @@ def main():
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],
                            "tiles_with_16bit_columns": info["narrow_tiles"], "column_panel_tiles": info["panel_tiles"]})
-        # `frac` prices what the launch really moves: the bytes the plan's tile classes stream (values 8 B or 1 index
-        # byte, columns 4 / 2 / 0 B, row_ptr where it is read, y in and out, x once, descriptors): every one of them
-        # has to come out of or go into memory once per launch, so achieved <= what the memory system delivered.  The ALGORITHMIC figure of
-        # SURVEY 8d (12 B per entry + 20 per row + 8 per column, what a plain CSR kernel would have to move) stays
-        # beside it as frac_algorithmic: it says how fast the multiply is in the reference's terms and may exceed 1
-        # exactly when the plan found a cheaper encoding.
-        roofline = {"bound": "hbm", "achieved": round(streamed_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(streamed_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        # `achieved` = ALGORITHMIC bytes per launch (CSR 12 Z + 4 (N+1) + 16 N + 8 M; COO 16 Z + 16 N + 8 M;
+        # ELL 12 N L + 16 N + 8 M) / the launch's mean duration; `frac` = achieved / 8 TB/s.  The bytes the plan's tile
+        # classes really stream (values 8 B or an index byte, columns 4 / 2 / 0 B, row_ptr where it is read, y in and out,
+        # x once, descriptors) stand beside it under `streamed`: below the algorithmic figure wherever the plan found a
+        # cheaper encoding of the columns (shifted tiles read one row of them), so `frac` may pass the rate HBM delivered.
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "kernel": kernel_name, "kernel_us": round(kern_s * 1e6, 2),
                     "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
                     "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
-                    "bytes_per_launch": int(streamed), "bytes_are": "streamed by the plan's tile classes (compulsory traffic of this launch)",
-                    "streamed_bytes_per_launch": int(streamed),
+                    "bytes_per_launch": int(local_bytes), "bytes_are": "algorithmic (SURVEY 8(d)); the launch reads the value array"
+                    if (fmt != "csr" or info.get("indexed_values", 0) == 0) else "algorithmic (SURVEY 8(d)); NOTE: this launch reads a value dictionary, not the value array (--headline product)",
                     "algorithmic_bytes_per_launch": int(local_bytes),
-                    "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
+                    "streamed": {"bytes_per_launch": int(streamed), "gbs": round(streamed_gbs, 1), "frac": round(streamed_gbs / HBM_PEAK_GBS, 4),
+                                 "frac_of_triad": round(streamed_gbs / triad_gbs, 4) if triad_gbs else None,
+                                 "over_algorithmic_bytes": round(streamed / max(1, local_bytes), 4)},
+                    "streamed_bytes_per_launch": int(streamed),
                     "triad_gbs": round(triad_gbs, 1) if triad_gbs else None,
-                    "frac_of_triad": round(streamed_gbs / triad_gbs, 4) if triad_gbs else None,
                     "gflops_kernel_only": round(2.0 * local_nnz / kern_s / 1e9, 1)}
-        if general is not None:
-            roofline["general_values"] = general
+        if cold is not None:
+            roofline["cold"] = cold
+        if plan_ms is not None:
+            roofline["plan_ms"] = plan_ms
+        if single:
+            roofline["compressed"] = compressed if compressed is not None else (
+                "none: the matrix has more than 128 distinct values (or the plan has its own variant): the library's default plan IS the timed one")
         if fmt == "csr" and local_nnz > 0:
             roofline["share_of_entries_not_reading_column_index"] = round(info["shifted_entries"] / local_nnz, 4)
             roofline["share_of_entries_with_16bit_columns"] = round(info["narrow_entries"] / local_nnz, 4)
@@ -858,6 +1064,8 @@ def main():
             "hbm_gbs_whole_step": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "setup_s": round(setup_s, 1),
         }
+        config["timed_plan"] = ("reads the value array (SPMV_HIP_FLAG_NO_VALUE_INDEX)" if (hflags & capi.FLAG_NO_VALUE_INDEX)
+                                else "the library's default plan") if fmt == "csr" else "context upload (library default)"
         if gather_us is not None:
             recv = 8.0 * op.chunk * (world - 1)
             # what the step can reach at best: the local multiply and the gather fully overlapped; the gather is bounded
@@ -879,6 +1087,8 @@ def main():
                                 "note": "all_gather_us: blocking collective alone, median of 5 after the timed region; schemes: t_total = a "
                                         "whole step (max over ranks) timed before the warm-up, `gather` = the one the timed region ran",
                                 "one_all_gather_after_the_k_multiplies": deferred}
+        for k in sorted(companions):
+            out[k] = companions[k]
         if config3 is not None:
             out["config3_kkt"] = config3
         if gather_check:
@@ -893,10 +1103,12 @@ def main():
             out["roofline"]["traffic_source"] = ("profiles/%s, kernel %s (%.1f us average under rocprofv3; PMC passes of the same command on the "
                                                  "same device code: source_sha256 %s matches%s)" % (tr[1], tr[3], tr[4], build["source_sha256"],
                                                                                                     "" if tr[2] else "; the .so was rebuilt from it since"))
-            if general is not None:  # the companion launch was profiled in the same process
-                tg = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build, general["kernel_us"])
+            out["roofline"]["traffic_over_algorithmic_bytes"] = round(tr[0] / max(1, int(local_bytes)), 3)
+            if compressed is not None:  # the other launch was profiled in the same process
+                tg = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build, compressed["kernel_us"])
                 if tg and tg[3] != tr[3]:
-                    general["traffic"] = tg[0]
+                    compressed["traffic"] = tg[0]
+                    compressed["traffic_over_streamed_bytes"] = round(tg[0] / max(1, compressed["streamed_bytes_per_launch"]), 3)
         else:
             out["roofline"]["traffic_source"] = ("none: no committed profiles/*_summary.json of this workload was taken with device "
                                                  "sources %s" % build["source_sha256"])

@@ -123,6 +123,13 @@ extern "C" {
                                              tiles in up to 8 far-apart column segments: rows of a 3-D mesh in natural
                                              ordering, KKT systems; the tiles' 16-bit column stream then holds window
                                              slots).  Unstructured bands fall back to the one-ring block window. */
+#define SPMV_HIP_FLAG_NO_BLOCK_TILES 0x2000000u /* plan_csr / plan_csr_repack: no block tiles.  By default a matrix whose rows come in
+                                             triples of equal length (3 unknowns per mesh node: finite-element elasticity) gets its
+                                             tiles cut on triple boundaries, and plan_csr_repack marks every tile that really consists
+                                             of dense 3 x 3 blocks (checked entry by entry): such a tile reads one 16-bit number per
+                                             BLOCK instead of a column index per entry and no row_ptr (8.2 instead of 10 bytes per
+                                             entry).  Only rows of more than 16 entries (1e-10 class either way); never under
+                                             SPMV_HIP_FLAG_EXACT_ORDER */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -286,7 +293,13 @@ int spmv_hip_plan_verify(spmv_hip_plan *plan, const int32_t *d_column_index, voi
  * used by spmv_hip_csr_spmv when it is called with the same d_column_index and d_value; the VALUES
  * ARE SNAPSHOTTED: after changing them call spmv_hip_plan_csr_repack on a fresh plan, or pass
  * SPMV_HIP_FLAG_NO_COLUMN_PANELS.  Does nothing (returns 0) when the matrix does not qualify;
- * plan_info[13] tells.  Costs 12 bytes per entry + 32 bytes per row of device memory.  Synchronises. */
+ * plan_info[13] tells.  Costs 12 bytes per entry + 32 bytes per row of device memory.  Synchronises.
+ * The same step -- it is the one that sees row_ptr next to the columns -- marks BLOCK TILES (plan_info[25]): in a matrix
+ * whose rows come in triples of equal length (spmv_hip_plan_csr noticed that from row_ptr and cut its tiles on triple
+ * boundaries) every tile of rows longer than 16 entries is checked entry by entry for dense 3 x 3 blocks; a tile that
+ * has them reads one 16-bit number per block from a plan-owned side stream instead of a column index per entry, and no
+ * row_ptr.  The CSR arrays are read in place; y stays within 1e-10 (such rows are summed by several lanes either way).
+ * SPMV_HIP_FLAG_NO_BLOCK_TILES / SPMV_HIP_FLAG_EXACT_ORDER switch it off. */
 int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
                              const double *d_value, void *stream);
 /* Optional planning step for matrices with FEW DISTINCT VALUES (at most 128 different bit patterns among
@@ -331,7 +344,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles
  *        [23] with a value dictionary: tiles whose rows all repeat the first row's values (constant-coefficient stencils) --
  *             they read no index stream at all, only the first row's bytes
- *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3]) */
+ *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
+ *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

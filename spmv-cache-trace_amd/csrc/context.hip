@@ -396,7 +396,8 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
         for (int32_t i = 0; i <= rows; ++i)
             row_ptr[(size_t) i] = i * row_length;
         if ((rc = spmv_hip_plan_csr(&c->plan, rows, cols, row_ptr.data(), SPMV_HIP_CSR_WAVETILE, 0,
-                                    c->flags | (row_length <= 16 || c->ell_in_place_any_length ? SPMV_HIP_FLAG_EXACT_ORDER : 0u))) != 0)
+                                    c->flags | SPMV_HIP_FLAG_NO_BLOCK_TILES /* padded rows are no 3 x 3 blocks, and this upload has no repack step */
+                                        | (row_length <= 16 || c->ell_in_place_any_length ? SPMV_HIP_FLAG_EXACT_ORDER : 0u))) != 0)
             return rc;
         if ((rc = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr.data(), ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

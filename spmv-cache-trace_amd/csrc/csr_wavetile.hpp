@@ -3,6 +3,7 @@
 #pragma once
 
 #include "tile_common.hpp"
+#include "csr_blocktile.hpp"
 
 namespace spmv {
 
@@ -590,6 +591,12 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             const bool pattern = (meta & kTileMetaPattern) != 0;
             tile_rows_pairs_constant<X32, PEER>(pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                 vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);
+            return;
+        }
+        if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !exact_order) {
+            // dense 3 x 3 blocks (csr_blocktile.hpp): one 16-bit number per block instead of a column per entry, no row_ptr
+            tile_rows_block3(prod, j16 + block_stream_offset(nnz_total) + block_stream_index(k0), a, x + cbase, y_in, r0, k0, k1, nrows, lane,
+                             [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
             return;
         }
         // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row

@@ -42,7 +42,8 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
-    SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE
+    SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
+    SPMV_HIP_FLAG_NO_BLOCK_TILES
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -108,6 +109,13 @@ struct spmv_hip_plan {
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     int split_rows = 0;    // rows cut into chunks that are added to y with atomics
     bool balanced = false; // tiles filled by entries, row sums by segmented reduction (csr_segtile_kernel)
+    // block tiles (csr_blocktile.hpp): rows in triples of equal length (a hint from row_ptr at plan time), checked against
+    // the columns and marked by spmv_hip_plan_csr_repack; their block stream lives behind the 16-bit columns in d_col16
+    int block_hint = 0;
+    int block_cuts = 0; // tiles the hint made shorter (0: the tiling is what it would have been without the hint)
+    int break_rows = 0; // (what the tiles were built with: a rebuild needs them again)
+    int block_tiles = 0;
+    long long block_entries = 0;
     size_t meta_bytes = 0;
     // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
     long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;

@@ -136,6 +136,13 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         const bool shifted = compressed && stream_tile && (meta & spmv::kTileMetaShifted);
         const bool narrow = compressed && stream_tile && (meta & spmv::kTileMetaNarrow);
         const bool uniform = stream_tile && (meta & spmv::kTileMetaUniform);
+        const bool block3 = compressed && stream_tile && (meta & spmv::kTileMetaBlock3) && !(meta & spmv::kTileMetaBlockWin) && pl->nvalues == 0
+            && !(pl->flags & SPMV_HIP_FLAG_EXACT_ORDER);
+        if (block3) { // one 16-bit number per 3 x 3 block, no row_ptr
+            pl->narrow_entries += entries;
+            bytes += 8 * entries + 2 * (entries / 9) + 16 + 16 * rows;
+            continue;
+        }
         long long col_bytes = 4 * entries;
         if (shifted) {
             col_bytes = (meta & spmv::kTileMetaPattern) ? 0 : 4LL * (meta & 0xFFFF);
@@ -201,6 +208,213 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
 
 } // extern "C"
 
+// Wave tiles of a plan from the HOST row_ptr: <= 64 (128) rows and <= tile entries (from the 4-aligned start) per wave.  Used by
+// plan_csr_internal and, once more, by spmv_hip_plan_csr_repack when the block hint taken here turned out to be wrong.
+static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flags, int32_t break_rows, int split_threshold, int split_chunk)
+{
+    const int32_t rows = pl->rows;
+    // wave tiles: <= 64 rows and <= tile entries (from the 4-aligned start) per wave
+    const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
+    const bool exact = (flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
+    pl->tile = tile;
+    // Block hint (csr_blocktile.hpp): rows in triples of equal length, divisible by 3 and longer than 16 entries -- three
+    // unknowns per mesh node.  Only a hint: tiles are then cut on triple boundaries, and spmv_hip_plan_csr_repack checks the
+    // columns of every tile before it marks it.
+    if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
+        long long good = 0;
+        for (int32_t q = 0; q + 2 < rows; q += 3) {
+            const int l0 = p[q + 1] - p[q];
+            good += l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+        }
+        if (good * 5 >= (long long) (rows / 3) * 4)
+            pl->block_hint = 3;
+    }
+    std::vector<int4> desc;
+    desc.reserve((size_t) rows / 48 + 16);
+    int32_t r = 0;
+    int next_panel = 0;
+    long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
+    while (r < rows) {
+        if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
+            while (next_panel <= 8 && next_panel <= r / break_rows)
+                pl->pinfo.first[next_panel++] = (int) desc.size();
+        const int32_t kb = p[r] & ~3;
+        int32_t r1 = r;
+        int32_t maxlen = 0, minlen = INT32_MAX;
+        // rows per tile: 128 (two short rows per lane, fuller quads) pays once the matrix streams from
+        // HBM (twice the 256 MiB Infinity Cache); below that more, smaller tiles win (measured:
+        // Poisson 4096^2 223 vs 238 us, half of it 103 vs 107 us, a quarter 48 vs 43 us, 2048^2 57 vs 50 us)
+        const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
+        const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
+            : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 512e6 ? 128 : 64);
+        // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
+        // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
+        // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
+        auto lanes_for = [](int len) {
+            int l = 0;
+            while (l < 6 && (16 << l) < len)
+                ++l;
+            return l;
+        };
+        while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
+            if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
+                break;
+            const int len = p[r1 + 1] - p[r1];
+            // A long run of equally long rows (the interior of a stencil line) starts its own tile: the rows in front of it
+            // (a grid line's boundary rows) would make the run's first tile non-uniform and send it down the general path --
+            // Poisson 4096^2: 2.5 % of the tiles, each holding its wave slot twice as long as a stencil tile.  "Long" = at
+            // least four full tiles of such rows, so that a matrix cannot fall apart into small tiles; only for rows short
+            // enough for the one-lane-per-row stencil path (with 27 entries per row a tile is 18 rows: cutting in front of every
+            // run leaves a partly filled tile per grid line -- KKT-like 758 -> 750 us, but its twin without shifted rows
+            // 927 -> 956 us: not done there).
+            if (r1 > r && len != p[r1] - p[r1 - 1] && len > 0 && len <= spmv::kLanePerRowMaxLen) {
+                const long long need = 4LL * std::max(1, std::min(row_cap, tile / len));
+                if (r1 + need <= rows) {
+                    bool run = true;
+                    for (long long q = r1 + 1; q < r1 + need && run; ++q)
+                        run = p[q + 1] - p[q] == len;
+                    if (run)
+                        break;
+                }
+            }
+            if (!exact && r1 > r) {
+                const int l = lanes_for(std::max(maxlen, len));
+                if (l > 0 && ((r1 - r + 1) << l) > 64)
+                    break;
+            }
+            maxlen = std::max(maxlen, len);
+            minlen = std::min(minlen, len);
+            ++r1;
+        }
+        // block hint: a tile of long rows ends on a triple boundary and holds at most kBlockTileMaxRows rows
+        if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
+            int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows);
+            if (cut < rows)
+                cut -= cut % 3;
+            if (cut > r && cut < r1) {
+                pl->block_cuts++;
+                r1 = cut;
+                maxlen = 0;
+                minlen = INT32_MAX;
+                for (int32_t q = r; q < r1; ++q) {
+                    maxlen = std::max(maxlen, p[q + 1] - p[q]);
+                    minlen = std::min(minlen, p[q + 1] - p[q]);
+                }
+            }
+        }
+#ifdef SPMV_HIP_EXPERIMENTS
+        // tools/ab.py: tiles of short rows end on a multiple of SPMV_HIP_TILE_ROW_ALIGN rows (whole 128-byte lines of y per tile)
+        if (const char * al = std::getenv("SPMV_HIP_TILE_ROW_ALIGN")) {
+            const int align = std::atoi(al);
+            if (align > 1 && r1 - r > 2 * align && r1 < rows && (r1 % align) != 0 && (r1 / align) * align > r) {
+                r1 = (r1 / align) * align;
+                maxlen = 0;
+                minlen = INT32_MAX;
+                for (int32_t q = r; q < r1; ++q) {
+                    maxlen = std::max(maxlen, p[q + 1] - p[q]);
+                    minlen = std::min(minlen, p[q + 1] - p[q]);
+                }
+            }
+        }
+#endif
+        if (r1 == r) { // one row longer than a tile
+            const long long len = (long long) p[r + 1] - p[r];
+            pl->long_blocks++;
+            if (!exact && len > split_threshold) {
+                pl->split_rows++;
+                for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
+                    desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+            } else {
+                desc.push_back(make_int4(r, p[r], 0, 0));
+            }
+            r1 = r + 1;
+        } else {
+            // one lane per row (rows of <= 16 entries) keeps the reference's summation order
+            const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
+            pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+            // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
+            const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+            const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
+            if (uniform)
+                pl->uniform_tiles++;
+            stream_tiles++;
+            stream_tile_entries += (long long) p[r1] - p[r];
+            desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
+                                                  (uniform ? (1 << 26) : 0), 0));
+        }
+        r = r1;
+    }
+    // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
+    // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
+    // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
+    // Regular matrices (every tile already full, or only short rows) keep the tiles above and with
+    // them the reference's summation order.
+    {
+        int longest = 0;
+        for (int32_t q = 0; q < rows; ++q)
+            longest = std::max(longest, (int) (p[q + 1] - p[q]));
+        // (rows with a wave or more to themselves are the same in both tilings and do not count)
+        const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
+            && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
+        if (want) {
+            desc.clear();
+            pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
+            r = 0;
+            while (r < rows) {
+                const int32_t kb = p[r] & ~3;
+                int32_t r1 = r;
+                int32_t maxlen = 0;
+                while (r1 < rows && (r1 - r) < spmv::kSegMaxRows && (long long) p[r1 + 1] - kb <= tile) {
+                    maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
+                    ++r1;
+                }
+                if (r1 == r) { // one row longer than a tile
+                    const long long len = (long long) p[r + 1] - p[r];
+                    pl->long_blocks++;
+                    if (len > split_threshold) {
+                        pl->split_rows++;
+                        for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
+                            desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
+                    } else {
+                        desc.push_back(make_int4(r, p[r], 0, 0));
+                    }
+                    r1 = r + 1;
+                } else {
+                    pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+                    const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
+                    desc.push_back(make_int4(r, p[r], maxlen | (fast ? (1 << 25) : 0) | spmv::kTileMetaSeg, 0));
+                }
+                r = r1;
+            }
+            pl->balanced = true;
+            pl->block_hint = 0;
+        }
+    }
+    pl->ntiles = (int) desc.size();
+    if (break_rows > 0) {
+        while (next_panel <= 8)
+            pl->pinfo.first[next_panel++] = pl->ntiles;
+        pl->pinfo.rows = break_rows;
+    }
+    desc.push_back(make_int4(rows, p[rows], 0, 0));
+    pl->nblk = pl->ntiles;
+    pl->workgroups = (pl->ntiles + 3) / 4;
+    if (pl->ntiles > 0) {
+        pl->meta_bytes = desc.size() * sizeof(int4);
+        hipError_t e = hipMalloc((void **) &pl->d_tiles, pl->meta_bytes);
+        if (e == hipSuccess)
+            e = hipMemcpy(pl->d_tiles, desc.data(), pl->meta_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            int rc = fail_hip(e, "plan metadata upload");
+            if (pl->d_tiles)
+                (void) hipFree(pl->d_tiles);
+            pl->d_tiles = nullptr;
+            return rc;
+        }
+    }
+    return SPMV_HIP_OK;
+}
+
 // break_rows > 0: no tile may contain a row index that is a multiple of break_rows except as its
 // first row (column panels: tiles stay inside one panel)
 namespace spmvi {
@@ -253,175 +467,11 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
         pl->lanes_per_row = lanes_per_row ? lanes_per_row : pick_lanes(mean);
         pl->workgroups = grid_for((long long) rows * pl->lanes_per_row, kBlock, cu_count() * 32);
     } else if (algorithm == SPMV_HIP_CSR_WAVETILE) {
-        // wave tiles: <= 64 rows and <= tile entries (from the 4-aligned start) per wave
-        const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
-        const bool exact = (flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
-        pl->tile = tile;
-        std::vector<int4> desc;
-        desc.reserve((size_t) rows / 48 + 16);
-        int32_t r = 0;
-        int next_panel = 0;
-        long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
-        while (r < rows) {
-            if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
-                while (next_panel <= 8 && next_panel <= r / break_rows)
-                    pl->pinfo.first[next_panel++] = (int) desc.size();
-            const int32_t kb = p[r] & ~3;
-            int32_t r1 = r;
-            int32_t maxlen = 0, minlen = INT32_MAX;
-            // rows per tile: 128 (two short rows per lane, fuller quads) pays once the matrix streams from
-            // HBM (twice the 256 MiB Infinity Cache); below that more, smaller tiles win (measured:
-            // Poisson 4096^2 223 vs 238 us, half of it 103 vs 107 us, a quarter 48 vs 43 us, 2048^2 57 vs 50 us)
-            const double footprint = 12.0 * (double) p[rows] + 20.0 * (double) rows;
-            const int row_cap = (flags & SPMV_HIP_FLAG_ROWS64) ? 64
-                : (flags & SPMV_HIP_FLAG_ROWS128) ? 128 : (footprint >= 512e6 ? 128 : 64);
-            // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
-            // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
-            // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
-            auto lanes_for = [](int len) {
-                int l = 0;
-                while (l < 6 && (16 << l) < len)
-                    ++l;
-                return l;
-            };
-            while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
-                if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
-                    break;
-                const int len = p[r1 + 1] - p[r1];
-                // A long run of equally long rows (the interior of a stencil line) starts its own tile: the rows in front of it
-                // (a grid line's boundary rows) would make the run's first tile non-uniform and send it down the general path --
-                // Poisson 4096^2: 2.5 % of the tiles, each holding its wave slot twice as long as a stencil tile.  "Long" = at
-                // least four full tiles of such rows, so that a matrix cannot fall apart into small tiles; only for rows short
-                // enough for the one-lane-per-row stencil path (with 27 entries per row a tile is 18 rows: cutting in front of every
-                // run leaves a partly filled tile per grid line -- KKT-like 758 -> 750 us, but its twin without shifted rows
-                // 927 -> 956 us: not done there).
-                if (r1 > r && len != p[r1] - p[r1 - 1] && len > 0 && len <= spmv::kLanePerRowMaxLen) {
-                    const long long need = 4LL * std::max(1, std::min(row_cap, tile / len));
-                    if (r1 + need <= rows) {
-                        bool run = true;
-                        for (long long q = r1 + 1; q < r1 + need && run; ++q)
-                            run = p[q + 1] - p[q] == len;
-                        if (run)
-                            break;
-                    }
-                }
-                if (!exact && r1 > r) {
-                    const int l = lanes_for(std::max(maxlen, len));
-                    if (l > 0 && ((r1 - r + 1) << l) > 64)
-                        break;
-                }
-                maxlen = std::max(maxlen, len);
-                minlen = std::min(minlen, len);
-                ++r1;
-            }
-#ifdef SPMV_HIP_EXPERIMENTS
-            // tools/ab.py: tiles of short rows end on a multiple of SPMV_HIP_TILE_ROW_ALIGN rows (whole 128-byte lines of y per tile)
-            if (const char * al = std::getenv("SPMV_HIP_TILE_ROW_ALIGN")) {
-                const int align = std::atoi(al);
-                if (align > 1 && r1 - r > 2 * align && r1 < rows && (r1 % align) != 0 && (r1 / align) * align > r) {
-                    r1 = (r1 / align) * align;
-                    maxlen = 0;
-                    minlen = INT32_MAX;
-                    for (int32_t q = r; q < r1; ++q) {
-                        maxlen = std::max(maxlen, p[q + 1] - p[q]);
-                        minlen = std::min(minlen, p[q + 1] - p[q]);
-                    }
-                }
-            }
-#endif
-            if (r1 == r) { // one row longer than a tile
-                const long long len = (long long) p[r + 1] - p[r];
-                pl->long_blocks++;
-                if (!exact && len > split_threshold) {
-                    pl->split_rows++;
-                    for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
-                        desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
-                } else {
-                    desc.push_back(make_int4(r, p[r], 0, 0));
-                }
-                r1 = r + 1;
-            } else {
-                // one lane per row (rows of <= 16 entries) keeps the reference's summation order
-                const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
-                pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
-                // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
-                const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
-                const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
-                if (uniform)
-                    pl->uniform_tiles++;
-                stream_tiles++;
-                stream_tile_entries += (long long) p[r1] - p[r];
-                desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
-                                                      (uniform ? (1 << 26) : 0), 0));
-            }
-            r = r1;
-        }
-        // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
-        // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
-        // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
-        // Regular matrices (every tile already full, or only short rows) keep the tiles above and with
-        // them the reference's summation order.
-        {
-            int longest = 0;
-            for (int32_t q = 0; q < rows; ++q)
-                longest = std::max(longest, (int) (p[q + 1] - p[q]));
-            // (rows with a wave or more to themselves are the same in both tilings and do not count)
-            const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
-                && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
-            if (want) {
-                desc.clear();
-                pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
-                r = 0;
-                while (r < rows) {
-                    const int32_t kb = p[r] & ~3;
-                    int32_t r1 = r;
-                    int32_t maxlen = 0;
-                    while (r1 < rows && (r1 - r) < spmv::kSegMaxRows && (long long) p[r1 + 1] - kb <= tile) {
-                        maxlen = std::max(maxlen, p[r1 + 1] - p[r1]);
-                        ++r1;
-                    }
-                    if (r1 == r) { // one row longer than a tile
-                        const long long len = (long long) p[r + 1] - p[r];
-                        pl->long_blocks++;
-                        if (len > split_threshold) {
-                            pl->split_rows++;
-                            for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
-                                desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
-                        } else {
-                            desc.push_back(make_int4(r, p[r], 0, 0));
-                        }
-                        r1 = r + 1;
-                    } else {
-                        pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
-                        const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
-                        desc.push_back(make_int4(r, p[r], maxlen | (fast ? (1 << 25) : 0) | spmv::kTileMetaSeg, 0));
-                    }
-                    r = r1;
-                }
-                pl->balanced = true;
-            }
-        }
-        pl->ntiles = (int) desc.size();
-        if (break_rows > 0) {
-            while (next_panel <= 8)
-                pl->pinfo.first[next_panel++] = pl->ntiles;
-            pl->pinfo.rows = break_rows;
-        }
-        desc.push_back(make_int4(rows, p[rows], 0, 0));
-        pl->nblk = pl->ntiles;
-        pl->workgroups = (pl->ntiles + 3) / 4;
-        if (pl->ntiles > 0) {
-            pl->meta_bytes = desc.size() * sizeof(int4);
-            hipError_t e = hipMalloc((void **) &pl->d_tiles, pl->meta_bytes);
-            if (e == hipSuccess)
-                e = hipMemcpy(pl->d_tiles, desc.data(), pl->meta_bytes, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                int rc = fail_hip(e, "plan metadata upload");
-                if (pl->d_tiles)
-                    (void) hipFree(pl->d_tiles);
-                delete pl;
-                return rc;
-            }
+        pl->break_rows = break_rows;
+        int rc = build_wave_tiles(pl, p, flags, break_rows, split_threshold, split_chunk);
+        if (rc != SPMV_HIP_OK) {
+            delete pl;
+            return rc;
         }
     } else {
         // adaptive: cut rows into blocks of <= kTile entries (from the 4-aligned
@@ -517,7 +567,9 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     if (pl->d_col16)
         return fail(SPMV_HIP_ERR_STATE, "plan is already compressed");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = (size_t) pl->nnz * sizeof(uint16_t) + 64;
+    // (with a block hint the block stream of csr_blocktile.hpp lives behind the 16-bit columns, in the same allocation)
+    const size_t bytes = pl->block_hint ? (spmv::block_stream_offset(pl->nnz) + (size_t) pl->nnz / 9 + 128) * sizeof(uint16_t)
+                                        : (size_t) pl->nnz * sizeof(uint16_t) + 64;
     const bool want_patterns = !(pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES);
     int * d_count = nullptr;
     unsigned long long * d_fp = nullptr;
@@ -731,6 +783,82 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
     if (pl->inner)
         return fail(SPMV_HIP_ERR_STATE, "plan is already repacked");
+    // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
+    if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
+        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
+        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES))) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        unsigned long long * d_count = nullptr;
+        unsigned long long count[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMalloc((void **) &d_count, sizeof(count)));
+        hipError_t e = hipMemsetAsync(d_count, 0, sizeof(count), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
+                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(d_count);
+        if (e != hipSuccess)
+            return fail_hip(e, "block tiles");
+        pl->block_tiles = (int) count[2];
+        pl->block_entries = (long long) count[3];
+        // Block tiles and block windows (x staged through LDS per 16 tiles, 10 bytes per entry) want the same narrow tiles: where
+        // most of the matrix consists of blocks the windows are given up -- 8.2 bytes per entry and no second launch
+        if (pl->d_blocks && 2 * (long long) count[0] > pl->ntiles) {
+            hipLaunchKernelGGL(spmv::csr_clear_blockwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            (void) hipFree(pl->d_blocks);
+            pl->d_blocks = nullptr;
+            pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nblocks16 * sizeof(int2));
+            pl->nblocks16 = 0;
+            pl->blockwin_tiles = 0;
+            if (pl->d_rest_tiles) {
+                (void) hipFree(pl->d_rest_tiles);
+                pl->d_rest_tiles = nullptr;
+                pl->nrest_tiles = 0;
+            }
+            pl->block_tiles = (int) count[0];
+            pl->block_entries = (long long) count[1];
+        }
+        if (pl->block_cuts > 0 && 2 * (long long) count[0] < pl->ntiles) {
+            // The hint was wrong (rows in equal triples, but no 3 x 3 blocks: a scalar mesh, a band) AND it made tiles shorter
+            // than they would have been: the tiles are built once more without it, from row_ptr fetched back from the device,
+            // and classified again -- plan time only, and only for such matrices.
+            std::vector<int32_t> hp((size_t) pl->rows + 1);
+            HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (void * q : {(void *) pl->d_tiles, (void *) pl->d_col16, (void *) pl->d_patterns, (void *) pl->d_blocks, (void *) pl->d_segblocks,
+                             (void *) pl->d_rest_tiles})
+                if (q)
+                    (void) hipFree(q);
+            pl->d_tiles = nullptr; pl->d_col16 = nullptr; pl->d_patterns = nullptr; pl->d_blocks = nullptr; pl->d_segblocks = nullptr;
+            pl->d_rest_tiles = nullptr;
+            pl->ntiles = pl->nblk = pl->workgroups = 0;
+            pl->narrow_tiles = pl->shifted_tiles = pl->xwin_tiles = pl->longest_tile_row = pl->spread_tiles = 0;
+            pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
+            pl->uniform_tiles = pl->split_rows = pl->long_blocks = 0;
+            pl->balanced = false;
+            pl->block_hint = pl->block_cuts = pl->block_tiles = 0;
+            pl->block_entries = 0;
+            pl->meta_bytes = 0;
+            pl->compressed_from = nullptr;
+            pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
+            int rc = build_wave_tiles(pl, hp.data(), pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
+            if (rc == SPMV_HIP_OK)
+                rc = plan_account(pl, false);
+            if (rc == SPMV_HIP_OK)
+                rc = spmv_hip_plan_csr_compress(pl, d_column_index, stream);
+            if (rc != SPMV_HIP_OK)
+                return rc;
+        } else if (pl->block_tiles > 0) {
+            int rc = plan_account(pl, true);
+            if (rc != SPMV_HIP_OK)
+                return rc;
+        }
+    }
     // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
     // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
     const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
@@ -1072,14 +1200,15 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[25] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[27] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
-                           pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0};
-    for (int i = 0; i < n && i < 25; ++i)
+                           pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
+                           pl->nvalues > 0 ? 0 : pl->block_entries};
+    for (int i = 0; i < n && i < 27; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -1,0 +1,239 @@
+"""Block tiles (csr_blocktile.hpp): matrices of dense 3 x 3 blocks -- three unknowns per mesh node, Queen_4147's kind -- read
+one 16-bit number per BLOCK instead of a column index per entry, and no row_ptr.  The plan only takes a hint from row_ptr
+(rows in triples of equal length); spmv_hip_plan_csr_repack then checks every tile entry by entry before it marks it.
+
+Checked here against the oracle (src/matrix/csr-matrix-spmv.cpp:21-33 restated in oracle/spmv_oracle.c): meshes with 6 ... 56
+blocks per row (1 ... 9 block rows per tile), tiles whose structure is broken in one place (one column moved, one row of a
+triple longer, a block off the 3-grid) and must fall back alone, rows of <= 16 entries (never block tiles: bit-exact), the
+exact-order flag, accumulation, y_out != y_in, another column array at spmv time (nothing derived may be used), the
+context uploads (CSR, COO), and a matrix with a value dictionary (its launch ignores the marks)."""
+import numpy as np
+import pytest
+
+from helpers import assert_bitexact, assert_close, abs_products
+from spmv_amd import capi, hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def fem3(nodes, nbr_lo, nbr_hi, seed, reach=1500):
+    """3 unknowns per node; node n is linked to a random sorted set of nbr_lo..nbr_hi nodes within `reach` (itself included):
+    rows 3n .. 3n+2 carry the columns 3m .. 3m+2 of every linked node m."""
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(nbr_lo, nbr_hi + 1, size=nodes)
+    ptr = np.zeros(nodes + 1, dtype=np.int64)
+    np.cumsum(cnt, out=ptr[1:])
+    nbr = np.empty(int(ptr[-1]), dtype=np.int64)
+    for n in range(nodes):
+        lo, hi = max(0, n - reach), min(nodes, n + reach + 1)
+        pick = rng.choice(hi - lo, size=min(cnt[n], hi - lo), replace=False) + lo
+        pick[0] = n
+        pick = np.unique(pick)
+        while len(pick) < cnt[n]:  # duplicates of n removed: top up
+            extra = rng.integers(lo, hi)
+            pick = np.unique(np.append(pick, extra))
+        nbr[ptr[n]:ptr[n + 1]] = pick[:cnt[n]]
+    lens = np.repeat(3 * cnt, 3)
+    p = np.zeros(3 * nodes + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    c = np.empty(int(p[-1]), dtype=np.int32)
+    for n in range(nodes):
+        cols = (3 * nbr[ptr[n]:ptr[n + 1]][:, None] + np.arange(3)[None, :]).ravel()
+        for a in range(3):
+            c[p[3 * n + a]:p[3 * n + a + 1]] = cols
+    v = rng.uniform(-1.0, 1.0, size=len(c))
+    return 3 * nodes, 3 * nodes, p.astype(np.int32), c, v
+
+
+def run_plan(rows, cols, p, c, v, x, y0, flags=0, runs=1, other_columns=False, out_of_place=False, index_values=True):
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+    plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+    plan.compress(tc.data_ptr(), stream)
+    plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+    if index_values:
+        plan.index_values(tv.data_ptr(), stream)
+    info = plan.info()
+    cols_now = tc.clone() if other_columns else tc
+    ty = torch.from_numpy(y0.copy()).to(dev)
+    if out_of_place:
+        tout = torch.full((rows,), np.nan, dtype=torch.float64, device=dev)
+        plan.spmv_out(tp.data_ptr(), cols_now.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), tout.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert_bitexact(ty.cpu().numpy(), y0, "y_in untouched")
+        ty = tout
+    else:
+        for _ in range(runs):
+            plan.spmv(tp.data_ptr(), cols_now.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    got = ty.cpu().numpy()
+    plan.close()
+    return got, info
+
+
+@pytest.mark.parametrize("name,lo,hi,nodes", [("27 per node", 27, 27, 6000), ("20-34 per node", 20, 34, 6000), ("6-12 per node", 6, 12, 9000),
+                                              ("6 per node", 6, 6, 9000), ("40-56 per node", 40, 56, 3000), ("mixed 6-56", 6, 56, 5000)])
+def test_block_tiles_against_oracle(oracle, name, lo, hi, nodes):
+    rows, cols, p, c, v = fem3(nodes, lo, hi, seed=len(name))
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["block_tiles"] >= 0.95 * info["row_blocks"], (name, info)
+    assert info["block_entries"] >= 0.95 * info["nnz"], (name, info)
+    assert_close(got, want, scale, what=name, nterms=3 * hi)
+    # fewer bytes than the same plan without them: 8 + 2/9 instead of 8 + 2 (+ row_ptr) per entry
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES)
+    assert info_n["block_tiles"] == 0
+    assert info["streamed_bytes"] < info_n["streamed_bytes"] - 1.5 * info["nnz"], (info["streamed_bytes"], info_n["streamed_bytes"])
+    assert_close(got_n, want, scale, what=name + ", no block tiles", nterms=3 * hi)
+    # the exact-order flag: no block tiles, one lane per row, the reference's bits
+    got_e, info_e = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER)
+    assert info_e["block_tiles"] == 0
+    assert_bitexact(got_e, want, name + ", exact order")
+    # accumulating twice, and y_out = y_in + A x
+    got2, _ = run_plan(rows, cols, p, c, v, x, y0, runs=2)
+    assert_close(got2, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), 2 * scale, what=name + ", two runs", nterms=6 * hi)
+    got_o, _ = run_plan(rows, cols, p, c, v, x, y0, out_of_place=True)
+    assert np.array_equal(got_o.view(np.uint64), got.view(np.uint64)), name + ": y_out differs from the in-place result"
+    # another column array at the same multiply: nothing derived from the plan's columns may be used
+    got_c, _ = run_plan(rows, cols, p, c, v, x, y0, other_columns=True)
+    assert_close(got_c, want, scale, what=name + ", other column array", nterms=3 * hi)
+
+
+def test_broken_tiles_fall_back_alone(oracle):
+    """One column moved inside a block, one block off the 3-grid, one row of a triple a copy of ANOTHER row pattern: the tile that
+    holds the damage loses its mark (the check is entry by entry), its neighbours keep theirs, y matches the oracle."""
+    rows, cols, p, c, v = fem3(6000, 24, 30, seed=11)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    _, clean = run_plan(rows, cols, p, c, v, x, y0)
+    assert clean["block_tiles"] >= 0.95 * clean["row_blocks"]
+    damaged = 0
+    for what, node in (("column moved", 1000), ("block off the grid", 2500), ("row differs from its triple", 4000)):
+        c2 = c.copy()
+        r = 3 * node + 1
+        k = int(p[r]) + 4  # second entry of the row's second block
+        if what == "column moved":
+            c2[k] = c2[k - 1]  # a duplicate column: still a valid CSR matrix, no longer a run c, c+1, c+2
+        elif what == "block off the grid":
+            # move a whole block (in all three rows) one column to the right where there is room
+            for a in range(3):
+                q = int(p[3 * node + a]) + 3 * (int(p[3 * node + 1] - p[3 * node]) // 3 - 1)  # the row's last block
+                c2[q:q + 3] = np.minimum(c2[q:q + 3] + 1, cols - 1)
+        else:
+            q = int(p[r])
+            c2[q:q + 3] = c2[q + 3:q + 6]  # first block repeats the second one's columns in this row only
+        got, info = run_plan(rows, cols, p, c2, v, x, y0)
+        assert clean["block_tiles"] - 2 <= info["block_tiles"] < clean["block_tiles"], (what, clean["block_tiles"], info["block_tiles"])
+        damaged += 1
+        assert_close(got, oracle.csr_spmv(rows, p, c2, v, x, y=y0, num_threads=4), abs_products(rows, p, c2, v, x) + np.abs(y0), what=what)
+    assert damaged == 3
+    # a triple whose rows differ in LENGTH: the hint survives (one triple in 6000), the tile does not qualify
+    lens = np.diff(p).astype(np.int64)
+    r = 3 * 3000
+    keep = np.ones(len(c), dtype=bool)
+    keep[int(p[r + 2]) + 3:int(p[r + 2]) + 6] = False  # third row of the triple loses a block
+    lens[r + 2] -= 3
+    p3 = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p3[1:])
+    p3 = p3.astype(np.int32)
+    c3, v3 = c[keep], v[keep]
+    got, info = run_plan(rows, cols, p3, c3, v3, x, y0)
+    assert info["block_tiles"] > 0.9 * clean["block_tiles"], (clean, info)
+    assert info["row_blocks"] - info["block_tiles"] > clean["row_blocks"] - clean["block_tiles"], (clean, info)
+    assert_close(got, oracle.csr_spmv(rows, p3, c3, v3, x, y=y0, num_threads=4), abs_products(rows, p3, c3, v3, x) + np.abs(y0), what="ragged triple")
+
+
+def test_short_block_rows_stay_bit_exact(oracle):
+    """Rows of at most 16 entries (5 blocks) keep their one-lane-per-row tiles: no block tiles, the reference's bits."""
+    rows, cols, p, c, v = fem3(9000, 3, 5, seed=5)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["block_tiles"] == 0, info
+    assert_bitexact(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), "rows of <= 15 entries")
+
+
+def test_no_hint_no_block_tiles_and_scalar_meshes(oracle):
+    """A matrix whose rows do not come in equal triples gets no hint (the tiles are cut as ever), and one that does but has no
+    3 x 3 blocks (a scalar 27-point mesh with 3 N rows) gets the hint, no marks, and the same y."""
+    rows, cols, p, c, v = synth.stencil27_like(30, 30, 30)
+    x = synth.x_vector(cols, seed=3)
+    y0 = np.zeros(rows)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["block_tiles"] == 0
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, num_threads=4), abs_products(rows, p, c, v, x), what="27-point")
+    rows, cols, p, c, v = synth.banded(30000, list(range(-13, 14)), seed=2)  # 27 per row: triples of equal length, divisible by 3
+    x = synth.x_vector(cols, seed=3)
+    got, info = run_plan(rows, cols, p, c, v, x, np.zeros(rows), flags=capi.FLAG_NO_SHIFTED_TILES)
+    assert info["block_tiles"] == 0, info
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, num_threads=4), abs_products(rows, p, c, v, x), what="band of 27")
+
+
+def test_wrong_hint_rebuilds_the_tiles(oracle):
+    """Rows of 120 entries in equal triples but NO blocks (a scalar matrix): the hint cuts 4-row tiles down to 3 rows, the check
+    finds no block anywhere, and repack builds the tiles once more without the hint -- the plan ends up exactly as if the
+    hint had never been taken: same tiles, same bits."""
+    rng = np.random.default_rng(8)
+    rows = cols = 30000
+    L = 120
+    c = np.sort(np.clip(np.arange(rows)[:, None] + rng.choice(np.arange(-4000, 4000), size=(rows, L)), 0, cols - 1), axis=1)
+    c = c.astype(np.int32).ravel()
+    p = (np.arange(rows + 1, dtype=np.int64) * L).astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=len(c))
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES)
+    assert info["block_tiles"] == 0 and info["row_blocks"] == info_n["row_blocks"] == rows // 4, (info, info_n)
+    assert_bitexact(got, got_n, "rebuilt plan against the plan without the hint")
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="scalar rows of 120", nterms=L)
+
+
+def test_queen_like_generator_and_context_uploads(oracle):
+    """The Queen_4147 stand-in at a small size through the Level-2 plan and through the context API (CSR and COO uploads: the
+    sorted triplets run as the same row-major tiles)."""
+    M = hostapi.load("synthetic:queen:30,24,20", "csr")
+    rows, cols, p, c, v = M.rows, M.cols, np.array(M.row_ptr), np.array(M.column_index), np.array(M.value)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["block_tiles"] >= 0.9 * info["row_blocks"], info
+    assert_close(got, want, scale, what="queen-like, plan")
+    with capi.Context(0) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what="queen-like, context CSR")
+        i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(len(a))
+        ctx.upload_coo(rows, cols, np.ascontiguousarray((i - 1)[perm].astype(np.int32)), np.ascontiguousarray((j - 1)[perm].astype(np.int32)),
+                       np.ascontiguousarray(a[perm]))
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what="queen-like, context COO (shuffled)")
+    M.close()
+
+
+def test_block_structure_with_a_value_dictionary(oracle):
+    """Few distinct values: the dictionary launch has no block path and must ignore the marks (16-bit columns intact)."""
+    rows, cols, p, c, v = fem3(5000, 20, 30, seed=21)
+    rng = np.random.default_rng(2)
+    v = np.array([-1.0, 0.5, 2.0, 0.125])[rng.integers(0, 4, size=len(v))]
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["indexed_values"] == 4 and info["block_tiles"] == 0, info  # (reported as 0: the launch does not use them)
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="dictionary")
+    got_g, info_g = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_VALUE_INDEX)
+    assert info_g["block_tiles"] > 0
+    assert_close(got_g, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="values read")
