@@ -130,6 +130,17 @@ extern "C" {
                                              BLOCK instead of a column index per entry and no row_ptr (8.2 instead of 10 bytes per
                                              entry).  Only rows of more than 16 entries (1e-10 class either way); never under
                                              SPMV_HIP_FLAG_EXACT_ORDER */
+#define SPMV_HIP_FLAG_HUB_COLUMNS 0x4000000u /* plan_csr_compress, OPT-IN: hub columns.  A plan with balanced tiles (a graph matrix)
+                                             whose x is larger than an XCD's L2 counts the references to every column; the columns
+                                             with >= 8 of them (at most 2^18, carrying >= 10 % of the entries) become hubs: the plan
+                                             keeps its own column stream, every multiply first copies the hubs' x entries into a
+                                             dense plan-owned array (a second, small launch) and the tiles read them from there --
+                                             one line of x per sixteen hubs in every L2 instead of one per hub.  Same bits.  Off by
+                                             default because it was measured SLOWER on the webbase-like matrix (26.6 vs 23.9 us:
+                                             the traffic above the algorithmic bytes there is the long TAIL of rarely referenced
+                                             columns -- nearly every line of x ends up in every XCD's L2 -- not the head; DESIGN.md
+                                             section 3.3).  The dense array is scratch: multiplies through ONE plan must then be
+                                             ordered (same stream), like the runs of a context.  plan_info[27], [28] */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -345,7 +356,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [23] with a value dictionary: tiles whose rows all repeat the first row's values (constant-coefficient stencils) --
  *             they read no index stream at all, only the first row's bytes
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
- *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries */
+ *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries
+ *        [27] hub columns (see SPMV_HIP_FLAG_HUB_COLUMNS)  [28] the entries that refer to them */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

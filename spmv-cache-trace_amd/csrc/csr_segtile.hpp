@@ -2,6 +2,7 @@
 #pragma once
 
 #include "tile_common.hpp"
+#include "csr_hub.hpp"
 
 namespace spmv {
 
@@ -32,12 +33,15 @@ constexpr int kTileMetaSeg = 1 << 21;
 
 // VI: the plan holds a value dictionary (a pattern / graph matrix: all ones; few distinct weights): the stream tiles read one index
 // byte per entry instead of eight bytes of value (see csr_wavetile_kernel); long rows keep reading the values themselves.
-template <bool C16, bool X32, bool XCD, bool VI = false>
+// HUB: the plan holds hub columns (csr_hub.hpp): tiles with 32-bit columns read the plan's own column stream `jh`, in which a hub
+// column is 0x80000000 | its number in the dense copy `hubx` (filled by hub_gather_kernel just before this launch).
+template <bool C16, bool X32, bool XCD, bool VI = false, bool HUB = false>
 __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in, double * y,
-    int nnz_total, int cols, const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0)
+    int nnz_total, int cols, const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0,
+    const int32_t * __restrict__ jh = nullptr, const double * __restrict__ hubx = nullptr)
 {
     constexpr int TILE = 512, QUADS = 2, RPL = kSegMaxRows / kWave; // rows per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
         const int last = (k1 - 1 - kb) & ~3;
         if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, 0, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);
+        else if (HUB)
+            tile_products_wide_hub<QUADS, VI>(prod, jh + kb, a + kb, x, hubx, last, lane, vidx + kb, vtab);
         else
             tile_products_wide<QUADS, X32, VI>(prod, j + kb, a + kb, x, last, lane, vidx + kb, vtab);
         // (3) every non-empty row marks the slot of its first entry

@@ -43,7 +43,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -109,6 +109,14 @@ struct spmv_hip_plan {
     int uniform_tiles = 0; // tiles whose rows are all equally long: row_ptr is not read for them
     int split_rows = 0;    // rows cut into chunks that are added to y with atomics
     bool balanced = false; // tiles filled by entries, row sums by segmented reduction (csr_segtile_kernel)
+    // hub columns (csr_hub.hpp; balanced plans of graph matrices): the plan's own column stream with hubs renumbered, the hub
+    // columns, and the dense copy of their x entries -- SCRATCH written by every multiply: multiplies through one plan must be
+    // ordered (one stream, or the caller's own ordering), like the runs of a context
+    int32_t * d_colh = nullptr;
+    int32_t * d_hub_column = nullptr;
+    double * d_hubx = nullptr;
+    int nhubs = 0, hub_threshold = 0;
+    long long hub_entries = 0;
     // block tiles (csr_blocktile.hpp): rows in triples of equal length (a hint from row_ptr at plan time), checked against
     // the columns and marked by spmv_hip_plan_csr_repack; their block stream lives behind the 16-bit columns in d_col16
     int block_hint = 0;

@@ -162,7 +162,19 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
     hipLaunchKernelGGL((spmv::csr_segtile_kernel<C, X, R>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols)
 #define SPMV_SEG_X(C, R) do { if (x32) SPMV_SEG_LAUNCH(C, true, R); else SPMV_SEG_LAUNCH(C, false, R); } while (0)
 #define SPMV_SEG_C(R) do { if (c16) SPMV_SEG_X(true, R); else SPMV_SEG_X(false, R); } while (0)
-            if (c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a)
+            const bool vi = c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a;
+            if (c16 && x32 && !xcd && pl->nhubs > 0) {
+                // hub columns: the dense copy of their x entries first (every multiply: x is the caller's), then the tiles
+                hipLaunchKernelGGL(spmv::hub_gather_kernel, dim3((unsigned) ((pl->nhubs + 255) / 256)), dim3(256), 0, s, pl->nhubs, pl->d_hub_column, x,
+                                   pl->d_hubx);
+                if (vi)
+                    hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, true, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j,
+                                       pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, pl->d_vidx, pl->d_vtab, pl->nvalues, pl->d_colh, pl->d_hubx);
+                else
+                    hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j,
+                                       pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, (const uint8_t *) nullptr, (const double *) nullptr, 0, pl->d_colh,
+                                       pl->d_hubx);
+            } else if (vi)
                 // a value dictionary (pattern / graph matrices): one index byte per entry instead of eight bytes of value
                 hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16,
                                    a, x, y_in, y, pl->nnz, pl->cols, pl->d_vidx, pl->d_vtab, pl->nvalues);

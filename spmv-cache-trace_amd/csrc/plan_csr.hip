@@ -161,6 +161,8 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             : (pl->nvalues > 0 && stream_tile) ? entries : 8 * entries;
         bytes += val_bytes + col_bytes + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
     }
+    if (pl->nhubs > 0) // the dense copy: hub columns read, their x entries read and written, then read by the tiles (once)
+        bytes += 20LL * pl->nhubs;
     pl->streamed_bytes = bytes;
     // plans with block or segment windows: the list of tiles left to csr_wavetile_kernel (made once, right after marking)
     if (!vi_tiles && compressed && (pl->d_blocks || pl->d_segblocks) && !pl->d_rest_tiles && pl->blockwin_tiles < pl->ntiles) {
@@ -545,6 +547,12 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_vtab);
     if (pl->d_tiles_vi)
         (void) hipFree(pl->d_tiles_vi);
+    if (pl->d_colh)
+        (void) hipFree(pl->d_colh);
+    if (pl->d_hub_column)
+        (void) hipFree(pl->d_hub_column);
+    if (pl->d_hubx)
+        (void) hipFree(pl->d_hubx);
     if (pl->inner)
         spmv_hip_plan_destroy(pl->inner);
     if (pl->d_vrow_ptr)
@@ -554,6 +562,85 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
     if (pl->d_pval)
         (void) hipFree(pl->d_pval);
     delete pl;
+}
+
+int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
+
+// Hub columns (csr_hub.hpp; opt-in, SPMV_HIP_FLAG_HUB_COLUMNS) for balanced plans -- graph matrices -- whose x does not fit an XCD's L2: in-degrees, the columns
+// with at least `threshold` references (8, doubled while more than 2^18 qualify), the plan's own column stream.  Nothing is kept
+// unless the hubs are few (<= 2^18: 2 MB of x, resident in every L2) and carry a share of the entries worth a second launch
+// per multiply (>= 10 %).
+static int plan_hub_columns(spmv_hip_plan * pl, const int32_t * d_column_index, hipStream_t s)
+{
+    if (!pl->balanced || pl->tile != 512 || !(pl->flags & SPMV_HIP_FLAG_HUB_COLUMNS) || (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) || pl->nnz < (1 << 20)
+        || (long long) pl->cols * 8 < 4LL * 1024 * 1024 || pl->cols >= (1 << 29))
+        return SPMV_HIP_OK;
+    int32_t * d_degree = nullptr, * d_flag = nullptr, * d_slot = nullptr;
+    unsigned long long * d_stats = nullptr;
+    unsigned long long stats[2] = {0, 0};
+    const int cols = pl->cols;
+    const unsigned cgrid = (unsigned) ((cols + 255) / 256);
+    hipError_t e = hipMalloc((void **) &d_degree, (size_t) cols * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_flag, ((size_t) cols + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_slot, ((size_t) cols + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_stats, sizeof(stats));
+    if (e == hipSuccess) e = hipMemsetAsync(d_degree, 0, (size_t) cols * sizeof(int32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, ((size_t) cols + 1) * sizeof(int32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmv::hub_count_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 16)), dim3(256), 0, s, (long long) pl->nnz,
+                           d_column_index, d_degree);
+        e = hipGetLastError();
+    }
+    int threshold = 8;
+    int rc = SPMV_HIP_OK;
+    for (int attempt = 0; e == hipSuccess && attempt < 6; ++attempt, threshold *= 2) {
+        e = hipMemsetAsync(d_stats, 0, sizeof(stats), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::hub_flag_kernel, dim3(cgrid), dim3(256), 0, s, cols, d_degree, threshold, d_flag, d_stats);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess || stats[0] <= (1u << 18))
+            break;
+    }
+    const bool take = e == hipSuccess && stats[0] >= 256 && stats[0] <= (1u << 18) && 10 * stats[1] >= (unsigned long long) pl->nnz;
+    if (take) {
+        const int nhubs = (int) stats[0];
+        if (spmv_hip_internal_exclusive_scan_i32(d_flag, d_slot, (long long) cols + 1, s) != 0)
+            e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_colh, (size_t) pl->nnz * sizeof(int32_t) + 64);
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_hub_column, (size_t) nhubs * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **) &pl->d_hubx, (size_t) nhubs * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(pl->d_colh, 0, (size_t) pl->nnz * sizeof(int32_t) + 64, s);
+        if (e == hipSuccess) e = hipMemsetAsync(pl->d_hubx, 0, (size_t) nhubs * sizeof(double), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::hub_list_kernel, dim3(cgrid), dim3(256), 0, s, cols, d_flag, d_slot, pl->d_hub_column);
+            hipLaunchKernelGGL(spmv::hub_remap_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 16)), dim3(256), 0, s, (long long) pl->nnz,
+                               d_column_index, d_flag, d_slot, pl->d_colh);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            pl->nhubs = nhubs;
+            pl->hub_threshold = threshold;
+            pl->hub_entries = (long long) stats[1];
+            pl->meta_bytes += (size_t) pl->nnz * sizeof(int32_t) + 64 + (size_t) nhubs * 12;
+        } else {
+            for (void * q : {(void *) pl->d_colh, (void *) pl->d_hub_column, (void *) pl->d_hubx})
+                if (q)
+                    (void) hipFree(q);
+            pl->d_colh = nullptr;
+            pl->d_hub_column = nullptr;
+            pl->d_hubx = nullptr;
+        }
+    }
+    for (void * q : {(void *) d_degree, (void *) d_flag, (void *) d_slot, (void *) d_stats})
+        if (q)
+            (void) hipFree(q);
+    if (e != hipSuccess)
+        rc = fail_hip(e, "hub columns");
+    return rc;
 }
 
 int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
@@ -759,6 +846,8 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->meta_bytes += bytes;
     pl->compressed_from = d_column_index;
     int rc = device_column_checksum(d_column_index, pl->nnz, &pl->column_checksum, s);
+    if (rc == SPMV_HIP_OK)
+        rc = plan_hub_columns(pl, d_column_index, s);
     if (rc == SPMV_HIP_OK)
         rc = plan_account(pl, true);
     pl->verify_pending = true;
@@ -1088,7 +1177,17 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     if (e == hipSuccess) e = hipMalloc((void **) &d_state, sizeof(state));
     if (e == hipSuccess) e = hipMemcpyAsync(d_keys, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(state), s);
-    if (e == hipSuccess) {
+    // A matrix with more distinct values than the dictionary holds gives itself away within its first few thousand entries:
+    // one workgroup looks at a prefix first.  (Without it the whole grid's first entries all insert at once -- half a million
+    // threads contending for the table's 1024 slots before anybody sees the verdict: 8.5 ms on a 3 M-entry web graph, 11 ms on
+    // the queen-like matrix, for a "no".)
+    if (e == hipSuccess && pl->nnz > 16384) {
+        hipLaunchKernelGGL(spmv::value_dict_insert_kernel, dim3(1), dim3(256), 0, s, 8192LL, d_value, d_keys, d_state, spmv::kMaxIndexedValues);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(state, d_state, sizeof(state), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess && state[1] == 0) {
         hipLaunchKernelGGL(spmv::value_dict_insert_kernel, dim3((unsigned) grid_for(pl->nnz, kBlock, cu_count() * 8)), dim3(256), 0, s,
                            (long long) pl->nnz, d_value, d_keys, d_state, spmv::kMaxIndexedValues);
         e = hipGetLastError();
@@ -1200,15 +1299,15 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[27] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[29] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
-                           pl->nvalues > 0 ? 0 : pl->block_entries};
-    for (int i = 0; i < n && i < 27; ++i)
+                           pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries};
+    for (int i = 0; i < n && i < 29; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

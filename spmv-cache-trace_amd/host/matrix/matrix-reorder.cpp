@@ -132,14 +132,103 @@ std::vector<int> find_new_order_RCM(Matrix const & m, std::ostream & log, bool v
     return new_order;
 }
 
-std::vector<int> find_new_order_GP(Matrix const & m, int, std::ostream & log, bool)
+// "__GP<n>": rows clustered by a k-way partition of the matrix's graph, parts one after the other, the original order kept inside
+// a part -- what the reference does with the partition vector METIS_PartGraphKway returns (matrix-market-reorder.cpp:183-279:
+// `permutation[offset[part[i]]++] = i; new_order[permutation[i]] = i`).  METIS is a third-party library that is neither vendored
+// in the reference nor installed here; a reference build without it leaves the order unchanged (:172-181).  This build has its
+// own partitioner instead -- greedy graph growing: the graph is made undirected; a part starts at the unassigned node of
+// smallest degree (lowest index first) and grows breadth-first, neighbours in adjacency order, until it holds ceil(n / k)
+// nodes; the next part starts from the oldest node still waiting in the frontier (so parts are neighbours), or, when the
+// frontier is empty (a new component), again from the smallest degree.  Deterministic; balanced to within one node; NOT the
+// partition METIS would return (whose result depends on its version and seed anyway): a documented stand-in, compared with
+// the identity and with RCM in tests/test_host.py and profiles/r04_reordering.md.
+std::vector<int> find_new_order_GP(Matrix const & m, int nparts, std::ostream & log, bool verbose)
 {
     require_square_real(m);
-    // same outcome as the reference built without USE_METIS (matrix-market-reorder.cpp:172-181)
-    log << "Warning: No reordering is done. Graph partitioning needs METIS, which this build does not have\n";
-    std::vector<int> same((std::size_t) m.rows());
-    std::iota(same.begin(), same.end(), 0);
-    return same;
+    int const n = m.rows();
+    auto const & ri = m.row_indices();
+    auto const & ci = m.column_indices();
+    for (std::size_t k = 0; k < ri.size(); ++k)
+        if (ri[k] < 1 || ri[k] > n || ci[k] < 1 || ci[k] > n)
+            throw matrix_error("Row or column index out of bounds");
+    if (nparts <= 1)
+        nparts = 16; // the reference's default (:237-238)
+    nparts = std::min(nparts, std::max(n, 1));
+    // undirected adjacency (both directions of every off-diagonal entry; duplicates are harmless)
+    std::vector<std::size_t> first((std::size_t) n + 1, 0);
+    for (std::size_t k = 0; k < ri.size(); ++k)
+        if (ri[k] != ci[k]) {
+            ++first[(std::size_t) ri[k]];
+            ++first[(std::size_t) ci[k]];
+        }
+    for (int v = 0; v < n; ++v)
+        first[(std::size_t) v + 1] += first[(std::size_t) v];
+    std::vector<int> adjacency(first[(std::size_t) n]);
+    {
+        std::vector<std::size_t> fill(first.begin(), first.end() - 1);
+        for (std::size_t k = 0; k < ri.size(); ++k)
+            if (ri[k] != ci[k]) {
+                adjacency[fill[(std::size_t) ri[k] - 1]++] = ci[k] - 1;
+                adjacency[fill[(std::size_t) ci[k] - 1]++] = ri[k] - 1;
+            }
+    }
+    if (verbose)
+        log << "Number of rows=" << n << " columns=" << m.columns() << " entries=" << ri.size() << '\n'
+            << "Growing " << nparts << " parts breadth-first (this build's stand-in for METIS_PartGraphKway)\n";
+    std::vector<int> by_degree((std::size_t) n);
+    std::iota(by_degree.begin(), by_degree.end(), 0);
+    std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) {
+        return first[(std::size_t) a + 1] - first[(std::size_t) a] < first[(std::size_t) b + 1] - first[(std::size_t) b];
+    });
+    std::size_t next_start = 0;
+    std::vector<int> part((std::size_t) n, -1);
+    std::vector<char> queued((std::size_t) n, 0);
+    std::queue<int> frontier;
+    long long assigned = 0;
+    for (int q = 0; q < nparts && assigned < n; ++q) {
+        // sizes differ by at most one: the first n % k parts take one node more
+        long long const want = n / nparts + (q < n % nparts ? 1 : 0);
+        long long have = 0;
+        while (have < want) {
+            int v = -1;
+            while (!frontier.empty() && v < 0) {
+                if (part[(std::size_t) frontier.front()] < 0)
+                    v = frontier.front();
+                frontier.pop();
+            }
+            if (v < 0) {
+                while (part[(std::size_t) by_degree[next_start]] >= 0)
+                    ++next_start;
+                v = by_degree[next_start];
+            }
+            part[(std::size_t) v] = q;
+            ++have;
+            ++assigned;
+            for (std::size_t e = first[(std::size_t) v]; e < first[(std::size_t) v + 1]; ++e) {
+                int const w = adjacency[e];
+                if (part[(std::size_t) w] < 0 && !queued[(std::size_t) w]) {
+                    queued[(std::size_t) w] = 1;
+                    frontier.push(w);
+                }
+            }
+        }
+    }
+    // parts one after the other, file order inside a part (the reference's two loops)
+    std::vector<long long> offset((std::size_t) nparts + 1, 0);
+    for (int v = 0; v < n; ++v)
+        ++offset[(std::size_t) part[(std::size_t) v] + 1];
+    for (int q = 0; q < nparts; ++q)
+        offset[(std::size_t) q + 1] += offset[(std::size_t) q];
+    std::vector<int> new_order((std::size_t) n, -1);
+    for (int v = 0; v < n; ++v)
+        new_order[(std::size_t) v] = (int) offset[(std::size_t) part[(std::size_t) v]]++;
+    if (verbose) {
+        long long cut = 0;
+        for (std::size_t k = 0; k < ri.size(); ++k)
+            cut += part[(std::size_t) ri[k] - 1] != part[(std::size_t) ci[k] - 1];
+        log << "Entries whose row and column lie in different parts: " << cut << " of " << ri.size() << '\n';
+    }
+    return new_order;
 }
 
 Matrix permute(Matrix const & m, std::vector<int> const & new_order)

@@ -4,8 +4,11 @@
 // "__GP<n>" (METIS k-way partition) -- src/matrix/matrix-market.cpp:782-802,
 // src/matrix/matrix-market-reorder.cpp.  RCM is reproduced step for step (same start-node rule,
 // same neighbour ordering by out-degree through std::sort, same reversal), so that the
-// permutation is the one the reference computes with this toolchain.  METIS is not available
-// here; like a reference build without USE_METIS, "__GP" leaves the order unchanged and says so.
+// permutation is the one the reference computes with this toolchain.  METIS -- a third-party
+// library the reference links optionally -- is not available here; where a reference build
+// without USE_METIS leaves the order unchanged, "__GP<n>" here clusters the rows with the repo's
+// own k-way partitioner (greedy graph growing, matrix-reorder.cpp) and orders them exactly as
+// the reference orders METIS's parts: a documented stand-in, not METIS's partition.
 //
 // Why it matters on a GPU: reordering narrows the band, which shortens the x window of a tile
 // (more tiles qualify for 16-bit column offsets) and turns scattered gathers into cache hits.

@@ -455,6 +455,69 @@ csr_matrix::Matrix banded(long long N, long long b, std::uint64_t seed, long lon
     return build(N, N, rb, re, len, fill);
 }
 
+// ---- scrambled: banded(N, b, seed) with rows and columns renumbered by a pseudo-random permutation: P B P^T ----------------
+// What a mesh matrix looks like whose nodes were numbered in no particular order: every row still has its 2b + 1 entries, but
+// they are scattered over the whole index space and no two rows are shifted copies of each other -- the input the reordering
+// suffixes (file__RCM, file__GP<n>) exist for.  The permutation is a four-round Feistel network on the smallest even number of
+// bits that holds N, walked until it lands below N (a bijection of [0, N) with a cheap inverse; an affine map r -> r P + c
+// would keep consecutive rows shifted copies of each other, which the kernels exploit).
+csr_matrix::Matrix scrambled(long long N, long long b, std::uint64_t seed, long long rb, long long re, long long * total)
+{
+    if (N < 1 || N > INT32_MAX || b < 0 || 2 * b + 1 > 4096)
+        throw matrix::matrix_error("synthetic:scrambled:<N>,<b>[,seed]: 1 <= N <= 2^31-1, 0 <= b <= 2047");
+    if (total) *total = N;
+    if (re < 0) re = N;
+    int half = 1;
+    while ((1LL << (2 * half)) < N)
+        ++half;
+    std::uint64_t const mask = (1ull << half) - 1, key = seed * 0xD6E8FEB86659FD93ull + 0x5C4A;
+    auto round_fn = [=](std::uint64_t v, int k) { return h2(key + (std::uint64_t) k, v) & mask; };
+    auto feistel = [=](std::uint64_t v, bool inverse) {
+        std::uint64_t l = v >> half, r = v & mask;
+        if (!inverse)
+            for (int k = 0; k < 4; ++k) {
+                std::uint64_t const t = l ^ round_fn(r, k);
+                l = r;
+                r = t;
+            }
+        else
+            for (int k = 3; k >= 0; --k) {
+                std::uint64_t const t = r ^ round_fn(l, k);
+                r = l;
+                l = t;
+            }
+        return (l << half) | r;
+    };
+    auto fwd = [=](long long r) {
+        std::uint64_t v = (std::uint64_t) r;
+        do
+            v = feistel(v, false);
+        while (v >= (std::uint64_t) N);
+        return (long long) v;
+    };
+    auto back = [=](long long q) {
+        std::uint64_t v = (std::uint64_t) q;
+        do
+            v = feistel(v, true);
+        while (v >= (std::uint64_t) N);
+        return (long long) v;
+    };
+    auto len = [=](long long q) { long long const r = back(q); return std::min(N - 1, r + b) - std::max(0LL, r - b) + 1; };
+    auto fill = [=](long long q, index_type * c, double * v) {
+        long long const r = back(q), lo = std::max(0LL, r - b), hi = std::min(N - 1, r + b);
+        std::pair<index_type, double> tmp[4096];
+        int n = 0;
+        for (long long o = lo; o <= hi; ++o)
+            tmp[n++] = {(index_type) fwd(o), u11(h2(seed * 0x9E3779B97F4A7C15ull + (std::uint64_t) r, (std::uint64_t) o))};
+        std::sort(tmp, tmp + n, [](auto const & x, auto const & y) { return x.first < y.first; });
+        for (int i = 0; i < n; ++i) {
+            c[i] = tmp[i].first;
+            v[i] = tmp[i].second;
+        }
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
 // ---- random: SURVEY 8d "S-random(N, k, seed)": k distinct uniform columns per row, ascending, values U(-1, 1) --------
 csr_matrix::Matrix random_columns(long long N, long long k, std::uint64_t seed, long long rb, long long re, long long * total)
 {
@@ -541,15 +604,16 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
         int const loc = web ? (v.size() > 3 ? (int) v[3] : 75) : 0;
         check_range(N);
         A = webbase(N, Z, maxrow, loc, web ? 4 : 1, rb, re, &tot);
-    } else if (family == "banded" || family == "random") {
+    } else if (family == "banded" || family == "random" || family == "scrambled") {
         if (v.size() < 2 || v.size() > 3)
-            throw matrix::matrix_error("synthetic:" + family + ":<N>,<" + (family == "banded" ? "b" : "k") + ">[,seed]");
+            throw matrix::matrix_error("synthetic:" + family + ":<N>,<" + (family == "random" ? "k" : "b") + ">[,seed]");
         check_range(v[0]);
         std::uint64_t const seed = v.size() > 2 ? (std::uint64_t) v[2] : 1;
-        A = family == "banded" ? banded(v[0], v[1], seed, rb, re, &tot) : random_columns(v[0], v[1], seed, rb, re, &tot);
+        A = family == "banded" ? banded(v[0], v[1], seed, rb, re, &tot)
+            : family == "scrambled" ? scrambled(v[0], v[1], seed, rb, re, &tot) : random_columns(v[0], v[1], seed, rb, re, &tot);
     } else {
         throw matrix::matrix_error("unknown synthetic matrix family '" + family +
-                                   "' (poisson2d, queen, kkt, webbase, powerlaw, banded, random)");
+                                   "' (poisson2d, queen, kkt, webbase, powerlaw, banded, scrambled, random)");
     }
     if (total)
         *total = tot;

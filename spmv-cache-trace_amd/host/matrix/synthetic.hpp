@@ -27,6 +27,8 @@
 //                                    power-law-popular pages; default 1000005,3105536,4700,75
 //   synthetic:powerlaw[:N,Z,maxrow]  the same with locality 0: uniformly scattered columns (worst case)
 //   synthetic:banded:N,b[,seed]      SURVEY 8d S-banded: N rows, the 2b + 1 diagonals -b .. +b, values U(-1,1)
+//   synthetic:scrambled:N,b[,seed]   the same band matrix with rows and columns renumbered by a pseudo-random permutation (P B P^T): what
+//                                    the reordering suffixes __RCM / __GP<n> are for
 //   synthetic:random:N,k[,seed]      SURVEY 8d S-random: k distinct uniform columns per row, ascending, values U(-1,1)
 //
 // What these are NOT: the SuiteSparse matrices themselves.  They reproduce size, row-length

@@ -160,13 +160,68 @@ def test_rcm_reordering_matches_reference(host, reflib, golden, tmp_path, case):
     assert sorted(ha.tolist()) == sorted(oa.tolist())
     if case == "scrambled_band":
         assert np.max(np.abs(hi - hj)) < np.max(np.abs(oi - oj)) / 4
-    # graph partitioning needs METIS: like a reference build without it, the order is unchanged
-    g = host.mm_load(path + "__GP8")
-    gi, gj, ga = host.mm_entries(g)
-    assert gi.tolist() == oi.tolist() and gj.tolist() == oj.tolist()
-    for x in (h, o, g):
+    for x in (h, o):
         host.mm_free(x)
     reflib.mm_free(r)
+
+
+def test_rcm_reordering_matches_the_golden_vectors(host, tmp_path):
+    """The same against tests/golden/reorder_vectors.json: what the reference library returned for <file>__RCM when the
+    fixtures were generated (tests/golden/make_reorder_golden.py) -- this test needs no reference build."""
+    import json
+    G = json.load(open(os.path.join(GOLDEN, "reorder_vectors.json")))
+    assert len(G["cases"]) >= 5
+    for case in G["cases"]:
+        text = open(os.path.join(GOLDEN, case["mtx"][1:])).read() if case["mtx"].startswith("@") else case["mtx"]
+        path = str(tmp_path / (case["name"] + ".mtx"))
+        open(path, "w").write(text)
+        h = host.mm_load(path + "__RCM")
+        hi, hj, _ = host.mm_entries(h)
+        assert hi.tolist() == case["rcm_i"] and hj.tolist() == case["rcm_j"], case["name"]
+        host.mm_free(h)
+
+
+@pytest.mark.parametrize("nparts", [2, 8, 16, 37])
+def test_graph_partition_order(host, tmp_path, nparts):
+    """<file>__GP<n>: METIS is not vendored by the reference and not installed here; where a reference build without it
+    leaves the order unchanged (src/matrix/matrix-market-reorder.cpp:172-181) this build clusters the rows with its own k-way
+    partitioner and orders them the way the reference orders METIS's parts (:253-268): parts one after the other, the file's
+    order inside a part.  Checked: a symmetric permutation; parts balanced to one row; old indices ascending inside a part;
+    far fewer entries between parts than for the scrambled numbering."""
+    n = 900
+    i, j, a = _scrambled_band(n, 5)
+    # the diagonal entry of old row r carries r: the permutation can be read off the result
+    diag = i == j
+    a = a.copy()
+    a[diag] = i[diag].astype(np.float64)
+    assert diag.sum() == n
+    path = str(tmp_path / "band.mtx")
+    synth.write_mtx(path, n, n, i, j, a)
+    g = host.mm_load(path + "__GP%d" % nparts)
+    gi, gj, ga = host.mm_entries(g)
+    host.mm_free(g)
+    assert sorted(ga.tolist()) == sorted(a.tolist())
+    d = gi == gj
+    new_of_old = np.zeros(n + 1, dtype=np.int64)
+    new_of_old[ga[d].astype(np.int64)] = gi[d]
+    assert sorted(new_of_old[1:].tolist()) == list(range(1, n + 1))
+    assert np.array_equal(gi, new_of_old[i]) and np.array_equal(gj, new_of_old[j])  # one permutation, applied to rows and columns
+    sizes = [n // nparts + (1 if q < n % nparts else 0) for q in range(nparts)]
+    bounds = np.cumsum([0] + sizes)
+    old_of_new = np.zeros(n + 1, dtype=np.int64)
+    old_of_new[new_of_old[1:]] = np.arange(1, n + 1)
+    part_of_new = np.searchsorted(bounds, np.arange(n), side="right") - 1
+    for q in range(nparts):
+        block = old_of_new[1 + bounds[q]:1 + bounds[q + 1]]
+        assert np.all(np.diff(block) > 0), "file order inside part %d" % q
+    cut = int(np.sum(part_of_new[gi - 1] != part_of_new[gj - 1]))
+    cut_identity = int(np.sum(part_of_new[i - 1] != part_of_new[j - 1]))
+    assert cut < 0.4 * cut_identity, (cut, cut_identity)  # (37 parts of 24 rows of a band that reaches 7 rows: a quarter is cut by any split)
+    # the default number of parts is the reference's 16 (:237-238)
+    g0, g16 = host.mm_load(path + "__GP"), host.mm_load(path + "__GP16")
+    assert host.mm_entries(g0)[0].tolist() == host.mm_entries(g16)[0].tolist()
+    host.mm_free(g0)
+    host.mm_free(g16)
 
 
 def test_rcm_requires_square_real(host, tmp_path):
