@@ -55,6 +55,7 @@ struct Arguments
     bool check = false;
     bool x_uniform = false;
     bool device_given = false;
+    bool shortcut = false; // the kernel was chosen with --csr / --coo / --ell PATH
     SpmvOptions spmv;
 };
 
@@ -138,9 +139,9 @@ error_t parse_option(int key, char * arg, argp_state * state)
             argp_error(state, "spmv-format '%s' is not part of this build (choose coo, coo-atomic, csr, ell or hybrid)", arg);
         else argp_error(state, "invalid argument");
         break;
-    case key_csr: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::csr; a.matrix_path = arg; break;
-    case key_coo: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::coo; a.matrix_path = arg; break;
-    case key_ell: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::ell; a.matrix_path = arg; break;
+    case key_csr: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::csr; a.matrix_path = arg; a.shortcut = true; break;
+    case key_coo: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::coo; a.matrix_path = arg; a.shortcut = true; break;
+    case key_ell: a.kernel_type = KernelType::spmv; a.format = SpmvFormat::ell; a.matrix_path = arg; a.shortcut = true; break;
     case key_device:
         if (!std::strcmp(arg, "hip") || !std::strcmp(arg, "gpu")) a.hip = true;
         else if (!std::strcmp(arg, "cpu")) a.hip = false;
@@ -265,9 +266,10 @@ int main(int argc, char ** argv)
         {nullptr, 0, nullptr, 0, "Sparse matrix-vector multplication kernels:", 2},
         {"spmv-format", key_spmv_format, "FMT", 0,
          "choose one of: coo, coo-atomic, csr, ell, hybrid (CPU, OpenMP) or hip-csr, hip-coo, hip-ell, hip-hybrid (MI355X)", 2},
-        {"csr", key_csr, "PATH", 0, "same as --spmv-format csr --matrix PATH", 2},
-        {"coo", key_coo, "PATH", 0, "same as --spmv-format coo --matrix PATH", 2},
-        {"ell", key_ell, "PATH", 0, "same as --spmv-format ell --matrix PATH", 2},
+        {"csr", key_csr, "PATH", 0, "CSR SpMV of the matrix in PATH: on the MI355X when a HIP device is usable (= --spmv-format hip-csr), else "
+                                    "the OpenMP kernel with a note on stderr (= --spmv-format csr); --device cpu|hip decides", 2},
+        {"coo", key_coo, "PATH", 0, "the same for COO", 2},
+        {"ell", key_ell, "PATH", 0, "the same for ELLPACK", 2},
         {"synthetic", key_synthetic, "SPEC", 0,
          "EXTENSION: generate the matrix instead of reading it: poisson2d:<n>, queen[:gx,gy,gz], kkt[:<n>], "
          "webbase[:N,Z,maxrow,locality%], powerlaw[:N,Z,maxrow], banded:N,b[,seed], random:N,k[,seed] (same as --matrix synthetic:SPEC)", 2},
@@ -281,8 +283,9 @@ int main(int argc, char ** argv)
 
         {nullptr, 0, nullptr, 0, "GPU:", 3},
         {"device", key_device, "cpu|hip", 0,
-         "Where the kernel runs: cpu (default, the reference's kernels) or hip (MI355X, no fallback). The environment "
-         "variable SPMV_DEVICE=hip changes the default, so that --csr/--coo/--ell PATH run on the GPU", 3},
+         "Where the kernel runs: cpu (the reference's OpenMP kernels) or hip (MI355X; an error without a usable device). Default: "
+         "--csr/--coo/--ell PATH pick hip when a device is usable, --spmv-format FMT and --triad mean what they name; the "
+         "environment variable SPMV_DEVICE=cpu|hip sets the default of them all", 3},
         {"gpu", key_gpu, "INDEX", 0, "HIP device index (default 0)", 3},
         {"gpus", key_gpus, "G", 0,
          "hip-csr, hip-coo, hip-ell: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
@@ -339,14 +342,28 @@ int main(int argc, char ** argv)
     // runtime switch for drop-in use: SPMV_DEVICE=hip makes the GPU the default of every format
     // option that does not say otherwise (an explicit --device / hip-* always wins); anything but
     // "hip" or "cpu" is an error, and a GPU default without a usable GPU fails like --device hip
+    bool env_decides = false;
     if (char const * env = std::getenv("SPMV_DEVICE")) {
         if (!std::strcmp(env, "hip") || !std::strcmp(env, "gpu")) {
             if (!args.device_given)
                 args.hip = true;
-        } else if (std::strcmp(env, "cpu") && *env) {
+            env_decides = true;
+        } else if (!std::strcmp(env, "cpu")) {
+            env_decides = true;
+        } else if (*env) {
             std::cerr << "SPMV_DEVICE: expected 'cpu' or 'hip'\n";
             return EXIT_FAILURE;
         }
+    }
+    // --csr / --coo / --ell PATH, the README's spelling (README.md:81,124), is what a user of the reference types: as the drop-in
+    // for that path it runs the MI355X kernel whenever a device is usable and nothing said otherwise (--device, SPMV_DEVICE, an
+    // explicit --spmv-format); without one it runs the reference's OpenMP kernel and says so in one line -- never silently.
+    if (args.shortcut && !args.device_given && !env_decides && args.kernel_type == KernelType::spmv) {
+        int count = 0;
+        if (spmv_hip_device_count(&count) == 0 && count > 0)
+            args.hip = true;
+        else
+            std::cerr << "note: no usable HIP device: the CPU (OpenMP) kernel runs (--device hip makes this an error, --device cpu silences the note)\n";
     }
 
     std::unique_ptr<Kernel> kernel;

@@ -532,13 +532,39 @@ def test_cli_expand_symmetric_extension():
     assert json.loads(out)["kernel"]["nonzeros"] == 2 * 2596 - 1138
 
 
+def _no_note(err):
+    """stderr without the one-line note that --csr/--coo/--ell print where no HIP device is usable (this test box)."""
+    return "\n".join(l for l in err.strip().split("\n") if not l.startswith("note: no usable HIP device"))
+
+
+def test_cli_shortcuts_say_where_they_run():
+    """--csr/--coo/--ell PATH are the drop-in's spelling (README.md:81,124): the MI355X kernel when a device is usable, else the
+    reference's OpenMP kernel WITH a one-line note; --device cpu and SPMV_DEVICE=cpu choose the CPU kernel silently; --device hip
+    without a device is an error, never a fallback; --spmv-format csr names the CPU kernel and stays silent."""
+    import subprocess
+    rc, out, err = hostlib.run_cli("--threads", 1, "--csr", BUS, "--profile=1")
+    assert rc == 0
+    name = json.loads(out)["kernel"]["name"]
+    if name == "csr-spmv":
+        assert "note: no usable HIP device" in err
+    else:
+        assert name == "hip-csr-spmv" and "note:" not in err
+    rc, out, err = hostlib.run_cli("--threads", 1, "--csr", BUS, "--profile=1", "--device", "cpu")
+    assert rc == 0 and json.loads(out)["kernel"]["name"] == "csr-spmv" and "note:" not in err
+    rc, out, err = hostlib.run_cli("--threads", 1, "--spmv-format", "csr", "-m", BUS, "--profile=1")
+    assert rc == 0 and json.loads(out)["kernel"]["name"] == "csr-spmv" and "note:" not in err
+    r = subprocess.run([hostlib.CLI, "--threads", "1", "--ell", BUS, "--profile=1"], env=dict(os.environ, SPMV_DEVICE="cpu"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout)["kernel"]["name"] == "ell-spmv" and "note:" not in r.stderr
+
+
 def test_cli_errors():
     rc, out, err = hostlib.run_cli("--csr", BUS, "--profile=1")
     assert rc != 0 and "Please specify --trace-config" in err
     rc, out, err = hostlib.run_cli("-c", TC1, "--csr", "/nonexistent.mtx", "--profile=1")
-    assert rc == 1 and err.strip() == "csr-spmv: /nonexistent.mtx: No such file or directory" and out == ""
+    assert rc == 1 and _no_note(err) == "csr-spmv: /nonexistent.mtx: No such file or directory" and out == ""
     rc, out, err = hostlib.run_cli("-c", "/nonexistent.json", "--csr", BUS, "--profile=1")
-    assert rc == 1 and err.strip() == "/nonexistent.json: No such file or directory"
+    assert rc == 1 and _no_note(err) == "/nonexistent.json: No such file or directory"
     rc, out, err = hostlib.run_cli("-c", TC1, "--csr", BUS)
     assert rc == 1 and "Cache tracing" in err
     rc, out, err = hostlib.run_cli("-c", TC1, "--spmv-format", "mkl-csr", "-m", BUS, "-p", 1)
