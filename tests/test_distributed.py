@@ -96,7 +96,9 @@ def _worker(rank, world, port, steps, out_dir, overlap=False, balanced=False, pi
 @pytest.mark.parametrize("world,overlap,balanced,pingpong", [(2, False, False, True), (3, False, False, True),
                                                              (2, True, False, True), (2, True, False, False),
                                                              (3, False, True, True), (2, True, True, True),
-                                                             (3, True, True, False)])
+                                                             (3, True, True, False),
+                                                             # eight ranks, what the first 8-GPU run will launch: 693 rows in chunks of 87, the last one 84
+                                                             (8, True, False, True), (8, False, True, True)])
 def test_partitioned_spmv_with_allgather_gloo(tmp_path, world, overlap, balanced, pingpong):
     """overlap + pingpong: two segment buffers alternate (y_out = y_in + A*x), several gathers may be in
     flight; overlap without it: one buffer and a snapshot copy; 5 steps so both buffers are reused."""
@@ -202,7 +204,7 @@ def _peer_worker(rank, world, port, steps, out_dir, balanced):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,balanced", [(2, False), (3, False), (3, True)])
+@pytest.mark.parametrize("world,balanced", [(2, False), (3, False), (3, True), (8, False), (8, True)])
 def test_partitioned_spmv_with_peer_stores_gloo(tmp_path, world, balanced):
     """The gather as stores into the other ranks' vectors (spmv_amd/peer.py): partition, slots, completion by
     finish() (sync + barrier), zero(), uneven segments -- on CPU with the vectors in shared memory."""
