@@ -51,6 +51,22 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 XGMI_LINK_GBS = 64.0       # per direction and link, 7 links per GPU: the conservative figure DESIGN.md section 6 uses
 XGMI_LINK_GBS_QUOTED = 153.0  # the per-link figure usually quoted for MI355X; the truth for one direction lies in between
+
+
+def strong_scaling_model(rows, t1_us):
+    """What the replicated-y design can reach on one node: every GPU multiplies rows / G and must RECEIVE
+    the other G - 1 segments, each over its own xGMI link (direct all-to-all: segment bytes / link rate, whatever G is), fully
+    overlapped with the multiply at best: step = max(t1 / G, 8 rows / G / rate).  Rates per link and direction: 64 GB/s (what
+    MI300X-class links deliver), 76.8 (half of the 153.6 GB/s bidirectional figure quoted for MI355X)."""
+    out = {"formula": "step_us(G) = max(t1_us / G, 8 * rows / G / link_rate); speedup = t1_us / step_us", "t1_us": round(t1_us, 1), "rows": int(rows)}
+    for rate in (64.0, 76.8):
+        row = {}
+        for G in (2, 4, 8):
+            gather = 8.0 * rows / G / (rate * 1e9) * 1e6
+            step = max(t1_us / G, gather)
+            row["G%d" % G] = {"local_us": round(t1_us / G, 1), "gather_us": round(gather, 1), "speedup": round(t1_us / step, 2)}
+        out["link_%.1f_GBs" % rate] = row
+    return out
 CLI = os.path.join(ROOT, "spmv-cache-trace_amd", "spmv-cache-trace-hip")
 
 
@@ -972,8 +988,10 @@ def main():
                    "frac_algorithmic_whole_step": round(synth.csr_bytes(rows3, cols3, nnz3) / (el3.item() / 10) / 1e9 / (HBM_PEAK_GBS * world), 4),
                    "local_tiles": i3["row_blocks"], "local_shifted_tiles": i3["shifted_tiles"], "local_x_window_tiles": i3["xwin_tiles"],
                    "setup_s": round(time.perf_counter() - t3 - el3.item(), 1),
+                   "strong_scaling_model": strong_scaling_model(rows3, el3.item() / 10 * 1e6 * (world if use_dist else 1)),
                    "note": "whole-job GFLOP/s of BASELINE configs[3]'s stand-in on these ranks; parity of this matrix and path: "
-                           "tests/test_gpu_fullsize.py, tests/test_gpu_peer.py"}
+                           "tests/test_gpu_fullsize.py, tests/test_gpu_peer.py; strong_scaling_model: t1 = this run's step time"
+                           + (" x ranks (an estimate of the single-GPU time)" if use_dist else "")}
         if not op3.collective:
             op3.close()
         del op3, keep3, p3, c3, v3

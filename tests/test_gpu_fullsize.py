@@ -400,6 +400,37 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
         os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
 
 
+@pytest.mark.parametrize("spec,gather", [("synthetic:kkt:200", "fused"), ("synthetic:kkt:199", "fused"), ("synthetic:kkt:199", "push")])
+def test_eight_row_blocks_of_the_kkt_matrix_on_one_device(oracle, spec, gather):
+    """BASELINE configs[3] as the first 8-GPU run will see it -- nlpkkt200's stand-in in EIGHT row blocks (ceil(rows / 8) rows
+    each, src/matrix/csr-matrix.cpp:77-95), eight plans, eight copies of y, the fused peer store / the push -- rehearsed with all
+    eight parts on this box's one device.  kkt:200 divides evenly (8 x 2 030 000 rows); kkt:199 does not (15 998 804 rows: the
+    last block is 4 rows short), which is the uneven-last-chunk case at G = 8.  Whole vector against the CPU kernel; under
+    VERIFY_PLAN get_y also compares all eight copies of y bit for bit."""
+    import os
+    A = hostapi.load(spec, "csr")
+    rows, cols = A.rows, A.cols
+    assert (rows % 8 == 0) == (spec.endswith("200")) and A.stored > 400000000
+    x = synth.x_vector(cols, seed=12345)
+    want = oracle.csr_spmv(rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS, runs=2)
+    os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
+    try:
+        gflag = capi.FLAG_FUSED_PEER_STORE if gather == "fused" else capi.FLAG_PEER_GATHER
+        with capi.Context(num_gpus=8, flags=gflag | capi.FLAG_VERIFY_PLAN) as ctx:
+            ctx.upload_csr(rows, cols, A.row_ptr, A.column_index, A.value)
+            ctx.set_x(x)
+            ctx.run(2)
+            got = ctx.get_y()
+            info = ctx.info()
+            assert info["devices"] == 8 and info["rows"] == rows and info["stored"] == A.stored
+            k_ns, g_ns = ctx.last_run_times()
+            assert k_ns > 0
+    finally:
+        os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
+    assert_close(got, want, scale=2 * abs_products(rows, A.row_ptr, A.column_index, A.value, x), what="%s in 8 row blocks, %s" % (spec, gather))
+    A.close()
+
+
 @pytest.mark.parametrize("fmt,parts,balance", [("coo", 3, False), ("coo", 8, True), ("ell", 2, False), ("ell", 5, False),
                                                ("hybrid", 3, False), ("hybrid", 4, True)])
 def test_multi_gpu_context_coo_and_ellpack_blocks(oracle, fmt, parts, balance):
