@@ -237,3 +237,69 @@ def test_block_structure_with_a_value_dictionary(oracle):
     got_g, info_g = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_VALUE_INDEX)
     assert info_g["block_tiles"] > 0
     assert_close(got_g, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="values read")
+
+
+def block_patchwork(seed, nodes=4000):
+    """Sections of 3 x 3 block rows (2 ... 60 blocks per row, any mix: 1 ... 9 block rows per tile) interleaved with sections
+    that are NOT blocks (rows of any length, sometimes a number of rows that is no multiple of 3, so that the triples behind
+    them sit off the tiler's 3-row grid), with damage sprinkled over the block sections: a column moved, a row of a triple
+    made longer, a block off the 3-grid.  Columns stay within 60 000 of the row (16-bit tiles) or anywhere (32-bit)."""
+    rng = np.random.default_rng(seed)
+    cols = 3 * nodes + 300
+    rows_c, rows_v = [], []
+    node = 0
+    while node < nodes:
+        kind = rng.integers(0, 10)
+        if kind <= 6:  # a run of block rows
+            n = int(rng.integers(5, 400))
+            lo_b, hi_b = sorted(rng.integers(2, 61, size=2).tolist())
+            wide = rng.integers(0, 8) == 0
+            for _ in range(min(n, nodes - node)):
+                nb = int(rng.integers(lo_b, hi_b + 1))
+                reach = nodes if wide else 6000
+                lo, hi = max(0, node - reach), min(nodes, node + reach + 1)
+                nbrs = np.unique(rng.integers(lo, hi, size=nb))
+                cc = (3 * nbrs[:, None] + np.arange(3)[None, :]).ravel()
+                trio = [cc.copy(), cc.copy(), cc.copy()]
+                dmg = rng.integers(0, 60)
+                if dmg == 0 and len(cc) > 3:
+                    trio[int(rng.integers(0, 3))][int(rng.integers(1, len(cc)))] += 1  # may collide with its neighbour: a duplicate
+                elif dmg == 1:
+                    trio[int(rng.integers(0, 3))] = np.append(cc, [cols - 3, cols - 2, cols - 1])  # one row a block longer
+                elif dmg == 2 and len(cc) > 3:
+                    for t in trio:
+                        t[-3:] = np.minimum(t[-3:] + 1, cols - 1)  # last block off the grid
+                for t in trio:
+                    rows_c.append(np.sort(t))
+                node += 1
+        elif kind <= 8:  # rows that are no blocks; one time in four knocking the triples behind them off the 3-row grid
+            nr = int(rng.integers(1, 13))
+            if rng.integers(0, 4):
+                nr = 3 * ((nr + 2) // 3)
+            for _ in range(nr):
+                rows_c.append(np.sort(rng.integers(0, cols, size=int(rng.integers(0, 120)))))
+        else:
+            for _ in range(3 if rng.integers(0, 4) else 1):
+                rows_c.append(np.sort(rng.integers(0, cols, size=int(rng.choice([513, 700, 2049])))))
+    lens = np.array([len(r) for r in rows_c], dtype=np.int64)
+    p = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    c = np.concatenate(rows_c).astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=len(c))
+    return len(lens), cols, p.astype(np.int32), c, v
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_block_patchwork(oracle, seed):
+    rows, cols, p, c, v = block_patchwork(seed)
+    x = synth.x_vector(cols, seed=seed + 50)
+    y0 = synth.x_vector(rows, seed=seed + 60)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert_close(got, want, scale, what="block patchwork %d" % seed, nterms=2100)
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES)
+    assert info_n["block_tiles"] == 0
+    assert_close(got_n, want, scale, what="block patchwork %d, no block tiles" % seed, nterms=2100)
+    got_e, _ = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER)
+    assert_bitexact(got_e, want, "block patchwork %d, exact order" % seed)

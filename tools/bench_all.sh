@@ -4,20 +4,24 @@
 TAG=${1:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-run() { name=$1; shift; python3 bench.py --steps 50 --warmup 10 --cpu-seconds 4 "$@" > gpurun_out/${TAG}_$name.log 2> gpurun_out/${TAG}_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/${TAG}_$name.err; }; python3 - gpurun_out/${TAG}_$name.log $name <<'PY'
+run() { name=$1; shift; python3 bench.py --steps 50 --warmup 10 --cpu-seconds 4 --no-companions --no-config3 "$@" > gpurun_out/${TAG}_$name.log 2> gpurun_out/${TAG}_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/${TAG}_$name.err; }; python3 - gpurun_out/${TAG}_$name.log $name <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     r = d["roofline"]
-    print("%-16s %8.1f us  %7.1f GFLOP/s  frac %.3f  algorithmic %.3f  of-triad %s  cpu %s GFLOP/s  parity %s  refproto %s" % (
-        sys.argv[2], r["kernel_us"], d["value"], r["frac"], r["frac_algorithmic"], r["frac_of_triad"],
+    st = r["streamed"]
+    comp = r.get("compressed") if isinstance(r.get("compressed"), dict) else None
+    print("%-20s %8.1f us (cold %s)  %7.1f GFLOP/s  frac(8d) %.3f  streamed %.3f (%.2f of triad)  cpu %s GFLOP/s  parity %s  refproto %s%s" % (
+        sys.argv[2], r["kernel_us"], (r.get("cold") or {}).get("kernel_us_median"), d["value"], r["frac"], st["frac"], st["frac_of_triad"] or 0,
         (d.get("cpu_baseline") or {}).get("value"), (d.get("parity") or {}).get("pass"),
-        ((d.get("reference_protocol") or {}).get("execution_time_ns") or {}).get("median")))
+        ((d.get("reference_protocol") or {}).get("execution_time_ns") or {}).get("median"),
+        ("  | compressed %.1f us %.0f GFLOP/s" % (comp["kernel_us"], comp["gflops"])) if comp else ""))
 except Exception as e:
     print(sys.argv[2], "no line:", e)
 PY
 }
 run poisson_csr
+run poisson_csr_product --headline product
 run queen_csr --workload queen
 run kkt_csr --workload kkt
 run webbase_csr --workload webbase
@@ -36,6 +40,8 @@ run poisson_csr_hashed --matrix synthetic:poisson2d:4096,1
 run kkt_csr_noshift --workload kkt --flags 0x400
 run kkt_csr_jitter50 --matrix synthetic:kkt:200,50
 run queen_csr_jitter6 --matrix synthetic:queen:110,71,177,6
+run queen_csr_noblocks --workload queen --flags 0x2000000
+run webbase_csr_hubs --workload webbase --flags 0x4000000
 # the launches of tests/test_gpu_perf_floor.py measured on this box -- measured and logged only: updating the committed table
 # (tests/golden/perf_floor.json) is an explicit, reviewed step (python3 tools/perf_floor.py --write), never a side effect of a
 # sweep, or a regressed build run through this script would loosen the very floor that exists to catch it
