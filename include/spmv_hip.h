@@ -141,6 +141,11 @@ extern "C" {
                                              columns -- nearly every line of x ends up in every XCD's L2 -- not the head; DESIGN.md
                                              section 3.3).  The dense array is scratch: multiplies through ONE plan must then be
                                              ordered (same stream), like the runs of a context.  plan_info[27], [28] */
+#define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 129 ... 512 entries, which fill a
+                                             512-entry tile badly (one row of 361: 70 %), are taken up to 8 at a time by one wave
+                                             that walks them in windows of 512 entries and carries the row sums in registers
+                                             (7 rows of 361 = 4.94 windows).  1e-10 class like every row of more than 16 entries;
+                                             never under SPMV_HIP_FLAG_EXACT_ORDER */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -357,7 +362,8 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             they read no index stream at all, only the first row's bytes
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
  *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries
- *        [27] hub columns (see SPMV_HIP_FLAG_HUB_COLUMNS)  [28] the entries that refer to them */
+ *        [27] hub columns (see SPMV_HIP_FLAG_HUB_COLUMNS)  [28] the entries that refer to them
+ *        [29] multi-window tiles (several rows of 161 ... 512 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

@@ -29,8 +29,12 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     if (w >= ntiles)
         return;
     const int4 d0 = desc[w];
-    const int k0 = d0.y, k1 = desc[w + 1].y;
-    if ((d0.x & kTileFlagPartial) || k1 <= k0 || k1 - (k0 & ~3) > tile)
+    const int4 d1 = desc[w + 1];
+    const int k0 = d0.y, k1 = d1.y;
+    // (a tile of SEVERAL rows that holds more than `tile` entries is a multi-window tile, csr_wavetile.hpp: it may have 16-bit
+    // columns like any other, but none of the classes below that park a whole tile's columns or x in LDS)
+    const bool big = k1 - (k0 & ~3) > tile;
+    if ((d0.x & kTileFlagPartial) || k1 <= k0 || (big && (d1.x & ~kTileFlagPartial) - (d0.x & ~kTileFlagPartial) < 2))
         return; // long rows and empty tiles keep 32-bit indices
     int cmin = 0x7FFFFFFF, cmax = -1;
     for (int k = k0 + lane; k < k1; k += kWave) {
@@ -55,7 +59,7 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         for (int k = k0 + lane; k < k1; k += kWave)
             j16[k] = (uint16_t) (j[k] - cmin);
     const int len = d0.z & 0xFFFF;
-    int shifted = detect_shifted && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
+    int shifted = detect_shifted && !big && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
                   && len <= kShiftedMaxLen && k1 - k0 >= 2 * len && tile <= 1024;
     if (shifted) {
         int ok = 1;
@@ -66,7 +70,7 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         shifted = __all(ok);
     }
     int xwin = 0;
-    if (narrow && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
+    if (narrow && !big && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
         xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
     if (shifted && fingerprint) {
         // the tile's shape: (row length, rows, first-row columns relative to the first row);

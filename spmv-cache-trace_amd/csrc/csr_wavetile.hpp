@@ -503,6 +503,61 @@ __device__ __forceinline__ void tile_rows_pairs_constant(
     }
 }
 
+// Multi-window tiles: SEVERAL rows of 129 ... 512 entries owned by one wave that holds more than TILE entries (the host forms
+// them where such rows would leave a 512-entry tile badly filled, plan_csr.hip).  The wave walks the tile's entries in windows
+// of TILE: loads, gathers and parks one window's products exactly like a plain tile, then every row's lanes add what the window
+// holds of THEIR row to a partial sum they keep in registers; one butterfly per row at the very end.  Every window is full
+// but the last: 7 rows of 361 entries = 4.94 windows instead of 7 tiles 70 % full.
+template <int TILE, int QUADS, bool C16, bool X32, bool VI, typename YStore>
+__device__ __forceinline__ void tile_rows_multi_window(
+    double * prod, const int32_t * __restrict__ p, const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
+    const double * __restrict__ a, const double * __restrict__ x, const double * y_in, int r0, int k0, int k1, int nrows, int meta,
+    int cbase, int cols, int lane, const uint8_t * __restrict__ vidx, ValueLookup vtab, YStore && store)
+{
+    const int kb = k0 & ~3;
+    const int lanes_log2 = (meta >> kTileMetaLanesShift) & 0x7; // 3, 4 or 5: rows * lanes <= 64
+    const int sub = lane >> lanes_log2, part = lane & ((1 << lanes_log2) - 1);
+    const int rowi = sub < nrows ? sub : nrows - 1;
+    int ps, pe;
+    if (meta & kTileMetaUniform) {
+        ps = k0 + rowi * (meta & 0xFFFF);
+        pe = ps + (meta & 0xFFFF);
+    } else {
+        ps = p[r0 + rowi];
+        pe = p[r0 + rowi + 1];
+    }
+    const double yv = y_in[r0 + rowi];
+    const bool narrow = C16 && (meta & kTileMetaNarrow);
+    double z = 0.0;
+    for (int base = kb; base < k1; base += TILE) { // wave-uniform
+        const int left = k1 - base;
+        const int last = ((left < TILE ? left : TILE) - 1) & ~3;
+        if (narrow)
+            tile_products_narrow<QUADS, 0, VI>(prod, j16 + base, a + base, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + base, vtab);
+        else
+            tile_products_wide<QUADS, X32, VI>(prod, j + base, a + base, x, last, lane, vidx + base, vtab);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int s = (ps > base ? ps : base) - base;
+        const int e = (pe < base + TILE ? pe : base + TILE) - base;
+        for (int k = s + part; k < e; k += 1 << lanes_log2)
+            z += prod[k];
+        // (the next window overwrites the slice: same-wave LDS operations execute in order; the fences pin the compiler)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    switch (lanes_log2) {
+    case 3: z = group_sum<8>(z); break;
+    case 4: z = group_sum<16>(z); break;
+    case 5: z = group_sum<32>(z); break;
+    default: z = group_sum<64>(z); break;
+    }
+    if (sub < nrows && part == 0)
+        store(r0 + sub, yv + z);
+}
+
 // VI: the plan holds a value dictionary (see TileValues): vidx = one byte per stored entry, vtable = the
 // <= kMaxIndexedValues distinct values; the workgroup copies the table into LDS before anything else (the
 // only workgroup barrier of this kernel, passed by every wave before any of them can leave).
@@ -591,6 +646,11 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             const bool pattern = (meta & kTileMetaPattern) != 0;
             tile_rows_pairs_constant<X32, PEER>(pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                 vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);
+            return;
+        }
+        if (TILE == 512 && !PANELS && nrows > 1 && k1 - kb > TILE) {
+            tile_rows_multi_window<TILE, QUADS, C16, X32, VI>(prod, p, j, j16, a, x, y_in, r0, k0, k1, nrows, meta, cbase, cols, lane, vidx, vtab,
+                                                              [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
             return;
         }
         if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !exact_order) {

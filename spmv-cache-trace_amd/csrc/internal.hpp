@@ -43,7 +43,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_NO_MULTI_WINDOW
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -119,6 +119,7 @@ struct spmv_hip_plan {
     long long hub_entries = 0;
     // block tiles (csr_blocktile.hpp): rows in triples of equal length (a hint from row_ptr at plan time), checked against
     // the columns and marked by spmv_hip_plan_csr_repack; their block stream lives behind the 16-bit columns in d_col16
+    int multi_window_tiles = 0; // tiles of several long rows walked in windows of 512 entries
     int block_hint = 0;
     int block_cuts = 0; // tiles the hint made shorter (0: the tiling is what it would have been without the hint)
     int break_rows = 0; // (what the tiles were built with: a rebuild needs them again)

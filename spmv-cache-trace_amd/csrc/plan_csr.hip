@@ -236,6 +236,20 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     int32_t r = 0;
     int next_panel = 0;
     long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
+    int longest = 0;
+    for (int32_t q = 0; q < rows; ++q)
+        longest = std::max(longest, (int) (p[q + 1] - p[q]));
+    // Two passes at most: the first cuts plain tiles and decides on them whether the matrix gets balanced tiles instead (below);
+    // only if it does not, and rows of 161 ... 512 entries exist, the second cuts again with multi-window tiles allowed.
+    bool want_balanced = false;
+    long long multi_candidates = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool allow_multi = pass == 1;
+    desc.clear();
+    r = 0;
+    next_panel = 0;
+    stream_tiles = stream_tile_entries = 0;
+    pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = pl->multi_window_tiles = pl->block_cuts = 0;
     while (r < rows) {
         if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
             while (next_panel <= 8 && next_panel <= r / break_rows)
@@ -304,6 +318,49 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                 }
             }
         }
+        // Multi-window tiles (csr_wavetile.hpp): rows of 129 ... 512 entries fill a 512-entry tile badly -- one row of 361 leaves
+        // 30 % of the wave's load slots empty, two of 201 leave 21 % -- so a wave takes up to 8 such rows and walks them in
+        // windows of 512 entries, carrying the row sums in registers: 7 rows of 361 are 4.94 windows (99 % full).  Chosen: the
+        // row count (at most 8, all rows <= 512 entries, at most 8 windows) with the fullest windows, if that beats the plain
+        // tile by a tenth.  Not in exact order (one lane per row), not for column panels, not at the ragged end of the arrays.
+        int multi_lanes_log2 = -1;
+        // (measured on ELLPACK bands, profiles/r04_ell_long_rows.md: 177 ... 441 per row 0.69-0.72 -> 0.76-0.84 of the roofline; rows
+        // of up to 160 keep the plain tile -- three rows of 141 fill it to 83 % and have their x window, 0.93 against 0.90)
+        if (!exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160 && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
+            ++multi_candidates;
+        if (allow_multi && !exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160
+            && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) {
+            const double plain = (double) ((long long) p[r1] - kb) / tile;
+            int best = 0;
+            double best_fill = std::max(plain + 0.1, 0.75); // (rows of 257: no row count up to 8 reaches 0.9 -- 7 rows are 0.88 -- and one row per tile is 0.50)
+            int mx = 0;
+            for (int32_t q = r; q < rows && q - r < 8; ++q) {
+                mx = std::max(mx, p[q + 1] - p[q]);
+                if (mx > tile)
+                    break;
+                const long long e = (long long) p[q + 1] - kb;
+                const long long windows = (e + tile - 1) / tile;
+                if (windows > 8)
+                    break;
+                const bool inside = ((e + kb - 1) | 3) < (long long) p[rows]; // the last quad's 16-byte loads stay inside the arrays
+                const double fill = (double) e / (double) (windows * tile);
+                if (q + 1 > r1 && q + 1 - r >= 2 && inside && fill > best_fill) {
+                    best_fill = fill;
+                    best = (int) (q + 1 - r);
+                }
+            }
+            if (best > 0) {
+                r1 = r + best;
+                maxlen = 0;
+                minlen = INT32_MAX;
+                for (int32_t q = r; q < r1; ++q) {
+                    maxlen = std::max(maxlen, p[q + 1] - p[q]);
+                    minlen = std::min(minlen, p[q + 1] - p[q]);
+                }
+                multi_lanes_log2 = best <= 2 ? 5 : (best <= 4 ? 4 : 3); // 64 / (rows rounded up to a power of two)
+                pl->multi_window_tiles++;
+            }
+        }
 #ifdef SPMV_HIP_EXPERIMENTS
         // tools/ab.py: tiles of short rows end on a multiple of SPMV_HIP_TILE_ROW_ALIGN rows (whole 128-byte lines of y per tile)
         if (const char * al = std::getenv("SPMV_HIP_TILE_ROW_ALIGN")) {
@@ -332,7 +389,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             r1 = r + 1;
         } else {
             // one lane per row (rows of <= 16 entries) keeps the reference's summation order
-            const int lanes_log2 = exact ? 0 : lanes_for(maxlen);
+            const int lanes_log2 = multi_lanes_log2 >= 0 ? multi_lanes_log2 : (exact ? 0 : lanes_for(maxlen));
             pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
             // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
             const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
@@ -346,21 +403,24 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         }
         r = r1;
     }
+    if (pass == 0) {
+        // (rows with a wave or more to themselves are the same in both tilings and do not count)
+        want_balanced = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
+            && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
+        if (want_balanced || multi_candidates == 0)
+            break;
+    }
+    }
     // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
     // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
     // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
     // Regular matrices (every tile already full, or only short rows) keep the tiles above and with
     // them the reference's summation order.
     {
-        int longest = 0;
-        for (int32_t q = 0; q < rows; ++q)
-            longest = std::max(longest, (int) (p[q + 1] - p[q]));
-        // (rows with a wave or more to themselves are the same in both tilings and do not count)
-        const bool want = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
-            && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
+        const bool want = want_balanced;
         if (want) {
             desc.clear();
-            pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = 0;
+            pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = pl->multi_window_tiles = 0;
             r = 0;
             while (r < rows) {
                 const int32_t kb = p[r] & ~3;
@@ -928,7 +988,7 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
             pl->ntiles = pl->nblk = pl->workgroups = 0;
             pl->narrow_tiles = pl->shifted_tiles = pl->xwin_tiles = pl->longest_tile_row = pl->spread_tiles = 0;
             pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
-            pl->uniform_tiles = pl->split_rows = pl->long_blocks = 0;
+            pl->uniform_tiles = pl->split_rows = pl->long_blocks = pl->multi_window_tiles = 0;
             pl->balanced = false;
             pl->block_hint = pl->block_cuts = pl->block_tiles = 0;
             pl->block_entries = 0;
@@ -1299,15 +1359,15 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[29] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[30] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
-                           pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries};
-    for (int i = 0; i < n && i < 29; ++i)
+                           pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles};
+    for (int i = 0; i < n && i < 30; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

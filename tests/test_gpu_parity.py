@@ -844,7 +844,7 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
             assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
 
 
-@pytest.mark.parametrize("L", [1, 16, 27, 255, 256, 257, 300, 600])
+@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 480, 481, 512, 600])
 def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
     """ELLPACK runs in place as wave tiles.  Default: rows of more than 16 entries are summed by several lanes (1e-10);
     EXACT_ORDER keeps one lane per row (in place up to 80 entries per row, column-major beyond) and ELL_COLUMN_MAJOR
@@ -872,9 +872,10 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.run()
             assert_ell(c2.get_y(), want, L, flags, ec, ev, x, y0, 2, "ell L=%d flags %x" % (L, flags))
             if flags == 0 and L > 16:
-                # several lanes per row on the row-major arrays in place, except rows of 161..512 entries (one or two
-                # rows per tile: the column-major kernel measured faster there, profiles/r03_ell_row_lengths.log)
-                assert (c2.info()["row_blocks"] > 0) == (not 160 < L <= 512), (L, c2.info())
+                # several lanes per row on the row-major arrays in place (rows of 161..480 entries in multi-window tiles, round 4);
+                # rows of more than 480 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
+                assert (c2.info()["row_blocks"] > 0) == (L <= 480), (L, c2.info())
+                assert c2.info()["ell_path"] == (1 if L <= 480 else 2)
         finally:
             c2.close()
 
@@ -1441,3 +1442,62 @@ def test_coo_and_hybrid_column_panels(oracle):
             c3.close()
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("case", ["uniform361", "mixed", "random_columns", "few_values"])
+def test_multi_window_tiles(oracle, case):
+    """Rows of 161 ... 512 entries are taken up to 8 at a time by one wave that walks them in windows of 512 entries, the row
+    sums carried in registers (plan_info[29]): against the oracle, against the plan without them (SPMV_HIP_FLAG_NO_MULTI_WINDOW),
+    accumulating, y_out != y_in, with another column array (32-bit columns), with a value dictionary, and never under
+    EXACT_ORDER (bit-exact there)."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(len(case))
+    rows, cols = 6000, 40000
+    if case == "uniform361":
+        lens = np.full(rows, 361)
+    else:
+        lens = np.where(rng.random(rows) < 0.7, rng.integers(161, 513, rows), rng.integers(0, 160, rows))
+        lens[:40] = rng.choice([161, 255, 256, 257, 480, 511, 512], size=40)
+    p = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    p = p.astype(np.int32)
+    wide = case == "random_columns"
+    c = np.concatenate([np.sort(rng.choice(cols if wide else 3000, size=n, replace=False) + (0 if wide else min(r * 6, cols - 3000)))
+                        for r, n in enumerate(lens)]).astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=len(c))
+    if case == "few_values":
+        v = np.array([0.5, -2.0, 3.0])[rng.integers(0, 3, size=len(c))]
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+    results = {}
+    for flags in (0, capi.FLAG_NO_MULTI_WINDOW, capi.FLAG_EXACT_ORDER):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        plan.index_values(tv.data_ptr(), stream)
+        info = plan.info()
+        assert (info["multi_window_tiles"] > 0) == (flags == 0), (case, flags, info)
+        if case == "few_values":  # (a plan with block windows keeps its values as they are: either way the same y)
+            assert info["indexed_values"] in (0, 3)
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        tout = torch.full((rows,), np.nan, dtype=torch.float64, device=dev)
+        plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), tout.data_ptr(), stream)
+        tc2 = tc.clone()
+        tz = torch.from_numpy(y0.copy()).to(dev)
+        plan.spmv(tp.data_ptr(), tc2.data_ptr(), tv.data_ptr(), tx.data_ptr(), tz.data_ptr(), stream)
+        torch.cuda.synchronize()
+        results[flags] = (ty.cpu().numpy(), tout.cpu().numpy(), tz.cpu().numpy(), info)
+        plan.close()
+    got, got_out, got_other, info = results[0]
+    assert info["row_blocks"] < 0.75 * results[capi.FLAG_NO_MULTI_WINDOW][3]["row_blocks"], "fewer, fuller tiles"
+    assert_close(got, want, scale, what=case, nterms=512)
+    assert_close(got_other, want, scale, what=case + ", other column array", nterms=512)
+    assert_close(got_out, oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4), 2 * scale, what=case + ", y_out", nterms=1024)
+    assert_close(results[capi.FLAG_NO_MULTI_WINDOW][0], want, scale, what=case + ", plain tiles", nterms=512)
+    assert_bitexact(results[capi.FLAG_EXACT_ORDER][0], want, case + ", exact order")
