@@ -10,7 +10,7 @@ stream, compared by tests/test_gpu_perf_floor.py with the committed table tests/
 Each workload is HBM-resident at a size that loads in about a second; together they touch every kernel family a
 BASELINE configuration runs through: the lane-per-row stencil tiles with and without a value dictionary, shifted
 tiles with an x window, ELLPACK rows summed by one and by several lanes, narrow tiles with several lanes per row
-(queen-like), shifted KKT tiles, segment windows (KKT-like with jittered stencils), balanced tiles (web graph, as COO
+(queen-like: block tiles since round 4, also at Queen_4147's full size), multi-window tiles (ELLPACK rows of 201 and 361 entries), shifted KKT tiles, segment windows (KKT-like with jittered stencils), balanced tiles (web graph, as COO
 and as hybrid), column panels (uniformly random columns).  The number compared is the MINIMUM over a few rounds of
 the mean launch time of 20 back-to-back launches: the most repeatable figure a shared box gives.
 """
@@ -33,6 +33,9 @@ WORKLOADS = {
     "banded33_ell": ("synthetic:banded:2000000,16", "ell", 0),
     "queen_small_ell": ("synthetic:queen:80,60,60", "ell", 0),
     "queen_small_csr": ("synthetic:queen:80,60,60", "csr", 0),
+    "queen_full_csr": ("synthetic:queen", "csr", 0),                     # BASELINE configs[2] at full size: block tiles (round 4)
+    "banded201_ell": ("synthetic:banded:1000000,100", "ell", 0),         # ELLPACK rows of 161..480 entries: multi-window tiles (round 4)
+    "banded361_ell": ("synthetic:banded:1000000,180", "ell", 0),
     "kkt125_csr": ("synthetic:kkt:125", "csr", 0),
     "kkt125_jitter50_csr": ("synthetic:kkt:125,50", "csr", 0),
     "webbase_coo": ("synthetic:webbase", "coo", 0),
