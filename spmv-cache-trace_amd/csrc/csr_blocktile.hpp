@@ -186,11 +186,11 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     }
     if (lane == 0) {
         desc[w].z = meta | kTileMetaBlock3;
-        atomicAdd(count, 1ull);
-        atomicAdd(count + 1, (unsigned long long) n);
+        striped_add(count, 0, 1ull);
+        striped_add(count, 1, (unsigned long long) n);
         if (!(meta & kTileMetaBlockWin)) {
-            atomicAdd(count + 2, 1ull);
-            atomicAdd(count + 3, (unsigned long long) n);
+            striped_add(count, 2, 1ull);
+            striped_add(count, 3, (unsigned long long) n);
         }
     }
 }

@@ -416,7 +416,7 @@ static __global__ __launch_bounds__(1024) void csr_blockwin_mark_kernel(
         s_decision[0] = yes ? lo : 0;
         s_decision[1] = yes ? span : 0;
         if (yes)
-            atomicAdd(counts + 3, tiles);
+            striped_add(counts, 3, tiles);
         if (apply)
             blocks[blockIdx.x] = make_int2(yes ? lo : 0, yes ? span : 0);
     }

@@ -53,7 +53,7 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     // counts[4]: tiles whose columns reach further than one column panel (an eighth of the matrix):
     // what "scattered" means for spmv_hip_plan_csr_repack
     if (lane == 0 && cmax - cmin >= panel_width)
-        atomicAdd(counts + 4, 1);
+        striped_add(counts, 4, 1);
     const bool narrow = cmax - cmin < 65536;
     if (narrow)
         for (int k = k0 + lane; k < k1; k += kWave)
@@ -97,12 +97,12 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         desc[w].z = d0.z | (narrow ? kTileMetaNarrow : 0) | (shifted ? kTileMetaShifted : 0) | xwin;
         if (narrow) {
             desc[w].w = cmin;
-            atomicAdd(counts, 1);
+            striped_add(counts, 0, 1);
         }
         if (shifted)
-            atomicAdd(counts + 1, 1);
+            striped_add(counts, 1, 1);
         if (xwin)
-            atomicAdd(counts + 2, 1);
+            striped_add(counts, 2, 1);
     }
 }
 
@@ -206,7 +206,7 @@ static __global__ __launch_bounds__(256) void csr_pattern_assign_kernel(
                     | (window ? (kTileMetaXSeg | (((total - 1) >> 6) << kTileMetaXChunksShift)) : 0);
         desc[w].w = p;
         if (window)
-            atomicAdd(counts + 2, 1);
+            striped_add(counts, 2, 1);
     }
 }
 

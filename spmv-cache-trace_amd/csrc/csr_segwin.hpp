@@ -381,7 +381,7 @@ static __global__ __launch_bounds__(kSegWinWaves * kWave) void csr_segwin_mark_k
         return;
     }
     if (tid == 0)
-        atomicAdd(counts + 3, t1 - t0);
+        striped_add(counts, 3, t1 - t0);
     if (!apply)
         return;
     if (tid == 0) {

@@ -12,6 +12,28 @@
 
 using namespace spmvi;
 
+namespace {
+
+// Plan-time counters live in kCountStripes copies on the device (tile_common.hpp: striped_add); these read them back summed.
+constexpr size_t kStripedInts = (size_t) spmv::kCountStripes * spmv::kCountWidth;
+
+template <typename T>
+hipError_t read_striped(const T * d_counters, T * out, int n, hipStream_t s)
+{
+    T host[kStripedInts];
+    hipError_t e = hipMemcpyAsync(host, d_counters, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    for (int i = 0; i < n; ++i) {
+        out[i] = 0;
+        for (int k = 0; k < spmv::kCountStripes; ++k)
+            out[i] += host[(size_t) k * spmv::kCountWidth + i];
+    }
+    return e;
+}
+
+} // namespace
+
 namespace spmvi {
 
 // flags[0]: an index outside [0, limit); flags[1] (if asked): not non-decreasing
@@ -722,13 +744,13 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     unsigned long long * d_fp = nullptr;
     HIP_TRY(hipMalloc((void **) &pl->d_col16, bytes));
     int counts[5] = {0, 0, 0, 0, 0};
-    hipError_t e = hipMalloc((void **) &d_count, sizeof(counts));
+    hipError_t e = hipMalloc((void **) &d_count, kStripedInts * sizeof(int));
     if (e == hipSuccess && want_patterns) {
         e = hipMalloc((void **) &d_fp, (size_t) pl->ntiles * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(d_fp, 0, (size_t) pl->ntiles * sizeof(unsigned long long), s);
     }
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_col16, 0, bytes, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(counts), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(int), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
                            pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
@@ -793,8 +815,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
             }
         }
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = read_striped(d_count, counts, 5, s);
     pl->narrow_tiles = counts[0];
     pl->shifted_tiles = counts[1];
     pl->xwin_tiles = counts[2];
@@ -814,19 +835,18 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
         int shift = 0; // columns per bitmap bit = 2^shift: the whole column space in 65536 bits
         while (((long long) pl->cols - 1) >> shift >= 65536)
             ++shift;
-        counts[3] = 0;
-        e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
-        if (e == hipSuccess) {
+        // (counts[3] only ever grows on the device: every pass is read as the difference to the reading before it)
+        int before3 = counts[3];
+        {
             hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
                                d_column_index, pl->d_col16, (spmv::SegWinBlock *) nullptr, d_count, 0, shift, max_slots, take_narrow);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess && 2 * (long long) counts[3] > pl->ntiles) {
+        if (e == hipSuccess) e = read_striped(d_count, counts, 5, s);
+        const int seg_candidates = counts[3] - before3;
+        if (e == hipSuccess && 2 * (long long) seg_candidates > pl->ntiles) {
             e = hipMalloc((void **) &pl->d_segblocks, (size_t) nb * sizeof(spmv::SegWinBlock));
             if (e == hipSuccess) e = hipMemsetAsync(pl->d_segblocks, 0, (size_t) nb * sizeof(spmv::SegWinBlock), s);
-            if (e == hipSuccess) e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::csr_segwin_mark_kernel, dim3(nb), dim3(512), 0, s, pl->ntiles, pl->tile, per_block, pl->d_tiles,
                                    d_column_index, pl->d_col16, pl->d_segblocks, d_count, 1, shift, max_slots, take_narrow);
@@ -852,20 +872,20 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
                 pl->meta_bytes += (size_t) nb * sizeof(spmv::SegWinBlock);
             }
         }
-        counts[3] = 0;
-        if (e == hipSuccess) e = hipMemsetAsync(d_count + 3, 0, sizeof(int), s);
+        if (e == hipSuccess) e = read_striped(d_count, counts, 5, s);
     }
     // block windows (x staged through LDS per 16 tiles) for what has no cheaper path: first count
     // the tiles that would qualify, and only if they are the majority mark them
     if (e == hipSuccess && !pl->d_segblocks && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * spmv::kBlockWinTiles
         && !(pl->flags & (SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_XCD_REMAP))) {
         const int nb = (pl->ntiles + spmv::kBlockWinTiles - 1) / spmv::kBlockWinTiles;
+        const int before3 = counts[3];
         hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile, pl->d_tiles,
                            pl->d_col16, (int2 *) nullptr, d_count, 0);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, sizeof(counts), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess && 2 * (long long) counts[3] > pl->ntiles) {
+        if (e == hipSuccess) e = read_striped(d_count, counts, 5, s);
+        const int win_candidates = counts[3] - before3;
+        if (e == hipSuccess && 2 * (long long) win_candidates > pl->ntiles) {
             e = hipMalloc((void **) &pl->d_blocks, (size_t) nb * sizeof(int2));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::csr_blockwin_mark_kernel, dim3(nb), dim3(1024), 0, s, pl->ntiles, pl->tile,
@@ -875,7 +895,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e == hipSuccess) {
                 pl->nblocks16 = nb;
-                pl->blockwin_tiles = counts[3];
+                pl->blockwin_tiles = win_candidates;
                 pl->meta_bytes += (size_t) nb * sizeof(int2);
             }
         }
@@ -939,15 +959,14 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         hipStream_t s = static_cast<hipStream_t>(stream);
         unsigned long long * d_count = nullptr;
         unsigned long long count[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMalloc((void **) &d_count, sizeof(count)));
-        hipError_t e = hipMemsetAsync(d_count, 0, sizeof(count), s);
+        HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
                                pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = read_striped(d_count, count, 4, s);
         (void) hipFree(d_count);
         if (e != hipSuccess)
             return fail_hip(e, "block tiles");
@@ -1288,16 +1307,15 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
             unsigned long long * d_count = nullptr;
             uint8_t * d_same_prev = nullptr;
             unsigned long long count[2] = {0, 0};
-            e = hipMalloc((void **) &d_count, sizeof(count));
+            e = hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMalloc((void **) &d_same_prev, (size_t) pl->ntiles);
-            if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(count), s);
+            if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(spmv::value_rows_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->d_tiles,
                                    pl->d_vidx, spmv::kConstantRowMaxLen, d_count, d_same_prev);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = read_striped(d_count, count, 2, s);
             if (d_count) (void) hipFree(d_count);
             pl->value_row_tiles = (int) count[0];
             if (e == hipSuccess && count[0] > 0)

@@ -107,6 +107,17 @@ constexpr int kPatStride = 432;
 constexpr int kPatRel = 16, kPatXoff = 144, kPatSrc = 176;
 constexpr int kMaxPatterns = 64;
 
+// Plan-time counters are kept in kCountStripes copies -- a workgroup adds to copy (its number mod kCountStripes) -- and summed on
+// the host: one address takes about 10^8 atomic adds per second, and the plan passes issue one or more per TILE (the queen-like
+// matrix's 808 K tiles x 4 counters cost its block check 39 ms of its 40; round 4).
+constexpr int kCountStripes = 128;
+constexpr int kCountWidth = 8; // counters per copy
+template <typename T>
+__device__ __forceinline__ void striped_add(T * counters, int idx, T v)
+{
+    atomicAdd(counters + (size_t) (blockIdx.x & (kCountStripes - 1)) * kCountWidth + idx, v);
+}
+
 // native vector types: __builtin_nontemporal_load wants these, not HIP's wrapper structs
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));

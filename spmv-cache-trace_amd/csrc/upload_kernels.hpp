@@ -185,8 +185,8 @@ static __global__ __launch_bounds__(256) void value_rows_mark_kernel(
         if (now != meta)
             desc[w].z = now;
         if (same) {
-            atomicAdd(count, 1ull);
-            atomicAdd(count + 1, (unsigned long long) (k1 - k0));
+            striped_add(count, 0, 1ull);
+            striped_add(count, 1, (unsigned long long) (k1 - k0));
         }
     }
 }
