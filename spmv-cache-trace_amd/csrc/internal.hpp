@@ -121,6 +121,7 @@ struct spmv_hip_plan {
     // the columns and marked by spmv_hip_plan_csr_repack; their block stream lives behind the 16-bit columns in d_col16
     int multi_window_tiles = 0; // tiles of several long rows walked in windows of 512 entries
     int block_hint = 0;
+    int block_offset = 0; // the row (0, 1 or 2) at which the grid of triples starts
     int block_cuts = 0; // tiles the hint made shorter (0: the tiling is what it would have been without the hint)
     int break_rows = 0; // (what the tiles were built with: a rebuild needs them again)
     int block_tiles = 0;

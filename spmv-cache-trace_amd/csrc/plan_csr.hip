@@ -244,14 +244,22 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     // Block hint (csr_blocktile.hpp): rows in triples of equal length, divisible by 3 and longer than 16 entries -- three
     // unknowns per mesh node.  Only a hint: tiles are then cut on triple boundaries, and spmv_hip_plan_csr_repack checks the
     // columns of every tile before it marks it.
+    // (The triples need not start at row 0: a rank's row block of a partitioned matrix starts wherever ceil(rows / G) puts it, so
+    // the three possible offsets are tried and the tiles cut on THAT grid.)
+    pl->block_hint = 0;
+    pl->block_offset = 0;
     if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
-        long long good = 0;
-        for (int32_t q = 0; q + 2 < rows; q += 3) {
-            const int l0 = p[q + 1] - p[q];
-            good += l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+        for (int o = 0; o < 3 && !pl->block_hint; ++o) {
+            long long good = 0;
+            for (int32_t q = o; q + 2 < rows; q += 3) {
+                const int l0 = p[q + 1] - p[q];
+                good += l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+            }
+            if (good * 5 >= (long long) ((rows - o) / 3) * 4) {
+                pl->block_hint = 3;
+                pl->block_offset = o;
+            }
         }
-        if (good * 5 >= (long long) (rows / 3) * 4)
-            pl->block_hint = 3;
     }
     std::vector<int4> desc;
     desc.reserve((size_t) rows / 48 + 16);
@@ -328,7 +336,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
             int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows);
             if (cut < rows)
-                cut -= cut % 3;
+                cut -= ((cut - pl->block_offset) % 3 + 3) % 3;
             if (cut > r && cut < r1) {
                 pl->block_cuts++;
                 r1 = cut;

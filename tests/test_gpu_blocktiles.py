@@ -148,6 +148,21 @@ def test_broken_tiles_fall_back_alone(oracle):
     assert_close(got, oracle.csr_spmv(rows, p3, c3, v3, x, y=y0, num_threads=4), abs_products(rows, p3, c3, v3, x) + np.abs(y0), what="ragged triple")
 
 
+@pytest.mark.parametrize("first", [1, 2, 3001, 4499])
+def test_row_block_that_starts_inside_the_grid_of_triples(oracle, first):
+    """One rank's rows of a partitioned matrix start wherever ceil(rows / G) puts them (queen-like at G = 8: row 518 389, not a
+    multiple of 3): the plan finds the grid of triples at any of the three offsets and cuts its tiles on it."""
+    from spmv_amd import partition
+    rows, cols, p, c, v = fem3(3000, 20, 30, seed=3)
+    lp, lc, lv = partition.csr_slice(p, c, v, first, rows)
+    lrows = rows - first
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(lrows, seed=4)
+    got, info = run_plan(lrows, cols, lp, lc, lv, x, y0)
+    assert info["block_tiles"] >= 0.9 * info["row_blocks"], (first, info)
+    assert_close(got, oracle.csr_spmv(lrows, lp, lc, lv, x, y=y0, num_threads=4), abs_products(lrows, lp, lc, lv, x) + np.abs(y0), what="rows %d.." % first, nterms=90)
+
+
 def test_short_block_rows_stay_bit_exact(oracle):
     """Rows of at most 16 entries (5 blocks) keep their one-lane-per-row tiles: no block tiles, the reference's bits."""
     rows, cols, p, c, v = fem3(9000, 3, 5, seed=5)
