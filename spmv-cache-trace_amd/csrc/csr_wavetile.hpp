@@ -508,6 +508,23 @@ __device__ __forceinline__ void tile_rows_pairs_constant(
 // of TILE: loads, gathers and parks one window's products exactly like a plain tile, then every row's lanes add what the window
 // holds of THEIR row to a partial sum they keep in registers; one butterfly per row at the very end.  Every window is full
 // but the last: 7 rows of 361 entries = 4.94 windows instead of 7 tiles 70 % full.
+template <int LPR>
+__device__ __forceinline__ double window_row_sum(const double * prod, int s, int e, int part)
+{
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+    int k = s + part;
+    for (; k + 3 * LPR < e; k += 4 * LPR) {
+        const double a = prod[k], b = prod[k + LPR], c = prod[k + 2 * LPR], d = prod[k + 3 * LPR];
+        z0 += a;
+        z1 += b;
+        z2 += c;
+        z3 += d;
+    }
+    for (; k < e; k += LPR)
+        z0 += prod[k];
+    return (z0 + z1) + (z2 + z3);
+}
+
 template <int TILE, int QUADS, bool C16, bool X32, bool VI, typename YStore>
 __device__ __forceinline__ void tile_rows_multi_window(
     double * prod, const int32_t * __restrict__ p, const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
@@ -541,8 +558,13 @@ __device__ __forceinline__ void tile_rows_multi_window(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int s = (ps > base ? ps : base) - base;
         const int e = (pe < base + TILE ? pe : base + TILE) - base;
-        for (int k = s + part; k < e; k += 1 << lanes_log2)
-            z += prod[k];
+        // (four reads in flight per lane: a window holds one or two of the tile's rows, so only their lanes work here, each
+        // through 30 ... 60 products -- one dependent LDS round trip per product was most of a window's time)
+        switch (lanes_log2) {
+        case 3: z += window_row_sum<8>(prod, s, e, part); break;
+        case 4: z += window_row_sum<16>(prod, s, e, part); break;
+        default: z += window_row_sum<32>(prod, s, e, part); break;
+        }
         // (the next window overwrites the slice: same-wave LDS operations execute in order; the fences pin the compiler)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

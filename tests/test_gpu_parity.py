@@ -844,7 +844,7 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
             assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
 
 
-@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 480, 481, 512, 600])
+@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 460, 461, 512, 600])
 def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
     """ELLPACK runs in place as wave tiles.  Default: rows of more than 16 entries are summed by several lanes (1e-10);
     EXACT_ORDER keeps one lane per row (in place up to 80 entries per row, column-major beyond) and ELL_COLUMN_MAJOR
@@ -872,10 +872,10 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.run()
             assert_ell(c2.get_y(), want, L, flags, ec, ev, x, y0, 2, "ell L=%d flags %x" % (L, flags))
             if flags == 0 and L > 16:
-                # several lanes per row on the row-major arrays in place (rows of 161..480 entries in multi-window tiles, round 4);
-                # rows of more than 480 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
-                assert (c2.info()["row_blocks"] > 0) == (L <= 480), (L, c2.info())
-                assert c2.info()["ell_path"] == (1 if L <= 480 else 2)
+                # several lanes per row on the row-major arrays in place (rows of 161..460 entries in multi-window tiles, round 4);
+                # rows of more than 460 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
+                assert (c2.info()["row_blocks"] > 0) == (L <= 460), (L, c2.info())
+                assert c2.info()["ell_path"] == (1 if L <= 460 else 2)
         finally:
             c2.close()
 
