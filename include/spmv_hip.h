@@ -75,9 +75,11 @@ extern "C" {
                                             exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
                                                 kernel (bit-exact for any row length).  Default: the row-major arrays in
-                                                place as uniform wave tiles; with SPMV_HIP_FLAG_EXACT_ORDER the
-                                                column-major kernel takes rows of more than 80 entries.  Which path an
-                                                upload took: spmv_hip_ctx_info [17] */
+                                                place as uniform wave tiles for rows of up to 460 entries (several lanes per
+                                                row of more than 16 entries: 1e-10 class; rows of 161..460 entries in
+                                                multi-window tiles) and the column-major kernel -- bit-exact -- for longer
+                                                rows; with SPMV_HIP_FLAG_EXACT_ORDER the column-major kernel takes rows of
+                                                more than 80 entries.  Which path an upload took: spmv_hip_ctx_info [17] */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
                                                  such tiles read one row of column offsets instead of all of them */
