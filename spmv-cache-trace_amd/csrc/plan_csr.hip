@@ -250,12 +250,17 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     pl->block_offset = 0;
     if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
         for (int o = 0; o < 3 && !pl->block_hint; ++o) {
-            long long good = 0;
-            for (int32_t q = o; q + 2 < rows; q += 3) {
+            // (an offset is given up as soon as a fifth of all triples have failed: a matrix without blocks -- most -- pays for a
+            // fifth of one pass per offset, not for three passes over row_ptr)
+            const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
+            long long good = 0, bad = 0;
+            for (int32_t q = o; q + 2 < rows && bad <= allowed_bad; q += 3) {
                 const int l0 = p[q + 1] - p[q];
-                good += l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+                const bool ok = l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+                good += ok;
+                bad += !ok;
             }
-            if (good * 5 >= (long long) ((rows - o) / 3) * 4) {
+            if (bad <= allowed_bad && good * 5 >= triples * 4) {
                 pl->block_hint = 3;
                 pl->block_offset = o;
             }
