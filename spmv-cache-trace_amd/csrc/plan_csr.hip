@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 
@@ -266,26 +267,21 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             }
         }
     }
-    std::vector<int4> desc;
-    desc.reserve((size_t) rows / 48 + 16);
-    int32_t r = 0;
+    // The rows are cut into tiles in up to kTileChunks independent ranges, side by side on the host's threads (a tile never
+    // crosses a range boundary; the boundaries depend on the row count alone -- and, with a block hint, lie on the grid of
+    // triples -- so the tiling is the same on every machine).  Round 4: this walk over row_ptr was 29 of the 35 ms a Poisson
+    // 4096^2 plan costs.  Column panels (break_rows > 0) keep one range: their tiles are numbered per panel.
+    struct Range {
+        std::vector<int4> desc;
+        long long stream_tiles = 0, stream_tile_entries = 0, multi_candidates = 0; // tiles of whole rows (not long-row tiles) and what they hold
+        int uniform_tiles = 0, long_blocks = 0, split_rows = 0, longest_tile_row = 0, multi_window_tiles = 0, block_cuts = 0, longest = 0;
+    };
     int next_panel = 0;
-    long long stream_tiles = 0, stream_tile_entries = 0; // tiles of whole rows (not long-row tiles) and what they hold
-    int longest = 0;
-    for (int32_t q = 0; q < rows; ++q)
-        longest = std::max(longest, (int) (p[q + 1] - p[q]));
-    // Two passes at most: the first cuts plain tiles and decides on them whether the matrix gets balanced tiles instead (below);
-    // only if it does not, and rows of 161 ... 512 entries exist, the second cuts again with multi-window tiles allowed.
-    bool want_balanced = false;
-    long long multi_candidates = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-    const bool allow_multi = pass == 1;
-    desc.clear();
-    r = 0;
-    next_panel = 0;
-    stream_tiles = stream_tile_entries = 0;
-    pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = pl->multi_window_tiles = pl->block_cuts = 0;
-    while (r < rows) {
+    auto tile_range = [&](int32_t cb, int32_t ce, bool allow_multi, Range & o) {
+    std::vector<int4> & desc = o.desc;
+    desc.reserve((size_t) (ce - cb) / 48 + 16);
+    int32_t r = cb;
+    while (r < ce) {
         if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
             while (next_panel <= 8 && next_panel <= r / break_rows)
                 pl->pinfo.first[next_panel++] = (int) desc.size();
@@ -307,10 +303,11 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                 ++l;
             return l;
         };
-        while (r1 < rows && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
+        while (r1 < ce && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
             if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
                 break;
             const int len = p[r1 + 1] - p[r1];
+            o.longest = std::max(o.longest, len);
             // A long run of equally long rows (the interior of a stencil line) starts its own tile: the rows in front of it
             // (a grid line's boundary rows) would make the run's first tile non-uniform and send it down the general path --
             // Poisson 4096^2: 2.5 % of the tiles, each holding its wave slot twice as long as a stencil tile.  "Long" = at
@@ -340,10 +337,10 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         // block hint: a tile of long rows ends on a triple boundary and holds at most kBlockTileMaxRows rows
         if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
             int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows);
-            if (cut < rows)
+            if (cut < ce)
                 cut -= ((cut - pl->block_offset) % 3 + 3) % 3;
             if (cut > r && cut < r1) {
-                pl->block_cuts++;
+                o.block_cuts++;
                 r1 = cut;
                 maxlen = 0;
                 minlen = INT32_MAX;
@@ -362,14 +359,14 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         // (measured on ELLPACK bands, profiles/r04_ell_long_rows.md: 177 ... 441 per row 0.69-0.72 -> 0.76-0.84 of the roofline; rows
         // of up to 160 keep the plain tile -- three rows of 141 fill it to 83 % and have their x window, 0.93 against 0.90)
         if (!exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160 && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
-            ++multi_candidates;
+            ++o.multi_candidates;
         if (allow_multi && !exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160
             && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) {
             const double plain = (double) ((long long) p[r1] - kb) / tile;
             int best = 0;
             double best_fill = std::max(plain + 0.1, 0.75); // (rows of 257: no row count up to 8 reaches 0.9 -- 7 rows are 0.88 -- and one row per tile is 0.50)
             int mx = 0;
-            for (int32_t q = r; q < rows && q - r < 8; ++q) {
+            for (int32_t q = r; q < ce && q - r < 8; ++q) {
                 mx = std::max(mx, p[q + 1] - p[q]);
                 if (mx > tile)
                     break;
@@ -393,7 +390,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     minlen = std::min(minlen, p[q + 1] - p[q]);
                 }
                 multi_lanes_log2 = best <= 2 ? 5 : (best <= 4 ? 4 : 3); // 64 / (rows rounded up to a power of two)
-                pl->multi_window_tiles++;
+                o.multi_window_tiles++;
             }
         }
 #ifdef SPMV_HIP_EXPERIMENTS
@@ -413,9 +410,10 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
 #endif
         if (r1 == r) { // one row longer than a tile
             const long long len = (long long) p[r + 1] - p[r];
-            pl->long_blocks++;
+            o.longest = std::max(o.longest, (int) std::min<long long>(len, INT32_MAX));
+            o.long_blocks++;
             if (!exact && len > split_threshold) {
-                pl->split_rows++;
+                o.split_rows++;
                 for (long long k = p[r]; k < p[r + 1]; k += split_chunk)
                     desc.push_back(make_int4((int) (r | 0x80000000u), (int) k, 0, 0));
             } else {
@@ -425,27 +423,88 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         } else {
             // one lane per row (rows of <= 16 entries) keeps the reference's summation order
             const int lanes_log2 = multi_lanes_log2 >= 0 ? multi_lanes_log2 : (exact ? 0 : lanes_for(maxlen));
-            pl->longest_tile_row = std::max(pl->longest_tile_row, (int) maxlen);
+            o.longest_tile_row = std::max(o.longest_tile_row, (int) maxlen);
             // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
             const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
             const bool uniform = minlen == maxlen && !(flags & SPMV_HIP_FLAG_READ_ROW_PTR);
             if (uniform)
-                pl->uniform_tiles++;
-            stream_tiles++;
-            stream_tile_entries += (long long) p[r1] - p[r];
+                o.uniform_tiles++;
+            o.stream_tiles++;
+            o.stream_tile_entries += (long long) p[r1] - p[r];
             desc.push_back(make_int4(r, p[r], maxlen | (lanes_log2 << 16) | (fast ? (1 << 25) : 0) |
                                                   (uniform ? (1 << 26) : 0), 0));
         }
         r = r1;
     }
-    if (pass == 0) {
-        // (rows with a wave or more to themselves are the same in both tilings and do not count)
-        want_balanced = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
-            && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
-        if (want_balanced || multi_candidates == 0)
-            break;
+    };
+    constexpr int kTileChunks = 64;
+    const int nchunks = (break_rows > 0 || rows < (1 << 18)) ? 1 : kTileChunks;
+    std::vector<int32_t> bound((size_t) nchunks + 1);
+    for (int c = 0; c <= nchunks; ++c) {
+        long long bnd = (long long) rows * c / nchunks;
+        if (pl->block_hint && c > 0 && c < nchunks)
+            bnd -= ((bnd - pl->block_offset) % 3 + 3) % 3;
+        bound[(size_t) c] = (int32_t) bnd;
     }
+    std::vector<int4> desc;
+    long long stream_tiles = 0, stream_tile_entries = 0;
+    int longest = 0;
+    // Two passes at most: the first cuts plain tiles and decides on them whether the matrix gets balanced tiles instead (below);
+    // only if it does not, and rows of 161 ... 512 entries exist, the second cuts again with multi-window tiles allowed.
+    bool want_balanced = false;
+    long long multi_candidates = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool allow_multi = pass == 1;
+        std::vector<Range> part((size_t) nchunks);
+        next_panel = 0;
+        {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const int nthreads = (int) std::min<unsigned>({(unsigned) nchunks, hw, 16u});
+            if (nthreads <= 1) {
+                for (int c = 0; c < nchunks; ++c)
+                    tile_range(bound[(size_t) c], bound[(size_t) c + 1], allow_multi, part[(size_t) c]);
+            } else {
+                std::atomic<int> next{0};
+                std::vector<std::thread> pool;
+                for (int t = 0; t < nthreads; ++t)
+                    pool.emplace_back([&] {
+                        for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1))
+                            tile_range(bound[(size_t) c], bound[(size_t) c + 1], allow_multi, part[(size_t) c]);
+                    });
+                for (auto & th : pool)
+                    th.join();
+            }
+        }
+        desc.clear();
+        stream_tiles = stream_tile_entries = 0;
+        pl->uniform_tiles = pl->long_blocks = pl->split_rows = pl->longest_tile_row = pl->multi_window_tiles = pl->block_cuts = 0;
+        size_t total = 0;
+        for (auto const & o : part)
+            total += o.desc.size();
+        desc.reserve(total + 1);
+        for (auto const & o : part) {
+            desc.insert(desc.end(), o.desc.begin(), o.desc.end());
+            stream_tiles += o.stream_tiles;
+            stream_tile_entries += o.stream_tile_entries;
+            if (pass == 0)
+                multi_candidates += o.multi_candidates;
+            pl->uniform_tiles += o.uniform_tiles;
+            pl->long_blocks += o.long_blocks;
+            pl->split_rows += o.split_rows;
+            pl->longest_tile_row = std::max(pl->longest_tile_row, o.longest_tile_row);
+            pl->multi_window_tiles += o.multi_window_tiles;
+            pl->block_cuts += o.block_cuts;
+            longest = std::max(longest, o.longest);
+        }
+        if (pass == 0) {
+            // (rows with a wave or more to themselves are the same in both tilings and do not count)
+            want_balanced = !exact && tile == 512 && break_rows == 0 && !(flags & SPMV_HIP_FLAG_NO_BALANCED_TILES)
+                && longest > 16 && 2 * stream_tile_entries < stream_tiles * tile;
+            if (want_balanced || multi_candidates == 0)
+                break;
+        }
     }
+    int32_t r = 0;
     // Balanced tiles: when the tiles above come out mostly empty BECAUSE rows are skewed (a long row
     // limits its tile to the rows the wave has lanes for), fill tiles by entries instead -- up to 512 in
     // up to 256 whole rows -- and let csr_segtile_kernel add the rows up by segmented reduction.
