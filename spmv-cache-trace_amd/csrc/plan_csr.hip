@@ -584,9 +584,30 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
         return fail(SPMV_HIP_ERR_INVALID, "rows/cols negative or row_ptr null");
     if (p[0] < 0)
         return fail(SPMV_HIP_ERR_INVALID, "row_ptr[0] is negative");
-    for (int32_t r = 0; r < rows; ++r)
-        if (p[r + 1] < p[r])
+    {
+        // (one pass over row_ptr; side by side on the host's threads once it is long enough to matter)
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int nthreads = rows < (1 << 18) ? 1 : (int) std::min(hw, 16u);
+        std::atomic<int> decreasing{0};
+        auto check = [&](int32_t cb, int32_t ce) {
+            int bad = 0;
+            for (int32_t r = cb; r < ce; ++r)
+                bad |= p[r + 1] < p[r];
+            if (bad)
+                decreasing.store(1);
+        };
+        if (nthreads <= 1) {
+            check(0, rows);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t)
+                pool.emplace_back(check, (int32_t) ((long long) rows * t / nthreads), (int32_t) ((long long) rows * (t + 1) / nthreads));
+            for (auto & th : pool)
+                th.join();
+        }
+        if (decreasing.load())
             return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
+    }
     if (algorithm < SPMV_HIP_CSR_AUTO || algorithm > SPMV_HIP_CSR_WAVETILE)
         return fail(SPMV_HIP_ERR_INVALID, "unknown CSR algorithm");
     if (flags & ~kKnownFlags)
