@@ -75,8 +75,8 @@ extern "C" {
                                             exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
                                                 kernel (bit-exact for any row length).  Default: the row-major arrays in
-                                                place as uniform wave tiles for rows of up to 460 entries (several lanes per
-                                                row of more than 16 entries: 1e-10 class; rows of 161..460 entries in
+                                                place as uniform wave tiles for rows of up to 2048 entries (several lanes per
+                                                row of more than 16 entries: 1e-10 class; rows of 161..2048 entries in
                                                 multi-window tiles) and the column-major kernel -- bit-exact -- for longer
                                                 rows; with SPMV_HIP_FLAG_EXACT_ORDER the column-major kernel takes rows of
                                                 more than 80 entries.  Which path an upload took: spmv_hip_ctx_info [17] */
@@ -143,10 +143,11 @@ extern "C" {
                                              columns -- nearly every line of x ends up in every XCD's L2 -- not the head; DESIGN.md
                                              section 3.3).  The dense array is scratch: multiplies through ONE plan must then be
                                              ordered (same stream), like the runs of a context.  plan_info[27], [28] */
-#define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 129 ... 512 entries, which fill a
-                                             512-entry tile badly (one row of 361: 70 %), are taken up to 8 at a time by one wave
-                                             that walks them in windows of 512 entries and carries the row sums in registers
-                                             (7 rows of 361 = 4.94 windows).  1e-10 class like every row of more than 16 entries;
+#define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 161 ... 2048 entries, which fill a
+                                             512-entry tile badly (one row of 361: 70 %) or do not fit one at all (a wave per row, or
+                                             chunks that meet in atomics), are taken two to eight at a time by one wave that walks
+                                             them in windows of 512 entries and carries the row sums in registers (7 rows of 361 =
+                                             4.94 windows): no atomics, the same y on every run.  1e-10 class like every row of more than 16 entries;
                                              never under SPMV_HIP_FLAG_EXACT_ORDER */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 

@@ -388,9 +388,9 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     const bool exact = (c->flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
     // (round 4: multi-window tiles -- a wave takes up to 8 such rows and walks them in windows of 512 entries -- fill the tiles of
     // these lengths again; SPMV_HIP_FLAG_NO_MULTI_WINDOW brings the column-major kernel back for them)
-    // Rows of 461 entries and more -- one row to a tile (90 % full: nothing for more windows to gain), or split into chunks that
-    // meet in atomics -- stay with the column-major kernel: 0.69-0.72 against 0.64-0.70 in place (profiles/r04_ell_long_rows.md).
-    const bool poor_fill = (row_length > 160 && row_length <= 460 && (c->flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) || row_length > 460;
+    // Rows of more than 2048 entries -- a wave (or several, meeting in atomics) per row -- stay with the column-major kernel:
+    // 0.65-0.69 either way, and the column-major kernel keeps the reference's order (profiles/r04_ell_long_rows.md).
+    const bool poor_fill = (row_length > 160 && row_length <= 2048 && (c->flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) || row_length > 2048;
     c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR)
         && (exact ? row_length <= kEllInPlaceMaxLength : !poor_fill || c->ell_in_place_any_length);
     if (c->ell_in_place_any_length)

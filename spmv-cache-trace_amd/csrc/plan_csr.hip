@@ -358,17 +358,24 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         int multi_lanes_log2 = -1;
         // (measured on ELLPACK bands, profiles/r04_ell_long_rows.md: 177 ... 441 per row 0.69-0.72 -> 0.76-0.84 of the roofline; rows
         // of up to 160 keep the plain tile -- three rows of 141 fill it to 83 % and have their x window, 0.93 against 0.90)
-        if (!exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160 && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
+        // (... and rows of 513 ... 2048 entries, which otherwise have a wave each -- or, beyond 512, chunks that meet in atomics --
+        // are taken two to eight at a time the same way: no atomics, the same y on every run)
+        const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= 2048;
+        if (!exact && tile == 512 && break_rows == 0 && !pl->block_hint && multi_start && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
             ++o.multi_candidates;
-        if (allow_multi && !exact && tile == 512 && break_rows == 0 && !pl->block_hint && r1 > r && maxlen > 160
+        if (allow_multi && !exact && tile == 512 && break_rows == 0 && !pl->block_hint && multi_start
             && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) {
-            const double plain = (double) ((long long) p[r1] - kb) / tile;
+            const double plain = r1 > r ? (double) ((long long) p[r1] - kb) / tile : 0.0;
             int best = 0;
-            double best_fill = std::max(plain + 0.1, 0.75); // (rows of 257: no row count up to 8 reaches 0.9 -- 7 rows are 0.88 -- and one row per tile is 0.50)
+            // (rows of 257: no row count up to 8 reaches 0.9 -- 7 rows are 0.88 -- and one row per tile is 0.50.  A plain tile of ONE
+            // row is given up for any two rows that fill their windows to 3/4: a row of 479 has a tile 94 % full to itself and runs
+            // at 0.67 of the roofline -- a descriptor, a y access and a 64-lane sum per row -- where two rows of 511 in two windows
+            // run at 0.85, profiles/r04_ell_long_rows.md)
+            double best_fill = r1 - r >= 2 ? std::max(plain + 0.1, 0.75) : 0.75;
             int mx = 0;
             for (int32_t q = r; q < ce && q - r < 8; ++q) {
                 mx = std::max(mx, p[q + 1] - p[q]);
-                if (mx > tile)
+                if (mx > 2048)
                     break;
                 const long long e = (long long) p[q + 1] - kb;
                 const long long windows = (e + tile - 1) / tile;

@@ -844,7 +844,7 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
             assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
 
 
-@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 460, 461, 512, 600])
+@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 479, 511, 512, 600, 1025, 2048, 2049])
 def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
     """ELLPACK runs in place as wave tiles.  Default: rows of more than 16 entries are summed by several lanes (1e-10);
     EXACT_ORDER keeps one lane per row (in place up to 80 entries per row, column-major beyond) and ELL_COLUMN_MAJOR
@@ -872,10 +872,10 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.run()
             assert_ell(c2.get_y(), want, L, flags, ec, ev, x, y0, 2, "ell L=%d flags %x" % (L, flags))
             if flags == 0 and L > 16:
-                # several lanes per row on the row-major arrays in place (rows of 161..460 entries in multi-window tiles, round 4);
-                # rows of more than 460 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
-                assert (c2.info()["row_blocks"] > 0) == (L <= 460), (L, c2.info())
-                assert c2.info()["ell_path"] == (1 if L <= 460 else 2)
+                # several lanes per row on the row-major arrays in place (rows of 161..2048 entries in multi-window tiles, round 4);
+                # rows of more than 2048 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
+                assert (c2.info()["row_blocks"] > 0) == (L <= 2048), (L, c2.info())
+                assert c2.info()["ell_path"] == (1 if L <= 2048 else 2)
         finally:
             c2.close()
 
@@ -1444,7 +1444,7 @@ def test_coo_and_hybrid_column_panels(oracle):
         c2.close()
 
 
-@pytest.mark.parametrize("case", ["uniform361", "mixed", "random_columns", "few_values"])
+@pytest.mark.parametrize("case", ["uniform361", "mixed", "random_columns", "few_values", "very_long"])
 def test_multi_window_tiles(oracle, case):
     """Rows of 161 ... 512 entries are taken up to 8 at a time by one wave that walks them in windows of 512 entries, the row
     sums carried in registers (plan_info[29]): against the oracle, against the plan without them (SPMV_HIP_FLAG_NO_MULTI_WINDOW),
@@ -1457,13 +1457,17 @@ def test_multi_window_tiles(oracle, case):
     rows, cols = 6000, 40000
     if case == "uniform361":
         lens = np.full(rows, 361)
+    elif case == "very_long":  # rows of 513 ... 2048 entries: two to eight per wave instead of a wave (or chunks meeting in atomics) each
+        rows = 1500
+        lens = np.where(rng.random(rows) < 0.8, rng.integers(513, 2049, rows), rng.integers(0, 600, rows))
+        lens[:12] = [513, 2048, 2048, 1024, 1025, 700, 3, 600, 2049, 900, 4000, 800]
     else:
         lens = np.where(rng.random(rows) < 0.7, rng.integers(161, 513, rows), rng.integers(0, 160, rows))
         lens[:40] = rng.choice([161, 255, 256, 257, 480, 511, 512], size=40)
     p = np.zeros(rows + 1, dtype=np.int64)
     np.cumsum(lens, out=p[1:])
     p = p.astype(np.int32)
-    wide = case == "random_columns"
+    wide = case in ("random_columns", "very_long")
     c = np.concatenate([np.sort(rng.choice(cols if wide else 3000, size=n, replace=False) + (0 if wide else min(r * 6, cols - 3000)))
                         for r, n in enumerate(lens)]).astype(np.int32)
     v = rng.uniform(-1.0, 1.0, size=len(c))
@@ -1496,8 +1500,8 @@ def test_multi_window_tiles(oracle, case):
         plan.close()
     got, got_out, got_other, info = results[0]
     assert info["row_blocks"] < 0.75 * results[capi.FLAG_NO_MULTI_WINDOW][3]["row_blocks"], "fewer, fuller tiles"
-    assert_close(got, want, scale, what=case, nterms=512)
-    assert_close(got_other, want, scale, what=case + ", other column array", nterms=512)
-    assert_close(got_out, oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4), 2 * scale, what=case + ", y_out", nterms=1024)
-    assert_close(results[capi.FLAG_NO_MULTI_WINDOW][0], want, scale, what=case + ", plain tiles", nterms=512)
+    assert_close(got, want, scale, what=case, nterms=4096)
+    assert_close(got_other, want, scale, what=case + ", other column array", nterms=4096)
+    assert_close(got_out, oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4), 2 * scale, what=case + ", y_out", nterms=8192)
+    assert_close(results[capi.FLAG_NO_MULTI_WINDOW][0], want, scale, what=case + ", plain tiles", nterms=4096)
     assert_bitexact(results[capi.FLAG_EXACT_ORDER][0], want, case + ", exact order")

@@ -1,15 +1,15 @@
-# tools/ell_long_rows.sh -- on the GPU box: ELLPACK bands of 177 ... 601 entries per row through the context API: default flags
-# (in place, multi-window tiles), SPMV_HIP_FLAG_NO_MULTI_WINDOW (0x8000000: the column-major kernel for 161..512) and
-# SPMV_HIP_FLAG_ELL_COLUMN_MAJOR (0x200)
+# tools/ell_long_rows.sh -- on the GPU box: ELLPACK bands of 141 ... 2001 entries per row through the context API: default flags
+# (in place; rows of 161..2048 entries in multi-window tiles, longer rows column-major), SPMV_HIP_FLAG_NO_MULTI_WINDOW (0x8000000:
+# round 3's rule, the column-major kernel from 161) and SPMV_HIP_FLAG_ELL_COLUMN_MAJOR (0x200)
 cd ${GRAFT_REPO_ROOT:-.}
-for b in 70 88 100 128 150 180 220 255 300; do
-  for flags in 0 0x8000000 0x200; do
-  python3 bench.py --matrix synthetic:banded:1000000,$b --format ell --flags $flags --steps 10 --warmup 3 --no-cpu-baseline --no-reference-protocol > gpurun_out/ell_tmp.log 2> gpurun_out/ell_tmp.err || { echo FAILED; tail -3 gpurun_out/ell_tmp.err; }
-  python3 - $b $flags <<'PY'
+for spec in 1000000,70 1000000,88 1000000,100 1000000,128 1000000,150 1000000,180 1000000,220 1000000,239 1000000,255 400000,300 400000,400 400000,500 400000,750 400000,1000 200000,1100; do
+  for flags in 0 0x8000000; do
+  python3 bench.py --matrix synthetic:banded:$spec --format ell --flags $flags --steps 10 --warmup 3 --no-cpu-baseline --no-reference-protocol > gpurun_out/ell_tmp.log 2> gpurun_out/ell_tmp.err || { echo FAILED; tail -3 gpurun_out/ell_tmp.err; }
+  python3 - $spec $flags <<'PY'
 import json, sys
 d = json.loads([l for l in open("gpurun_out/ell_tmp.log") if l.startswith("{")][-1])
 r = d["roofline"]
-print("banded b=%s flags %s: %.1f us frac %.3f L=%s tiles=%s" % (sys.argv[1], sys.argv[2], r["kernel_us"], r["frac"], d["config"].get("ell_row_length"), d["config"].get("tiles")))
+print("banded %s flags %s: %.1f us frac %.3f L=%s tiles=%s" % (sys.argv[1], sys.argv[2], r["kernel_us"], r["frac"], d["config"].get("ell_row_length"), d["config"].get("tiles")))
 PY
   done
 done
