@@ -149,6 +149,16 @@ extern "C" {
                                              them in windows of 512 entries and carries the row sums in registers (7 rows of 361 =
                                              4.94 windows): no atomics, the same y on every run.  1e-10 class like every row of more than 16 entries;
                                              never under SPMV_HIP_FLAG_EXACT_ORDER */
+#define SPMV_HIP_FLAG_ROW_GROUPS 0x10000000u /* plan_csr_compress, OPT-IN: row-group tiles.  A plan in which most tiles are the interior
+                                             of a stencil or band with rows of 17 ... 64 entries (uniform, shifted, with an x window)
+                                             multiplies those with 2 ... 8 lanes per row, each adding up to twelve consecutive entries
+                                             in registers -- no products parked in LDS, 8 instead of 6 waves per SIMD
+                                             (csr_rowgroup.hpp) -- and the other tiles with a second launch.  Same 1e-10 class.  Off by
+                                             default because it was measured SLOWER (KKT-like matrix 797 vs 740 us, 27 diagonals 181 vs
+                                             176 us: a lane that owns 72 consecutive bytes makes every load instruction of the wave
+                                             touch all 36 cache lines of the tile, five times over).  Never
+                                             under SPMV_HIP_FLAG_EXACT_ORDER, with a value dictionary or with block / segment
+                                             windows.  plan_info[30] */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -366,7 +376,9 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
  *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries
  *        [27] hub columns (see SPMV_HIP_FLAG_HUB_COLUMNS)  [28] the entries that refer to them
- *        [29] multi-window tiles (several rows of 161 ... 512 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW) */
+ *        [29] multi-window tiles (several rows of 161 ... 512 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW),
+ *        [30] row-group tiles (rows of 17 ... 64 entries, 2 ... 8 lanes per row: SPMV_HIP_FLAG_ROW_GROUPS, opt-in; 0 unless
+ *        they are the majority of the plan's tiles) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

@@ -43,7 +43,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_NO_MULTI_WINDOW
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_NO_MULTI_WINDOW | SPMV_HIP_FLAG_ROW_GROUPS
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
 #endif
@@ -101,6 +101,9 @@ struct spmv_hip_plan {
     int blockwin_tiles = 0;
     int32_t * d_rest_tiles = nullptr; // with block / segment windows: the tiles NOT marked for them (what csr_wavetile_kernel<LIST> multiplies)
     int nrest_tiles = 0;
+    // row-group plans (csr_rowgroup.hpp): the tiles csr_rowgroup_kernel multiplies, and the others (csr_wavetile_kernel<LIST>)
+    int32_t * d_group_tiles = nullptr, * d_group_rest = nullptr;
+    int ngroup_tiles = 0, ngroup_rest = 0;
     // segment windows (csr_segwin.hpp): x staged through LDS per block of seg_tiles_per_block tiles, in up to 8 column segments
     spmv::SegWinBlock * d_segblocks = nullptr;
     int nsegblocks = 0, seg_tiles_per_block = 0, segwin_tiles = 0, segwin_slots = 0;

@@ -234,6 +234,26 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, false, false, false, true>), grid, dim3(256), 0, s,
                                        pl->nrest_tiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_rest_tiles);
+            } else if (pl->d_group_tiles && c16 && x32 && !xcd && !exact && pl->tile == 512 && (!peers || pl->split_rows == 0)) {
+                // most tiles are rows of 17 ... 64 entries of a stencil or band: a group of lanes per row (csr_rowgroup.hpp),
+                // then the other tiles (the x-window variant over a list)
+                const dim3 grid((unsigned) ((pl->ngroup_tiles + 3) / 4)), rest((unsigned) ((pl->ngroup_rest + 3) / 4));
+                if (peers) { // one process per GPU: both launches forward their row sums
+                    hipLaunchKernelGGL((spmv::csr_rowgroup_kernel<true>), grid, dim3(256), 0, s, pl->ngroup_tiles, pl->d_group_tiles, pl->d_tiles, a, x, y_in,
+                                       y, pl->cols, pl->d_patterns, *peers);
+                    if (pl->ngroup_rest > 0)
+                        hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256, false, false, true, true>), rest, dim3(256), 0, s,
+                                           pl->ngroup_rest, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                           spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, *peers, pl->d_group_rest);
+                    *fused = 1;
+                } else {
+                    hipLaunchKernelGGL((spmv::csr_rowgroup_kernel<false>), grid, dim3(256), 0, s, pl->ngroup_tiles, pl->d_group_tiles, pl->d_tiles, a, x, y_in,
+                                       y, pl->cols, pl->d_patterns);
+                    if (pl->ngroup_rest > 0)
+                        hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, true, false, 0, 256, false, false, false, true>), rest, dim3(256), 0, s,
+                                           pl->ngroup_rest, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
+                                           spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_group_rest);
+                }
             } else
             // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants

@@ -204,6 +204,32 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         for (int w = 0; w < pl->ntiles; ++w)
             pl->nrest_tiles += !(d[(size_t) w].z & spmv::kTileMetaBlockWin);
     }
+    // row-group plans (csr_rowgroup.hpp, opt-in): made anew after every change of the tile marks
+    for (int32_t ** q : {&pl->d_group_tiles, &pl->d_group_rest})
+        if (*q) {
+            (void) hipFree(*q);
+            *q = nullptr;
+        }
+    pl->ngroup_tiles = pl->ngroup_rest = 0;
+    if ((pl->flags & SPMV_HIP_FLAG_ROW_GROUPS) && compressed && pl->nvalues == 0 && !pl->d_blocks && !pl->d_segblocks && pl->tile == 512 && !pl->balanced && pl->cols < (1 << 29)
+        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_XCD_REMAP))) {
+        std::vector<int32_t> group, rest;
+        for (int w = 0; w < pl->ntiles; ++w) {
+            const long long k1 = d[(size_t) w + 1].y, entries = k1 - d[(size_t) w].y;
+            const long long rows = (long long) (d[(size_t) w + 1].x & 0x7FFFFFFF) - (d[(size_t) w].x & 0x7FFFFFFF);
+            (spmv::rowgroup_tile(d[(size_t) w].x, d[(size_t) w].z, entries, rows, k1, pl->nnz) ? group : rest).push_back(w);
+        }
+        if (2 * group.size() > (size_t) pl->ntiles) {
+            pl->ngroup_tiles = (int) group.size();
+            pl->ngroup_rest = (int) rest.size();
+            HIP_TRY(hipMalloc((void **) &pl->d_group_tiles, group.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(pl->d_group_tiles, group.data(), group.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (!rest.empty()) {
+                HIP_TRY(hipMalloc((void **) &pl->d_group_rest, rest.size() * sizeof(int32_t)));
+                HIP_TRY(hipMemcpy(pl->d_group_rest, rest.data(), rest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
+    }
     return SPMV_HIP_OK;
 }
 
@@ -723,6 +749,10 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
         (void) hipFree(pl->d_segblocks);
     if (pl->d_rest_tiles)
         (void) hipFree(pl->d_rest_tiles);
+    if (pl->d_group_tiles)
+        (void) hipFree(pl->d_group_tiles);
+    if (pl->d_group_rest)
+        (void) hipFree(pl->d_group_rest);
     if (pl->d_vidx)
         (void) hipFree(pl->d_vidx);
     if (pl->d_vtab)
@@ -1477,15 +1507,16 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[30] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[31] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
                            pl->narrow_entries, pl->uniform_rows, pl->inner ? 1 : 0, pl->balanced ? 1 : 0, pl->nvalues,
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
-                           pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles};
-    for (int i = 0; i < n && i < 30; ++i)
+                           pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles,
+                           pl->ngroup_tiles};
+    for (int i = 0; i < n && i < 31; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -13,6 +13,7 @@
 #include "tile_common.hpp"
 #include "csr_basic.hpp"
 #include "csr_wavetile.hpp"
+#include "csr_rowgroup.hpp"
 #include "csr_segtile.hpp"
 #include "csr_panels.hpp"
 #include "csr_blockwin.hpp"

@@ -37,6 +37,7 @@ FLAG_FUSED_PEER_STORE = 0x1000000
 FLAG_NO_BLOCK_TILES = 0x2000000
 FLAG_HUB_COLUMNS = 0x4000000
 FLAG_NO_MULTI_WINDOW = 0x8000000
+FLAG_ROW_GROUPS = 0x10000000  # opt-in (measured slower: include/spmv_hip.h)
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -310,12 +311,12 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(30, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 30))
+        out = np.zeros(31, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 31))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
                 "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
-                "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles"]
+                "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):
