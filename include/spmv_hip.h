@@ -152,11 +152,11 @@ extern "C" {
 #define SPMV_HIP_FLAG_ROW_GROUPS 0x10000000u /* plan_csr_compress, OPT-IN: row-group tiles.  A plan in which most tiles are the interior
                                              of a stencil or band with rows of 17 ... 64 entries (uniform, shifted, with an x window)
                                              multiplies those with 2 ... 8 lanes per row, each adding up to twelve consecutive entries
-                                             in registers -- no products parked in LDS, 8 instead of 6 waves per SIMD
-                                             (csr_rowgroup.hpp) -- and the other tiles with a second launch.  Same 1e-10 class.  Off by
+                                             in registers -- no products parked in LDS (csr_rowgroup.hpp) -- and the other tiles with a
+                                             second launch.  Same 1e-10 class.  Off by
                                              default because it was measured SLOWER (KKT-like matrix 797 vs 740 us, 27 diagonals 181 vs
                                              176 us: a lane that owns 72 consecutive bytes makes every load instruction of the wave
-                                             touch all 36 cache lines of the tile, five times over; DESIGN.md section 3.6).  Never
+                                             touch all 36 cache lines of the tile, five times over; DESIGN.md section 3.1b).  Never
                                              under SPMV_HIP_FLAG_EXACT_ORDER, with a value dictionary or with block / segment
                                              windows.  plan_info[30] */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */

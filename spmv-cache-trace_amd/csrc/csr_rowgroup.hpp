@@ -3,17 +3,17 @@
 //
 // The reference's loop (src/matrix/csr-matrix-spmv.cpp:21-33) walks a row left to right.  csr_wavetile_kernel deals such a
 // tile's entries to the lanes four at a time, whatever row they belong to, parks the products in LDS and has 2 or 4 lanes per
-// row read them back -- 36 LDS instructions per wave and 26.6 KB of LDS per workgroup (6 waves per SIMD) with the x window
+// row read them back -- 36 LDS instructions per wave (and, when this kernel was written, 26.6 KB of LDS per workgroup: 6 waves
+// per SIMD; 18.5 KB and 8 since the window lives inside the product slice)
 // (profiles/r04_prof_kkt_csr_extra_summary.md: two thirds of the wave cycles wait for memory with that few waves in flight).
 //
 // Here a tile that is uniform (all rows equally long), shifted (every row has the first row's columns moved along with it) and
 // has an x window -- the marks csr_tile_compress_kernel / csr_pattern_assign_kernel set -- is multiplied by G lanes per row,
-// G = as many as the tile's rows leave room for in the wave (2 ... 8): a lane loads E = ceil(len / G) <= 12 CONSECUTIVE values of its row (straight from the value array, 16 bytes
-// at a time, consecutive across the lanes of a row and across rows: coalesced, every byte fetched once), multiplies them by x
-// from the wave's window and adds them up in registers; the G partial sums of a row meet through the lane crossbar.  No
-// product is parked: 5 LDS writes (window, positions) + 12 reads + 3 crossbar steps per wave, 9 KB of LDS per workgroup, 8
-// waves per SIMD.  The window and the positions come from the tile's pattern record exactly as in tile_products_xseg /
-// tile_products_xwin (csr_wavetile.hpp).
+// G = as many as the tile's rows leave room for in the wave (2 ... 8): a lane loads E = ceil(len / G) <= 12 CONSECUTIVE values
+// of its row (straight from the value array, 16 bytes at a time), multiplies them by x from the wave's window and adds them up
+// in registers; the G partial sums of a row meet through the lane crossbar.  No product is parked: 5 LDS writes (window,
+// positions) + 3 + E reads + 3 crossbar steps per wave, 9 KB of LDS per workgroup, 8 waves per SIMD.  The window and the
+// positions come from the tile's pattern record exactly as in tile_products_xseg / tile_products_xwin (csr_wavetile.hpp).
 //
 // OPT-IN (SPMV_HIP_FLAG_ROW_GROUPS): measured SLOWER than csr_wavetile_kernel's x-window variant -- KKT-like matrix 797 vs 740
 // us, 27 diagonals 181 vs 176 us (profiles/r04_rowgroup_ab_*.log).  A lane that owns 72 consecutive bytes makes each of the

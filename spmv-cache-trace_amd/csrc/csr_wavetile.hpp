@@ -587,7 +587,7 @@ __device__ __forceinline__ void tile_rows_multi_window(
 // whose other tiles belong to a window kernel (a launch over ALL tiles in which 99.8 % of the waves read a descriptor
 // and leave cost the KKT-like matrix 61 of 1040 us).
 template <int TILE, bool C16, bool X32, bool XCD, int ABL = 0, int XW = 0, bool PANELS = false, bool VI = false, bool PEER = false, bool LIST = false>
-__global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wavetile_kernel(
+__global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kernel(
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
@@ -603,7 +603,6 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
-    __shared__ double xwin_all[XW ? 4 : 1][XW ? XW : 1];                // XW variant: the tile's window of x
     __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -625,6 +624,12 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             w = __builtin_amdgcn_readfirstlane(tile_list[w]);
     }
     double * prod = prod_all[wave];
+    // XW variant: the tile's window of x lives in the END of the wave's product slice (round 4; it had 2 KB of its own: 26.6 KB per
+    // workgroup, 6 waves per SIMD -- now 18.5 KB, 8).  The slots it covers belong to the products of the tile's LAST quad only
+    // (256 * (QUADS - 1) <= TILE + 4 - XW), and a lane has read the x entries of that quad before any lane writes a product of
+    // it: same-wave LDS operations execute in order, and the compiler keeps a store behind the loads that may alias it.
+    static_assert(XW == 0 || TILE + 4 - XW >= 256 * (QUADS - 1), "the window may only overlap the last quad's product slots");
+    double * xwin = prod + (XW ? TILE + 4 - XW : 0);
 
     // (VI: waves past the last tile read its descriptor and leave after the table barrier)
     const int wd = VI ? (w < ntiles ? w : ntiles - 1) : w;
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
         // of neighbouring tiles that share the first/last quad are multiplied as well and never
         // read back
         if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
-            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0],
+            tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin,
                                       reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]),
                                       patterns + (size_t) cbase * kPatStride, r0,
                                       a + kb, x, cols - 1, last, lane,
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 && XW == 0 ? 8 : 4)) void csr_wav
             const bool pattern = (meta & kTileMetaPattern) != 0;
             const int32_t * pat = patterns + (size_t) (pattern ? cbase : 0) * kPatStride;
             const int cb = pattern ? r0 + __builtin_amdgcn_readfirstlane(pat[3]) : cbase;
-            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin_all[XW ? wave : 0], first_row_all[C16 ? wave : 0], j16 + kb,
+            tile_products_xwin<QUADS, (XW > 0 ? XW : 64)>(prod, xwin, first_row_all[C16 ? wave : 0], j16 + kb,
                                       pattern ? pat + kPatRel : j + k0, pattern ? r0 : 0,
                                       a + kb, x + cb, cb, (unsigned) (cols - 1 - cb), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
