@@ -103,6 +103,8 @@ def parse_args():
     ap.add_argument("--events", choices=["launch", "region"], default="region",
                     help="one HIP event pair around the K timed launches (default; mean launch duration = span / K, "
                          "launch gaps included), or a pair around every launch (adds ~5 us of gap per step)")
+    ap.add_argument("--no-host-boundary", action="store_true",
+                    help="skip the host_boundary leg (upload from host arrays; one multiply with x sent and y fetched over PCIe)")
     ap.add_argument("--partition", choices=["rows", "nnz"], default="rows",
                     help="N > 1: the reference's static row chunks (default), or a split on row boundaries with "
                          "equal stored entries per rank (uneven rows)")
@@ -413,6 +415,37 @@ class ContextOperator:
 
     def y(self):
         return self.ctx.get_y()
+
+
+def host_boundary(capi, device_index, rows, cols, A, x, nnz, runs=5):
+    """What the Level-1 boundary costs when the caller's arrays live in HOST memory (the reference's adapters: init uploads the matrix
+    once, run multiplies on the device): the upload (PCIe + plan), and one multiply with x sent and y fetched around it -- the
+    PCIe-inclusive rate of a caller that keeps nothing resident.  Never `value`."""
+    t0 = time.perf_counter()
+    ctx = capi.Context(device_index, 0)
+    ctx.upload_csr(rows, cols, A["p"], A["c"], A["v"])
+    ctx.set_x(x)
+    ctx.run(1)  # first multiply: the plan's one-time checks
+    upload_s = time.perf_counter() - t0
+    ts = []
+    for _ in range(runs):
+        t1 = time.perf_counter()
+        ctx.set_x(x)
+        ctx.run(1)
+        y = ctx.get_y()
+        ts.append(time.perf_counter() - t1)
+    del y
+    ctx.close()
+    ts.sort()
+    med = ts[len(ts) // 2]
+    matrix_bytes = 12.0 * nnz + 4.0 * (rows + 1)
+    return {"upload_ms": round(upload_s * 1e3, 1), "upload_bytes": int(matrix_bytes),
+            "upload_gbs": round(matrix_bytes / upload_s / 1e9, 2),
+            "set_x_run_get_y_ms": round(med * 1e3, 3), "vector_bytes_over_pcie": int(8 * (rows + cols)),
+            "gflops_pcie_inclusive": round(2.0 * nnz / med / 1e9, 1),
+            "note": "spmv_hip_create + upload_csr (host arrays -> device, plan, first multiply) once; then the median of %d x "
+                    "(set_x from host, run, get_y to host), pageable host memory, host clock.  The timed region of `value` has x, y "
+                    "and the matrix resident in HBM, as the reference's run() has them resident in DRAM" % runs}
 
 
 def time_launches(torch, fn, steps, warmup):
@@ -1137,6 +1170,11 @@ def main():
                 code, message = 1, "bench.py: parity check failed: max relative error %s > 1e-10" % out["parity"]["max_rel_err"]
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not use_dist and fmt == "csr" and not args.no_host_boundary and host_arrays is not None and code == 0:
+            try:
+                out["host_boundary"] = host_boundary(capi, device.index or 0, rows, cols, host_arrays, x, nnz)
+            except Exception as e:  # reported, never fatal: the line's value does not depend on it
+                out["host_boundary"] = {"error": str(e)[:200]}
         if world == 1 and not use_dist and not args.no_reference_protocol and code == 0:
             big = nnz > 200e6
             rp = reference_protocol(args, fmt, 10 if big else 20)
