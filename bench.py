@@ -103,6 +103,9 @@ def parse_args():
     ap.add_argument("--events", choices=["launch", "region"], default="region",
                     help="one HIP event pair around the K timed launches (default; mean launch duration = span / K, "
                          "launch gaps included), or a pair around every launch (adds ~5 us of gap per step)")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the short measurements of north_star's synthetic banded / random CSR matrices that the default "
+                         "workload's line carries beside config3_kkt")
     ap.add_argument("--no-host-boundary", action="store_true",
                     help="skip the host_boundary leg (upload from host arrays; one multiply with x sent and y fetched over PCIe)")
     ap.add_argument("--partition", choices=["rows", "nnz"], default="rows",
@@ -976,11 +979,10 @@ def main():
     # configuration BASELINE.json partitions over 8 GPUs is nlpkkt200 (27 entries per row).  So that a run at N = 1, 2, 4, 8
     # also says what THAT matrix does on the same ranks with the same gather scheme, the default line carries a short
     # measurement of its stand-in (30 timed steps after 10 warm-up steps; never part of `value`).
-    config3 = None
-    if fmt == "csr" and args.matrix is None and args.workload == "poisson2d" and args.grid == 4096 and not args.no_config3:
+    def partitioned_companion(spec3, label3, note3):
         import argparse as _ap
         a3 = _ap.Namespace(**vars(args))
-        a3.matrix, a3.expand_symmetric, a3.partition = "synthetic:kkt:200", False, "rows"
+        a3.matrix, a3.expand_symmetric, a3.partition = spec3, False, "rows"
         t3 = time.perf_counter()
         rows3, cols3, nnz3, p3, c3, v3, b3, e3, _, keep3 = load_csr(a3, rank, world)
         if nnz3 is None:
@@ -1016,20 +1018,35 @@ def main():
         if use_dist:
             dist.all_reduce(el3, op=dist.ReduceOp.MAX)
         i3 = op3.plan.info()
-        config3 = {"workload": "kkt-27pt-200^3 (nlpkkt200-like), csr, %s" % ("rows/%d static chunks" % world if use_dist else "single GPU"),
-                   "rows": rows3, "nnz": nnz3, "steps": K3, "warmup": W3, "gather": scheme3 or ("rccl" if use_dist else None),
-                   "ms_per_step": round(el3.item() / K3 * 1e3, 5), "gflops": round(2.0 * nnz3 * K3 / el3.item() / 1e9, 2),
-                   "frac_algorithmic_whole_step": round(synth.csr_bytes(rows3, cols3, nnz3) / (el3.item() / K3) / 1e9 / (HBM_PEAK_GBS * world), 4),
-                   "local_tiles": i3["row_blocks"], "local_shifted_tiles": i3["shifted_tiles"], "local_x_window_tiles": i3["xwin_tiles"],
-                   "setup_s": round(time.perf_counter() - t3 - el3.item(), 1),
-                   "strong_scaling_model": strong_scaling_model(rows3, el3.item() / K3 * 1e6 * (world if use_dist else 1)),
-                   "note": "whole-job GFLOP/s of BASELINE configs[3]'s stand-in on these ranks; parity of this matrix and path: "
-                           "tests/test_gpu_fullsize.py, tests/test_gpu_peer.py; strong_scaling_model: t1 = this run's step time"
-                           + (" x ranks (an estimate of the single-GPU time)" if use_dist else "")}
+        out3 = {"workload": "%s, csr, %s" % (label3, "rows/%d static chunks" % world if use_dist else "single GPU"),
+                "rows": rows3, "nnz": nnz3, "steps": K3, "warmup": W3, "gather": scheme3 or ("rccl" if use_dist else None),
+                "ms_per_step": round(el3.item() / K3 * 1e3, 5), "gflops": round(2.0 * nnz3 * K3 / el3.item() / 1e9, 2),
+                "frac_algorithmic_whole_step": round(synth.csr_bytes(rows3, cols3, nnz3) / (el3.item() / K3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                "local_tiles": i3["row_blocks"], "local_shifted_tiles": i3["shifted_tiles"], "local_x_window_tiles": i3["xwin_tiles"],
+                "local_column_panel_tiles": i3["panel_tiles"],
+                "setup_s": round(time.perf_counter() - t3 - el3.item(), 1),
+                "strong_scaling_model": strong_scaling_model(rows3, el3.item() / K3 * 1e6 * (world if use_dist else 1)),
+                "note": note3 + "; strong_scaling_model: t1 = this run's step time"
+                        + (" x ranks (an estimate of the single-GPU time)" if use_dist else "")}
         if not op3.collective:
             op3.close()
         del op3, keep3, p3, c3, v3
         torch.cuda.empty_cache()
+        return out3
+
+    config3 = None
+    north_star = {}
+    if fmt == "csr" and args.matrix is None and args.workload == "poisson2d" and args.grid == 4096 and not args.no_config3:
+        config3 = partitioned_companion("synthetic:kkt:200", "kkt-27pt-200^3 (nlpkkt200-like)",
+                                        "whole-job GFLOP/s of BASELINE configs[3]'s stand-in on these ranks; parity of this matrix and "
+                                        "path: tests/test_gpu_fullsize.py, tests/test_gpu_peer.py")
+        # north_star: "throughput on synthetic banded/random CSR of stated nnz is reported at 1, 2, 4 and 8 GPUs": the same short
+        # measurement for the two synthetic families (108 M and 96 M entries), on the same ranks, never part of `value`
+        if not args.no_north_star:
+            north_star["banded"] = partitioned_companion("synthetic:banded:4000000,13", "banded-4M-27diagonals",
+                                                         "whole-job GFLOP/s on these ranks; parity: tests/test_gpu_parity.py, bench.py --workload banded")
+            north_star["random"] = partitioned_companion("synthetic:random:4000000,24,3", "random-4M-24perrow",
+                                                         "whole-job GFLOP/s on these ranks; parity: tests/test_gpu_parity.py, bench.py --workload random24")
 
     # ---- companions: BASELINE configs[2] and [4] on this GPU (default workload, one GPU) -------------------------------------
     companions = {}
@@ -1143,6 +1160,8 @@ def main():
             out[k] = companions[k]
         if config3 is not None:
             out["config3_kkt"] = config3
+        if north_star:
+            out["north_star_synthetic"] = north_star
         if gather_check:
             out["gather_check"] = gather_check
             if not gather_check["pass"]:
