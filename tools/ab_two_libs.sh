@@ -1,8 +1,11 @@
 #!/bin/bash
-# A/B of two library builds on one box: prev (libspmv_hip_prev.so) and new, alternating processes
+# tools/ab_two_libs.sh [TAG] -- on the GPU box: A/B of two library BUILDS, alternating processes (tools/ab.py compares plans of
+# one build).  Before gpurun: copy the build to compare against to spmv-cache-trace_amd/libspmv_hip_prev.so (git-ignored,
+# travels with the snapshot), then build the new sources.  Log: gpurun_out/TAG.log
 set -e
 mkdir -p gpurun_out
-out=gpurun_out/r04_window_alias_ab.log
+out=gpurun_out/${1:-ab_two_libs}.log
+[ -e spmv-cache-trace_amd/libspmv_hip_prev.so ] || { echo "no spmv-cache-trace_amd/libspmv_hip_prev.so"; exit 1; }
 : > $out
 for m in synthetic:kkt:200 synthetic:banded:4000000,13 synthetic:banded:2000000,30; do
   for rep in 1 2; do
