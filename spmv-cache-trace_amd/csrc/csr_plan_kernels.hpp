@@ -157,6 +157,21 @@ static __global__ __launch_bounds__(64) void csr_pattern_build_kernel(
             for (int i = 0; i < cnt && xo + i < 256; ++i)
                 pat[kPatSrc + xo + i] = col - r0 + i;
         }
+        // four window positions per row position (see tile_common.hpp), for both window forms
+        unsigned f_runs[4], f_win[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = lane + i, rr = q / len, qq = q - rr * len; // (every lane takes part in the shuffles)
+            const int xq = __shfl(xo, qq), cq = __shfl(col, qq);
+            f_runs[i] = (unsigned) min(xq + rr, 65535);
+            f_win[i] = (unsigned) min(max(cq - r0 - relmin + rr, 0), 65535);
+        }
+        if (lane < len) {
+            pat[kPatXoff4 + 2 * lane] = (int32_t) (f_runs[0] | (f_runs[1] << 16));
+            pat[kPatXoff4 + 2 * lane + 1] = (int32_t) (f_runs[2] | (f_runs[3] << 16));
+            pat[kPatWin4 + 2 * lane] = (int32_t) (f_win[0] | (f_win[1] << 16));
+            pat[kPatWin4 + 2 * lane + 1] = (int32_t) (f_win[2] | (f_win[3] << 16));
+        }
     }
     if (lane == 0) {
         pat[0] = len;

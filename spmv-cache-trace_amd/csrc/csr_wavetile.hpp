@@ -264,6 +264,24 @@ __device__ __forceinline__ void tile_rows_uniform_values(
     }
 }
 
+// The window slots of a quad's four entries from the packed position table (tile_common.hpp: one 64-bit word per row position):
+// tf = tile-relative index of the quad's first entry (negative in the tile's first quad when the tile does not start on a
+// quad boundary: those entries are the previous tile's, their products are never read).
+// ... kept in LDS with the four residues of the position apart: the lanes of a quad loop read positions 4 apart (8-byte words 32
+// bytes apart would meet in the same banks eight at a time), this way consecutive words
+__device__ __forceinline__ unsigned packed_slot_index(unsigned pos) { return ((pos & 3u) << 4) | (pos >> 2); } // pos < 64
+
+__device__ __forceinline__ void packed_window_slots(unsigned (&cc)[4], const unsigned long long * tab, int tf, int len, unsigned magic, unsigned wlimit)
+{
+    const unsigned t = tf > 0 ? (unsigned) tf : 0u;
+    const unsigned r = (t * magic) >> 22;
+    unsigned long long w = tab[packed_slot_index(t - r * (unsigned) len)];
+    w <<= tf < 0 ? (unsigned) (-16 * tf) : 0u; // entry i of the quad is entry tf + i of the tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        cc[i] = min(((unsigned) (w >> (16 * i)) & 0xFFFFu) + r, wlimit);
+}
+
 // x staged through LDS (kernel variant XW > 0, tiles marked kTileMetaXWin): the tile's column
 // range [base, base + 64 * chunks) is read once with coalesced loads into the wave's window and the
 // products take x from there (ds_read_b64) instead of gathering it through the vector L1.  All
@@ -273,7 +291,7 @@ __device__ __forceinline__ void tile_products_xwin(
     double * prod, double * xw, uint32_t * tab, const uint16_t * __restrict__ jt,
     const int32_t * __restrict__ first_row, int first_row_base, const double * __restrict__ at,
     const double * __restrict__ xt, int cbase, unsigned limit, int last, int lane, int chunks, bool shifted,
-    int len, int lead)
+    int len, int lead, const int32_t * __restrict__ win4 = nullptr /* shifted tile with a pattern, len <= 64: its packed positions */)
 {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     static_assert(XW % 64 == 0 && XW <= 256, "window is staged in at most four 64-entry chunks");
@@ -284,7 +302,10 @@ __device__ __forceinline__ void tile_products_xwin(
             xs[ch] = xt[min((unsigned) (64 * ch + lane), limit)];
     v2u c[QUADS];
     v2d va[QUADS], vb[QUADS];
-    if (shifted) {
+    const bool packed = shifted && win4 != nullptr;
+    if (packed) {
+        reinterpret_cast<unsigned long long *>(tab)[packed_slot_index((unsigned) lane)] = reinterpret_cast<const unsigned long long *>(win4)[lane < len ? lane : len - 1];
+    } else if (shifted) {
         for (int i = lane; i < len; i += kWave)
             tab[i] = (uint32_t) (first_row[i] + first_row_base - cbase);
     }
@@ -311,7 +332,9 @@ __device__ __forceinline__ void tile_products_xwin(
         const int o = 256 * q + 4 * lane;
         if (o <= last) {
             unsigned cc[4];
-            if (shifted) {
+            if (packed) {
+                packed_window_slots(cc, reinterpret_cast<const unsigned long long *>(tab), o - lead, len, magic, wlimit);
+            } else if (shifted) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int ti = o + i - lead;
@@ -348,7 +371,7 @@ __device__ __forceinline__ void tile_products_xwin(
 // and one more dependent round trip).
 template <int QUADS, int XW>
 __device__ __forceinline__ void tile_products_xseg(
-    double * prod, double * xw, uint16_t * tab, const int32_t * __restrict__ pat, int r0,
+    double * prod, double * xw, unsigned long long * tab, const int32_t * __restrict__ pat, int r0,
     const double * __restrict__ at, const double * __restrict__ x,
     int limit, int last, int lane, int chunks, int len, int lead)
 {
@@ -358,7 +381,8 @@ __device__ __forceinline__ void tile_products_xseg(
     for (int ch = 0; ch < XW / 64; ++ch)
         if (ch < chunks)
             so[ch] = pat[kPatSrc + 64 * ch + lane];
-    const unsigned xo = reinterpret_cast<const uint16_t *>(pat + kPatXoff)[lane < len ? lane : len - 1]; // len <= 64
+    // four window positions per row position (tile_common.hpp): len <= 64
+    const unsigned long long xo4 = reinterpret_cast<const unsigned long long *>(pat + kPatXoff4)[lane < len ? lane : len - 1];
     v2d va[QUADS], vb[QUADS];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -375,7 +399,7 @@ __device__ __forceinline__ void tile_products_xseg(
             c = c < 0 ? 0 : (c > limit ? limit : c); // padding slots of the last chunk
             xs[ch] = x[c];
         }
-    tab[lane] = (uint16_t) xo;
+    tab[packed_slot_index((unsigned) lane)] = xo4;
 #pragma unroll
     for (int ch = 0; ch < XW / 64; ++ch)
         if (ch < chunks)
@@ -390,13 +414,7 @@ __device__ __forceinline__ void tile_products_xseg(
         const int o = 256 * q + 4 * lane;
         if (o <= last) {
             unsigned cc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ti = o + i - lead;
-                const unsigned t = ti > 0 ? (unsigned) ti : 0u;
-                const unsigned r = (t * magic) >> 22;
-                cc[i] = min((unsigned) tab[t - r * (unsigned) len] + r, wlimit);
-            }
+            packed_window_slots(cc, tab, o - lead, len, magic, wlimit);
             const double q0 = va[q].x * xw[cc[0]];
             const double q1 = va[q].y * xw[cc[1]];
             const double q2 = vb[q].x * xw[cc[2]];
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
     // row is read and written by the same lane, so the in-place case needs no ordering.
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
-    __shared__ uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
+    __shared__ __attribute__((aligned(16))) uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
 
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -758,7 +776,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
         // read back
         if (XW > 0 && C16 && (meta & kTileMetaXSeg)) {
             tile_products_xseg<QUADS, (XW > 0 ? XW : 64)>(prod, xwin,
-                                      reinterpret_cast<uint16_t *>(first_row_all[C16 ? wave : 0]),
+                                      reinterpret_cast<unsigned long long *>(first_row_all[C16 ? wave : 0]),
                                       patterns + (size_t) cbase * kPatStride, r0,
                                       a + kb, x, cols - 1, last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, maxlen > 0 ? maxlen : 1, k0 - kb);
@@ -771,7 +789,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                                       pattern ? pat + kPatRel : j + k0, pattern ? r0 : 0,
                                       a + kb, x + cb, cb, (unsigned) (cols - 1 - cb), last, lane,
                                       ((meta >> kTileMetaXChunksShift) & 3) + 1, (meta & kTileMetaShifted) != 0,
-                                      maxlen > 0 ? maxlen : 1, k0 - kb);
+                                      maxlen > 0 ? maxlen : 1, k0 - kb, pattern && maxlen <= kPatPackedMaxLen ? pat + kPatWin4 : nullptr);
         }
         else if (C16 && (meta & kTileMetaShifted)) {
             const bool pattern = (meta & kTileMetaPattern) != 0;

@@ -103,8 +103,14 @@ constexpr int kTileMetaXSeg = (int) 0x80000000u;
 // (2^20 = none worked out), [3] smallest first-row column - first row index;
 // [16..144) first-row columns - first row index; [144..176) window position of each row position
 // (16 bits each); [176..432) x index - first row index of every window slot.
-constexpr int kPatStride = 432;
-constexpr int kPatRel = 16, kPatXoff = 144, kPatSrc = 176;
+// Rows of up to 64 entries also get, per row position p, one 64-bit word of FOUR 16-bit window positions: those of the entries
+// p, p + 1, p + 2, p + 3 of the tile's row-major entry sequence relative to the row of entry p (an entry past the row's end is
+// the next row's: that position's value + the rows passed), so that a lane finds the four window slots of its quad with ONE
+// division and ONE LDS read (slot = field + the row of the quad's first entry) instead of four of each: [432..560) for the
+// window of runs, [560..688) for the contiguous window (column - smallest column of the first row).  Round 4.
+constexpr int kPatStride = 688;
+constexpr int kPatRel = 16, kPatXoff = 144, kPatSrc = 176, kPatXoff4 = 432, kPatWin4 = 560;
+constexpr int kPatPackedMaxLen = 64;
 constexpr int kMaxPatterns = 64;
 
 // Plan-time counters are kept in kCountStripes copies -- a workgroup adds to copy (its number mod kCountStripes) -- and summed on
