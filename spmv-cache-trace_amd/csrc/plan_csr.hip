@@ -387,9 +387,11 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         // (... and rows of 513 ... 2048 entries, which otherwise have a wave each -- or, beyond 512, chunks that meet in atomics --
         // are taken two to eight at a time the same way: no atomics, the same y on every run)
         const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= 2048;
-        if (!exact && tile == 512 && break_rows == 0 && !pl->block_hint && multi_start && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
+        // (under the block hint only rows that no block tile could hold: three rows of more than 170 entries exceed a tile)
+        const bool hint_allows = !pl->block_hint || (r1 > r ? maxlen > 170 : true);
+        if (!exact && tile == 512 && break_rows == 0 && hint_allows && multi_start && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
             ++o.multi_candidates;
-        if (allow_multi && !exact && tile == 512 && break_rows == 0 && !pl->block_hint && multi_start
+        if (allow_multi && !exact && tile == 512 && break_rows == 0 && hint_allows && multi_start
             && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) {
             const double plain = r1 > r ? (double) ((long long) p[r1] - kb) / tile : 0.0;
             int best = 0;

@@ -1444,6 +1444,58 @@ def test_coo_and_hybrid_column_panels(oracle):
         c2.close()
 
 
+@pytest.mark.parametrize("length", [201, 257, 361, 600, 1025, 2048])
+def test_multi_window_tiles_of_equal_rows(oracle, length):
+    """Multi-window tiles of equally long rows that are copies of each other moved along the diagonal (a wide band, a stencil with
+    long rows; 600 and 201 are divisible by 3: the plan's block hint must not keep such rows out of the multi-window tiles --
+    no block tile could hold three of them).  Against the oracle, with and without SPMV_HIP_FLAG_NO_SHIFTED_TILES (the same
+    tiles: a tile of more than 512 entries has no shifted class -- computing the columns from the first row was measured slower
+    than streaming 16-bit columns, profiles/r04_results.md), one altered row, y_out != y_in, another column array."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(length)
+    n = 3000
+    nruns = int(rng.integers(1, 7))
+    cuts = np.sort(rng.choice(np.arange(1, length), size=nruns - 1, replace=False)) if nruns > 1 else np.array([], dtype=np.int64)
+    sizes = np.diff(np.concatenate([[0], cuts, [length]]))
+    starts = np.sort(rng.choice(np.arange(0, 30000, 2100), size=nruns, replace=False))
+    offsets = np.concatenate([s0 + np.arange(k) for s0, k in zip(starts, sizes)])
+    cols = n + int(offsets.max()) + 2
+    c = (np.arange(n, dtype=np.int64)[:, None] + offsets[None, :]).astype(np.int32)
+    for damaged in (False, True):
+        cc = c.copy()
+        if damaged:  # one entry of one row moved: still ascending
+            cc[1234, length - 1] += 1
+        p = (np.arange(n + 1, dtype=np.int64) * length).astype(np.int32)
+        cf = cc.ravel()
+        v = rng.uniform(-1.0, 1.0, size=len(cf))
+        x = synth.x_vector(cols, seed=3)
+        y0 = synth.x_vector(n, seed=4)
+        want = oracle.csr_spmv(n, p, cf, v, x, y=y0, num_threads=4)
+        scale = abs_products(n, p, cf, v, x) + np.abs(y0)
+        tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, cf, v, x))
+        for flags in (0, capi.FLAG_NO_SHIFTED_TILES):
+            plan = capi.CsrPlan(n, cols, p, capi.CSR_AUTO, 0, flags | capi.FLAG_NO_VALUE_INDEX)
+            plan.compress(tc.data_ptr(), stream)
+            plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+            info = plan.info()
+            assert info["multi_window_tiles"] > 0, (length, flags, info)
+            ty = torch.from_numpy(y0.copy()).to(dev)
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+            tout = torch.full((n,), np.nan, dtype=torch.float64, device=dev)
+            plan.spmv_out(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), tout.data_ptr(), stream)
+            tc2 = tc.clone()
+            tz = torch.from_numpy(y0.copy()).to(dev)
+            plan.spmv(tp.data_ptr(), tc2.data_ptr(), tv.data_ptr(), tx.data_ptr(), tz.data_ptr(), stream)
+            torch.cuda.synchronize()
+            what = "%d per row%s, flags %x" % (length, ", one row altered" if damaged else "", flags)
+            assert_close(ty.cpu().numpy(), want, scale, what=what, nterms=length)
+            assert_close(tout.cpu().numpy(), oracle.csr_spmv(n, p, cf, v, x, y=want, num_threads=4), 2 * scale, what=what + ", y_out", nterms=2 * length)
+            assert_close(tz.cpu().numpy(), want, scale, what=what + ", other column array", nterms=length)
+            plan.close()
+
+
 @pytest.mark.parametrize("case", ["uniform361", "mixed", "random_columns", "few_values", "very_long"])
 def test_multi_window_tiles(oracle, case):
     """Rows of 161 ... 512 entries are taken up to 8 at a time by one wave that walks them in windows of 512 entries, the row
