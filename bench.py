@@ -135,6 +135,8 @@ def parse_args():
                     help="process-group backend; gloo is for rehearsing N > 1 on a box with one GPU")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: every rank uses device 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
+    ap.add_argument("--reject-scheme", default=None, choices=["peer-fused", "peer-push"],
+                    help="rehearsal: treat this gather scheme as if its gathered y had failed the check against RCCL's")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the all-gather even with one rank (rehearsal)")
     return ap.parse_args()
@@ -744,6 +746,32 @@ def main():
             t = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return t.item() / n
+        # Before anything is timed, every scheme without a collective must deliver what the RCCL all-gather delivers: one multiply
+        # from y = 0 with each, the gathered vector's sum and absolute sum compared on every rank (the row sums are the same kernel's:
+        # equal bits).  A scheme that does not (peer stores that a platform maps but does not carry) is closed -- collectively, every
+        # rank takes the same branch -- and the run goes on without it.  `--reject-scheme NAME` rehearses that branch.
+        def signature(o):
+            o.zero()
+            o.multiply_local()
+            if o.collective:
+                o.gather()
+            o.finish()
+            yf = o.y_full
+            return torch.stack([yf.sum(), yf.abs().sum()])
+        rejected = {}
+        if len(ops) > 1:
+            ref_sig = signature(ops["rccl"])
+            for name in [n for n in ops if n != "rccl"]:
+                sig = signature(ops[name])
+                bad = bool(((sig - ref_sig).abs() > 1e-9 * ref_sig.abs().clamp_min(1e-300)).any()) or name == args.reject_scheme
+                flag = torch.tensor([1.0 if bad else 0.0], dtype=torch.float64, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0:
+                    ops.pop(name).close()
+                    rejected[name] = "closed before timing: its gathered y differed from the RCCL scheme's after one multiply" + (
+                        " (forced by --reject-scheme)" if name == args.reject_scheme else "")
+            for o in ops.values():
+                o.zero()
         schemes = {}
         ncal = max(5, min(20, args.warmup))
         for name, o in ops.items():
@@ -751,7 +779,10 @@ def main():
             schemes[name] = {"t_total_us": round(timed_steps(o, ncal) * 1e6, 2), "calibration_steps": ncal}
             if not o.collective:
                 schemes[name]["multiply_forwards_row_sums"] = bool(o.fused)
-        chosen = args.gather if args.gather in ops else min(schemes, key=lambda k: schemes[k]["t_total_us"])
+        for name, why in rejected.items():
+            schemes[name] = {"rejected": why}
+        timed = {k: v for k, v in schemes.items() if "t_total_us" in v}
+        chosen = args.gather if args.gather in ops else min(timed, key=lambda k: timed[k]["t_total_us"])
         if args.gather != "auto" and args.gather not in ops:
             chosen = "rccl"
         op = ops[chosen]
@@ -946,6 +977,8 @@ def main():
         t_local = events_us(ops["rccl"].multiply_local)
         ops["rccl"].finish()
         for name in schemes:
+            if "rejected" in schemes[name]:
+                continue
             schemes[name]["t_local_us"] = t_local
         schemes["rccl"]["t_gather_us"] = round(gather_us, 2)
         if "peer-push" in ops:
