@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the x-window paths (csr_wavetile_kernel's XW variant: window of runs and contiguous window, the window living in the
-end of the wave's product slice) and of the opt-in row-group kernel: stencil-like matrices with EVERY row length 2 ... 128, random
+end of the wave's product slice) and of the opt-in row-group kernel: stencil-like matrices with EVERY row length 2 ... 176, random
 first-row patterns in 1 ... 9 runs or one band, a random number of short rows in front (so that tiles start at every offset
 within a 16-byte quad) and behind, many seeds; default plan, SPMV_HIP_FLAG_ROW_GROUPS, SPMV_HIP_FLAG_NO_X_WINDOW and
 SPMV_HIP_FLAG_EXACT_ORDER (bit-exact) against the oracle (src/matrix/csr-matrix-spmv.cpp:21-33 restated in oracle/).
@@ -54,7 +54,7 @@ def main():
     checked = windows = groups = 0
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
-        length = int(rng.integers(2, 129))
+        length = int(rng.integers(2, 177))
         if rng.random() < 0.5:
             offsets = np.arange(length) - int(rng.integers(0, length + 1))  # one band
         else:
