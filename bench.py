@@ -270,6 +270,17 @@ def format_bytes(fmt, rows, cols, nnz, stored=None, coo_entries=0):
     return 12 * stored + 16 * coo_entries + 16 * rows + 8 * cols  # hybrid: ELL part + COO remainder
 
 
+def cpu_model():
+    """The host CPU's model name (core count and CPU model go into the result)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
     """The reference's OpenMP kernel (or the C oracle) on the host cores, bounded sample.  Also the
     parity gate: one CPU multiply from y = 0 is compared with the GPU's (y_gpu), whole vector,
@@ -354,7 +365,9 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
             "sample": "full workload (%s), %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
                       % (fmt, len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
             "gbs": round(A["bytes"] / med / 1e9, 2),
-            "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3)}, parity
+            "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3),
+            "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}}, parity
 
 
 def reference_protocol(args, fmt, runs, flush=False):
