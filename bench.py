@@ -53,20 +53,63 @@ XGMI_LINK_GBS = 64.0       # per direction and link, 7 links per GPU: the conser
 XGMI_LINK_GBS_QUOTED = 153.0  # the per-link figure usually quoted for MI355X; the truth for one direction lies in between
 
 
-def strong_scaling_model(rows, t1_us):
+def strong_scaling_model(rows, t1_us, measured_gbs=None):
     """What the replicated-y design can reach on one node: every GPU multiplies rows / G and must RECEIVE
     the other G - 1 segments, each over its own xGMI link (direct all-to-all: segment bytes / link rate, whatever G is), fully
     overlapped with the multiply at best: step = max(t1 / G, 8 rows / G / rate).  Rates per link and direction: 64 GB/s (what
     MI300X-class links deliver), 76.8 (half of the 153.6 GB/s bidirectional figure quoted for MI355X)."""
     out = {"formula": "step_us(G) = max(t1_us / G, 8 * rows / G / link_rate); speedup = t1_us / step_us", "t1_us": round(t1_us, 1), "rows": int(rows)}
-    for rate in (64.0, 76.8):
+    rates = [("link_64.0_GBs", 64.0), ("link_76.8_GBs", 76.8)]
+    if measured_gbs:
+        rates.append(("link_measured_%.1f_GBs" % measured_gbs, float(measured_gbs)))
+    for key, rate in rates:
         row = {}
         for G in (2, 4, 8):
             gather = 8.0 * rows / G / (rate * 1e9) * 1e6
             step = max(t1_us / G, gather)
             row["G%d" % G] = {"local_us": round(t1_us / G, 1), "gather_us": round(gather, 1), "speedup": round(t1_us / step, 2)}
-        out["link_%.1f_GBs" % rate] = row
+        out[key] = row
+    # 4 x at G = 8 needs step <= t1 / 4, i.e. the segment (8 rows / 8 bytes) received within t1 / 4 over ONE link
+    out["link_GBs_needed_for_4x_at_G8"] = round(8.0 * rows / 8 / (t1_us / 4 * 1e-6) / 1e9, 1)
+    out["needs"] = ("speedup >= 4 at G = 8 needs >= %.0f GB/s per link and direction, transfer fully hidden behind the multiply"
+                    % out["link_GBs_needed_for_4x_at_G8"])
     return out
+
+
+def link_probe(torch, dist, capi, o, rank, world, reps=5):
+    """What the links between the ranks' devices deliver for THIS path's traffic: every rank stores its y segment (the doubles
+    the gather moves) into its slot of one peer's vector at a time -- rank r -> (r + k) mod G for k = 1 .. G-1, all ranks at
+    once, so every link carries one sender per direction: the pattern of tools/probes/xgmi_bw.hip -- and then into all peers
+    at once (the fused store's pattern).  Timed with HIP events on the launch stream; a few ms in total.  The stores rewrite
+    the values the slots already hold (the segment was delivered by the last multiply), so nothing changes.
+    Returns (this rank's {peer: GB/s}, GB/s leaving this rank with all peers at once) or None."""
+    v = o.vectors
+    n = int(o.end - o.begin)
+    stream = torch.cuda.current_stream().cuda_stream
+    src = v.addr + 8 * rank * o.chunk
+
+    def timed(peers):
+        dsts = [v.peer_addr[h] + 8 * rank * o.chunk for h in peers]
+        if n > 0:
+            capi.peer_push(src, dsts, n, stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            if n > 0:
+                capi.peer_push(src, dsts, n, stream)
+        b.record()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = a.elapsed_time(b)
+        return round(8.0 * n * len(dsts) * reps / (ms * 1e-3) / 1e9, 2) if (n > 0 and ms > 0) else None
+    per_peer = {}
+    for k in range(1, world):
+        h = (rank + k) % world
+        per_peer[h] = timed([h])
+    together = timed(sorted(v.peer_addr)) if world > 1 else None
+    return per_peer, together
 CLI = os.path.join(ROOT, "spmv-cache-trace_amd", "spmv-cache-trace-hip")
 
 
@@ -183,6 +226,39 @@ def load_csr(args, rank, world):
         begin, end = partition.row_range(rows, rank, world)
         keep = hostapi.load_csr_rows(spec, begin, end)
         return rows, keep.cols, None, keep.row_ptr, keep.column_index, keep.value, begin, end, None, keep
+    elif world > 1 and spec.startswith("synthetic:") and args.partition == "nnz":
+        # equal stored entries per rank WITHOUT any rank holding the whole matrix: every rank generates its static chunk, the
+        # ranks exchange their entry counts, each finds the cut rows that fall into its chunk (partition.nnz_balanced_ranges'
+        # rule: first row whose row_ptr >= g * nnz / G), and then generates the rows it really owns
+        import torch.distributed as dist
+        probe = hostapi.load_csr_rows(spec, 0, 0)
+        rows = probe.rows_total
+        probe.close()
+        b0, e0 = partition.row_range(rows, rank, world)
+        part = hostapi.load_csr_rows(spec, b0, e0)
+        lp = np.asarray(part.row_ptr, dtype=np.int64)
+        counts = [None] * world
+        dist.all_gather_object(counts, int(lp[-1]))
+        offset, total = sum(counts[:rank]), sum(counts)
+        cuts = {}
+        for g in range(1, world):
+            t = g * total // world
+            if offset < t <= offset + counts[rank]:
+                cuts[g] = b0 + int(np.searchsorted(lp, t - offset, side="left"))
+            elif t <= 0 and rank == 0:
+                cuts[g] = 0
+        part.close()
+        every = [None] * world
+        dist.all_gather_object(every, cuts)
+        bounds = [0] * (world + 1)
+        bounds[world] = rows
+        for g in range(1, world):
+            bounds[g] = min(c[g] for c in every if g in c)
+        bounds = [int(v) for v in np.maximum.accumulate(np.minimum(bounds, rows))]
+        ranges = [(bounds[g], bounds[g + 1]) for g in range(world)]
+        begin, end = ranges[rank]
+        keep = hostapi.load_csr_rows(spec, begin, end)
+        return rows, keep.cols, total, keep.row_ptr, keep.column_index, keep.value, begin, end, ranges, keep
     else:
         keep = hostapi.load(spec, "csr", expand_symmetric=args.expand_symmetric)
         rows, cols, p, c, v = keep.rows, keep.cols, keep.row_ptr, keep.column_index, keep.value
@@ -610,8 +686,28 @@ def companion(torch, capi, hostapi, synth, args, device, stream, spec, fmt, name
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed plainly (no launcher): start the N ranks as FRESH child processes -- one
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` with this command line -- before this process has imported
+    torch or made any HIP call, let them write to this process's stdout / stderr (rank 0 prints the one JSON line), and leave
+    with their exit code.  Nothing is exec'ed and no process that has initialised the GPU starts another."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torch.distributed.run would set (and warn about) per rank anyway
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     from spmv_amd import capi, hostapi, partition, synth
@@ -641,6 +737,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        pg_world = dist.get_world_size()
+        if pg_world != world:
+            sys.exit("bench.py: the process group has %d ranks, WORLD_SIZE says %d" % (pg_world, world))
 
     def finish(code=0, message=None):
         """Every rank leaves together: the verdict travels before the last barrier."""
@@ -953,8 +1052,8 @@ def main():
     gather_check = None
     if use_dist:
         op.finish()  # every rank (the peer schemes meet at a barrier here); below, rank 0 reads its vector without one
-    if use_dist and world > 1 and rank == 0 and spec is not None and spec.startswith("synthetic:") and ranges is None:
-        ob, oe = partition.row_range(rows, world - 1, world)
+    if use_dist and world > 1 and rank == 0 and spec is not None and spec.startswith("synthetic:"):
+        ob, oe = ranges[world - 1] if ranges is not None else partition.row_range(rows, world - 1, world)
         strip = min(4096, oe - ob)
         S = hostapi.load_csr_rows(spec, ob, ob + strip)
         tps, tcs, tvs = (torch.from_numpy(np.array(t)).to(device) for t in (S.row_ptr, S.column_index, S.value))
@@ -963,7 +1062,7 @@ def main():
         plan_s.spmv(tps.data_ptr(), tcs.data_ptr(), tvs.data_ptr(), op._keep[3].data_ptr(), ys.data_ptr(), stream)
         torch.cuda.synchronize()
         want = ys * float(args.steps + args.warmup)
-        got = op.y_full[ob:ob + strip]  # static row chunks: the gathered vector is y itself
+        got = op.y_full[(world - 1) * op.chunk:(world - 1) * op.chunk + strip]  # the last rank's slot (static row chunks: = y[ob:])
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-300))
         gather_check = {"rows_checked": strip, "of_rank": world - 1, "max_rel_err": err, "pass": bool(err <= 1e-10)}
         plan_s.close()
@@ -1020,6 +1119,33 @@ def main():
         deferred = {"steps": args.steps, "all_gathers": 1, "ms_total": round(dt.item() * 1e3, 4),
                     "gflops": round(2.0 * nnz * args.steps / dt.item() / 1e9, 2)}
 
+    # ---- N > 1: what do the links deliver?  (after the timed region; a few ms; never part of `value`) -----------------------
+    # The y segments travel as stores into the other ranks' vectors (or as RCCL's transfers over the same links): the rate of
+    # exactly those stores, per peer and with all peers at once, so that the line explains its own step time.
+    probe = None
+    if use_dist and fmt == "csr":
+        po = ops.get("peer-push") or ops.get("peer-fused")
+        if po is None or world < 2:
+            probe = {"link_probe_gbs": None, "why": peer_note or ("one rank" if world < 2 else "no peer-store operator was set up (--gather rccl)")}
+        else:
+            po.finish()
+            tpr = time.perf_counter()
+            mine = link_probe(torch, dist, capi, po, rank, world)
+            took_ms = (time.perf_counter() - tpr) * 1e3
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            po.finish()
+            rates = [r for per, _ in everyone for r in per.values() if r]
+            tog = [t for _, t in everyone if t]
+            probe = {"link_probe_gbs": {"rank%d" % r: {"to_rank%d" % h: g for h, g in sorted(per.items())} for r, (per, _) in enumerate(everyone)},
+                     "all_peers_at_once_gbs_per_rank": [t for _, t in everyone],
+                     "min_link_gbs": min(rates) if rates else None, "median_link_gbs": float(np.median(rates)) if rates else None,
+                     "per_link_gbs_with_all_peers_at_once": round(min(tog) / (world - 1), 2) if tog else None,
+                     "bytes_per_store_pass": int(8 * (end - begin)), "took_ms": round(took_ms, 1),
+                     "pattern": "rank r stores its y segment into rank (r + k) mod G's vector, k = 1 .. G-1, every rank at once (one sender "
+                                "per link and direction), 5 passes per peer after one untimed pass; then into all peers at once",
+                     "same_device": bool(args.share_gpu)}
+
     # ---- companion: BASELINE configs[3] on the same ranks ----------------------------------------------------------------
     # The headline workload (configs[1], Poisson: 5 entries per row) cannot scale strongly with a replicated y; the
     # configuration BASELINE.json partitions over 8 GPUs is nlpkkt200 (27 entries per row).  So that a run at N = 1, 2, 4, 8
@@ -1028,9 +1154,9 @@ def main():
     def partitioned_companion(spec3, label3, note3):
         import argparse as _ap
         a3 = _ap.Namespace(**vars(args))
-        a3.matrix, a3.expand_symmetric, a3.partition = spec3, False, "rows"
+        a3.matrix, a3.expand_symmetric = spec3, False  # the partition is the headline's (--partition rows | nnz)
         t3 = time.perf_counter()
-        rows3, cols3, nnz3, p3, c3, v3, b3, e3, _, keep3 = load_csr(a3, rank, world)
+        rows3, cols3, nnz3, p3, c3, v3, b3, e3, ranges3, keep3 = load_csr(a3, rank, world)
         if nnz3 is None:
             tt = torch.tensor([float(p3[-1])], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt)
@@ -1039,10 +1165,11 @@ def main():
         scheme3 = chosen if (use_dist and schemes is not None) else None
         if scheme3 in ("peer-fused", "peer-push"):
             from spmv_amd.peer import PeerCsrSpmv
-            op3 = PeerCsrSpmv.on_gpu(rows3, cols3, rank, world, device, p3, c3, v3, x3, algo, args.lanes, flags, fused=(scheme3 == "peer-fused"))
+            op3 = PeerCsrSpmv.on_gpu(rows3, cols3, rank, world, device, p3, c3, v3, x3, algo, args.lanes, flags, fused=(scheme3 == "peer-fused"),
+                                     ranges=ranges3)
         else:
             op3 = DistributedCsrSpmv.on_gpu(rows3, cols3, rank, world, device, p3, c3, v3, x3, algo, args.lanes, flags,
-                                            overlap=use_dist and not args.no_overlap)
+                                            overlap=use_dist and not args.no_overlap, ranges=ranges3)
 
         def steps3(n):
             for _ in range(n):
@@ -1063,17 +1190,44 @@ def main():
         el3 = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
         if use_dist:
             dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+        # the local multiply alone (no delivery of any kind): one event pair around K3 launches into a scratch vector
+        tloc3 = None
+        if use_dist:
+            op3.finish()
+            tp3, tc3, tv3, tx3 = op3._keep
+            ys3 = torch.zeros(max(1, e3 - b3), dtype=torch.float64, device=device)
+            ptr3 = (tp3.data_ptr(), tc3.data_ptr(), tv3.data_ptr(), tx3.data_ptr(), ys3.data_ptr())
+            for _ in range(3):
+                op3.plan.spmv(*ptr3, stream)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ea.record()
+            for _ in range(K3):
+                op3.plan.spmv(*ptr3, stream)
+            eb.record()
+            torch.cuda.synchronize()
+            tl = torch.tensor([ea.elapsed_time(eb) * 1e3 / K3], dtype=torch.float64, device=device)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            tloc3 = tl.item()
+            del ys3
+        t1_est = tloc3 * world if tloc3 else el3.item() / K3 * 1e6
         i3 = op3.plan.info()
-        out3 = {"workload": "%s, csr, %s" % (label3, "rows/%d static chunks" % world if use_dist else "single GPU"),
+        out3 = {"workload": "%s, csr, %s" % (label3, (("rows/%d static chunks" % world) if ranges3 is None else
+                                                       ("%d row ranges of equal stored entries" % world)) if use_dist else "single GPU"),
+                "local_rows_min_max": [int(min(e - b for b, e in ranges3)), int(max(e - b for b, e in ranges3))] if ranges3 else None,
                 "rows": rows3, "nnz": nnz3, "steps": K3, "warmup": W3, "gather": scheme3 or ("rccl" if use_dist else None),
                 "ms_per_step": round(el3.item() / K3 * 1e3, 5), "gflops": round(2.0 * nnz3 * K3 / el3.item() / 1e9, 2),
                 "frac_algorithmic_whole_step": round(synth.csr_bytes(rows3, cols3, nnz3) / (el3.item() / K3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                 "local_tiles": i3["row_blocks"], "local_shifted_tiles": i3["shifted_tiles"], "local_x_window_tiles": i3["xwin_tiles"],
                 "local_column_panel_tiles": i3["panel_tiles"],
                 "setup_s": round(time.perf_counter() - t3 - el3.item(), 1),
-                "strong_scaling_model": strong_scaling_model(rows3, el3.item() / K3 * 1e6 * (world if use_dist else 1)),
-                "note": note3 + "; strong_scaling_model: t1 = this run's step time"
-                        + (" x ranks (an estimate of the single-GPU time)" if use_dist else "")}
+                "local_multiply_us": round(tloc3, 2) if tloc3 else None,
+                "strong_scaling_model": strong_scaling_model(rows3, t1_est, (probe or {}).get("per_link_gbs_with_all_peers_at_once")),
+                "note": note3 + "; strong_scaling_model: t1 = "
+                        + ("the slowest rank's local multiply alone (HIP events, no delivery) x ranks: an estimate of the single-GPU time"
+                           + ("; NOT meaningful in this rehearsal, where the ranks share one device and its memory" if args.share_gpu else "")
+                           if use_dist else "this run's step time")}
         if not op3.collective:
             op3.close()
         del op3, keep3, p3, c3, v3
@@ -1201,7 +1355,11 @@ def main():
                                 "schemes": schemes, "peer_note": peer_note if fmt == "csr" else None,
                                 "note": "all_gather_us: blocking collective alone, median of 5 after the timed region; schemes: t_total = a "
                                         "whole step (max over ranks) timed before the warm-up, `gather` = the one the timed region ran",
-                                "one_all_gather_after_the_k_multiplies": deferred}
+                                "one_all_gather_after_the_k_multiplies": deferred,
+                                "ranks": {"world_size": world, "process_group_world_size": int(pg_world), "backend": args.backend,
+                                          "devices": "every rank on device 0 (rehearsal)" if args.share_gpu else "one device per rank (LOCAL_RANK)"}}
+            if probe is not None:
+                out["multi_gpu"].update(probe)
         for k in sorted(companions):
             out[k] = companions[k]
         if config3 is not None:

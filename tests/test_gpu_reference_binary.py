@@ -1,0 +1,86 @@
+"""The reference's OWN program text driving the MI355X kernels: oracle/_ref/check-adapter and
+oracle/_ref/spmv-cache-trace-patched are the reference's loader, converters, trace-config reader, timed loop
+(src/profile-kernel.cpp:137-179, 197-313) and JSON writer, compiled in the build container from a temporary copy of the
+reference tree with integration/reference.patch applied (oracle/Makefile), linked against libspmv_hip.so.  check-adapter
+compares the y the adapter leaves on the device with the same multiplies by the reference's CPU kernels
+(csr_matrix::spmv src/matrix/csr-matrix-spmv.cpp:148-167, coo_matrix::spmv src/matrix/coo-matrix.cpp:313-335,
+ell_matrix::spmv src/matrix/ell-matrix.cpp:311-335) under SURVEY 8(d)'s per-row tolerance."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "oracle", "_ref", "check-adapter")
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "spmv-cache-trace-patched")
+CLI = os.path.join(ROOT, "spmv-cache-trace_amd", "spmv-cache-trace-hip")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _config(path, threads):
+    doc = {"caches": {"L1": {"size": 32768, "line_size": 64, "bandwidth": None, "bandwidth_per_numa_domain": None,
+                             "cache_miss_event": None, "parent": None}},
+           "num_numa_domains": 1,
+           "thread_affinities": [{"cpu": t, "cache": "L1", "numa_domain": 0, "event_groups": []} for t in range(threads)]}
+    path.write_text(json.dumps(doc))
+    return str(path)
+
+
+@pytest.fixture(scope="module")
+def matrices(tmp_path_factory):
+    if not (os.path.exists(CHECK) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/check-adapter not built (needs /root/reference at build time)")
+    d = tmp_path_factory.mktemp("mtx")
+    out = {"poisson2D": os.path.join(GOLDEN, "poisson2D.mtx"), "bus1138_like": os.path.join(GOLDEN, "bus1138_like.mtx")}
+    for name, spec in (("poisson512", "poisson2d:512"), ("band", "banded:60000,20"), ("fem", "queen:10,9,8")):
+        p = str(d / (name + ".mtx"))
+        r = subprocess.run([CLI, "--synthetic", spec, "--write-mtx", p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        out[name] = p
+    return d, out
+
+
+@pytest.mark.parametrize("name", ["poisson2D", "bus1138_like", "poisson512", "band", "fem"])
+@pytest.mark.parametrize("fmt", ["csr", "coo", "ell"])
+def test_reference_program_with_the_adapter_matches_its_cpu_kernel(matrices, fmt, name):
+    d, files = matrices
+    cfg = _config(d / "cfg_1.json", 1)
+    r = subprocess.run([CHECK, fmt, files[name], cfg, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    doc = json.loads(r.stdout)
+    assert doc["kernel"]["name"] == "hip-%s-spmv" % fmt and doc["kernel"]["matrix_format"] == fmt
+    assert doc["execution_time"]["samples"] == 4 and doc["execution_time"]["min"] > 0
+    check = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"check"')][-1])["check"]
+    assert check["pass"] is True and check["rows_outside_8d_bound"] == 0 and check["rows"] == doc["kernel"]["rows"]
+    assert check["max_rel_err"] <= 1e-10
+    if name == "poisson2D":  # rows of <= 5 entries are summed by one lane in the reference's order
+        assert check["bitexact"] is True
+
+
+def test_reference_program_with_a_team_of_threads(matrices):
+    """run() is called by every thread of the OpenMP team (profile-kernel.cpp:160); the master talks to the device."""
+    d, files = matrices
+    cfg = _config(d / "cfg_4.json", 4)
+    r = subprocess.run([CHECK, "csr", files["poisson512"], cfg, "6"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(json.loads(r.stdout)["trace_config"]["thread_affinities"]) == 4
+    assert json.loads([l for l in r.stderr.splitlines() if l.startswith('{"check"')][-1])["check"]["pass"] is True
+
+
+def test_patched_reference_cli_runs_the_gpu_kernel(matrices):
+    """What a user of the reference types after the patch: --spmv-format hip-csr --profile=N."""
+    d, files = matrices
+    cfg = _config(d / "cfg_cli.json", 1)
+    docs = {}
+    for fmt in ("hip-csr", "csr"):
+        r = subprocess.run([PATCHED, "-c", cfg, "-m", files["poisson512"], "--spmv-format", fmt, "--profile=10"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        docs[fmt] = json.loads(r.stdout)
+    a, b = docs["hip-csr"], docs["csr"]
+    assert a["kernel"]["name"] == "hip-csr-spmv" and b["kernel"]["name"] == "csr-spmv"
+    assert {k: v for k, v in a["kernel"].items() if k != "name"} == {k: v for k, v in b["kernel"].items() if k != "name"}
+    assert list(a["execution_time"]) == list(b["execution_time"]) and a["execution_time"]["samples"] == 10

@@ -717,6 +717,14 @@ Kernel * make_it() { return new hip_csr_spmv_kernel("A.mtx"); }
            "-I", os.path.join(ROOT, "include"), str(src)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
+    # ... and, where the reference tree is present (the build container), against the REFERENCE's own headers and language
+    # level (Makefile:3 -std=c++14; -include cstdint as SURVEY 8(c) notes for g++ 11): the class as a maintainer would compile it
+    ref = "/root/reference/src"
+    if os.path.isdir(ref):
+        cmd = ["g++", "-std=c++14", "-fopenmp", "-DUSE_OPENMP", "-DUSE_POSIX_MEMALIGN", "-include", "cstdint", "-fsyntax-only", "-Wall",
+               "-I", os.path.join(ref, "kernels"), "-I", ref, "-I", os.path.join(ROOT, "include"), str(src)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
 
 
 def test_cli_check_gate_fails_on_non_finite_values(tmp_path):
