@@ -132,33 +132,17 @@ extern "C" {
                                              BLOCK instead of a column index per entry and no row_ptr (8.2 instead of 10 bytes per
                                              entry).  Only rows of more than 16 entries (1e-10 class either way); never under
                                              SPMV_HIP_FLAG_EXACT_ORDER */
-#define SPMV_HIP_FLAG_HUB_COLUMNS 0x4000000u /* plan_csr_compress, OPT-IN: hub columns.  A plan with balanced tiles (a graph matrix)
-                                             whose x is larger than an XCD's L2 counts the references to every column; the columns
-                                             with >= 8 of them (at most 2^18, carrying >= 10 % of the entries) become hubs: the plan
-                                             keeps its own column stream, every multiply first copies the hubs' x entries into a
-                                             dense plan-owned array (a second, small launch) and the tiles read them from there --
-                                             one line of x per sixteen hubs in every L2 instead of one per hub.  Same bits.  Off by
-                                             default because it was measured SLOWER on the webbase-like matrix (26.6 vs 23.9 us:
-                                             the traffic above the algorithmic bytes there is the long TAIL of rarely referenced
-                                             columns -- nearly every line of x ends up in every XCD's L2 -- not the head; DESIGN.md
-                                             section 3.3).  The dense array is scratch: multiplies through ONE plan must then be
-                                             ordered (same stream), like the runs of a context.  plan_info[27], [28] */
+/* 0x4000000u and 0x10000000u are not flags of this library: two kernel families that were measured SLOWER than the paths they
+ * were meant to replace (hub columns for web graphs, 26.6 vs 23.9 us; a lane group per row for stencil rows of 17 ... 64
+ * entries, 797 vs 740 us: DESIGN.md sections 3.3, 3.1b) were retired from the product library in round 5 and are
+ * refused like any unknown bit.  They live on in libspmv_hip_experiments.so (csrc/internal.hpp) for tools/ and
+ * tests/experiments/. */
 #define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 161 ... 2048 entries, which fill a
                                              512-entry tile badly (one row of 361: 70 %) or do not fit one at all (a wave per row, or
                                              chunks that meet in atomics), are taken two to eight at a time by one wave that walks
                                              them in windows of 512 entries and carries the row sums in registers (7 rows of 361 =
                                              4.94 windows): no atomics, the same y on every run.  1e-10 class like every row of more than 16 entries;
                                              never under SPMV_HIP_FLAG_EXACT_ORDER */
-#define SPMV_HIP_FLAG_ROW_GROUPS 0x10000000u /* plan_csr_compress, OPT-IN: row-group tiles.  A plan in which most tiles are the interior
-                                             of a stencil or band with rows of 17 ... 64 entries (uniform, shifted, with an x window)
-                                             multiplies those with 2 ... 8 lanes per row, each adding up to twelve consecutive entries
-                                             in registers -- no products parked in LDS (csr_rowgroup.hpp) -- and the other tiles with a
-                                             second launch.  Same 1e-10 class.  Off by
-                                             default because it was measured SLOWER (KKT-like matrix 797 vs 740 us, 27 diagonals 181 vs
-                                             176 us: a lane that owns 72 consecutive bytes makes every load instruction of the wave
-                                             touch all 36 cache lines of the tile, five times over).  Never
-                                             under SPMV_HIP_FLAG_EXACT_ORDER, with a value dictionary or with block / segment
-                                             windows.  plan_info[30] */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -375,10 +359,9 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             they read no index stream at all, only the first row's bytes
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
  *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries
- *        [27] hub columns (see SPMV_HIP_FLAG_HUB_COLUMNS)  [28] the entries that refer to them
+ *        [27], [28] 0 in this library (hub columns and their entries in libspmv_hip_experiments.so)
  *        [29] multi-window tiles (several rows of 161 ... 512 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW),
- *        [30] row-group tiles (rows of 17 ... 64 entries, 2 ... 8 lanes per row: SPMV_HIP_FLAG_ROW_GROUPS, opt-in; 0 unless
- *        they are the majority of the plan's tiles) */
+ *        [30] 0 in this library (row-group tiles in libspmv_hip_experiments.so) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

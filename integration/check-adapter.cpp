@@ -34,12 +34,29 @@ namespace
 struct Outcome
 {
     double worst_rel = 0.0, worst_over_bound = 0.0, norm = 0.0;
-    long rows = 0, outside = 0;
+    long rows = 0, outside = 0, by_summation_bound = 0;
     bool bitexact = true;
 };
 
-/* |y_gpu - y_cpu| <= 1e-10 * max(|y_cpu_i|, 1e-6 * ||y_cpu||_inf) per row */
-Outcome compare(std::vector<double> const & got, double const * want, long n)
+/* What two summation orders of one row may differ by, a priori, after `multiplies` accumulating multiplies:
+ * 2 k (n_i + 1) 2^-53 (|A||x|)_i  (tests/helpers.py::assert_close's second clause). */
+std::vector<double> summation_slack(matrix_market::Matrix const & mm, int multiplies)
+{
+    csr_matrix::Matrix A = csr_matrix::from_matrix_market(mm);
+    for (auto & v : A.value)
+        v = std::fabs(v);
+    csr_matrix::value_array_type x(A.columns, 1.0), a(A.rows, 0.0);
+    csr_matrix::spmv(A, x, a);
+    std::vector<double> slack(A.rows);
+    for (csr_matrix::index_type i = 0; i < A.rows; i++)
+        slack[i] = 2.0 * multiplies * (A.row_ptr[i + 1] - A.row_ptr[i] + 1) * std::ldexp(1.0, -53) * a[i];
+    return slack;
+}
+
+/* |y_gpu - y_cpu| <= 1e-10 * max(|y_cpu_i|, 1e-6 * ||y_cpu||_inf) per row.  That floor is one unit in the
+ * last place of the largest element, so a row whose products cancel can miss it by rounding alone when its sum is formed
+ * in another order: such a row must then be within the a-priori summation bound, and is counted. */
+Outcome compare(std::vector<double> const & got, double const * want, long n, std::vector<double> const & slack)
 {
     Outcome o;
     o.rows = n;
@@ -47,15 +64,19 @@ Outcome compare(std::vector<double> const & got, double const * want, long n)
         o.norm = std::max(o.norm, std::fabs(want[i]));
     for (long i = 0; i < n; i++) {
         double d = std::fabs(got[i] - want[i]);
-        if (d != 0.0 || std::signbit(got[i]) != std::signbit(want[i]))
-            o.bitexact = o.bitexact && d == 0.0;
+        if (!(d == 0.0))
+            o.bitexact = false;
         double bound = 1e-10 * std::max(std::fabs(want[i]), 1e-6 * o.norm);
         if (bound > 0.0)
             o.worst_over_bound = std::max(o.worst_over_bound, d / bound);
         else if (d > 0.0)
             o.worst_over_bound = INFINITY;
-        if (d > bound)
-            o.outside++;
+        if (!(d <= bound)) {
+            if (d <= slack[i])
+                o.by_summation_bound++;
+            else
+                o.outside++;
+        }
         if (o.norm > 0.0)
             o.worst_rel = std::max(o.worst_rel, d / o.norm);
     }
@@ -79,31 +100,32 @@ int drive(std::string const & format, std::string const & path, TraceConfig cons
     matrix_market::Matrix mm = matrix_market::load_matrix(path, std::cerr, false);
     Outcome out;
     int const multiplies = runs + 1;
+    std::vector<double> slack = summation_slack(mm, multiplies);
     if (format == "csr") {
         csr_matrix::Matrix A = csr_matrix::from_matrix_market(mm);
         csr_matrix::value_array_type x(A.columns, 1.0), y(A.rows, 0.0);
         for (int k = 0; k < multiplies; k++)
             csr_matrix::spmv(A, x, y);
-        out = compare(got, y.data(), A.rows);
+        out = compare(got, y.data(), A.rows, slack);
     } else if (format == "coo") {
         coo_matrix::Matrix A = coo_matrix::from_matrix_market(mm);
         coo_matrix::value_array_type x(A.columns, 1.0), y(A.rows, 0.0), workspace;
         for (int k = 0; k < multiplies; k++)
             coo_matrix::spmv(1, A, x, y, workspace);
-        out = compare(got, y.data(), A.rows);
+        out = compare(got, y.data(), A.rows, slack);
     } else {
         ell_matrix::Matrix A = ell_matrix::from_matrix_market(mm);
         ell_matrix::value_array_type x(A.columns, 1.0), y(A.rows, 0.0);
         for (int k = 0; k < multiplies; k++)
             ell_matrix::spmv(A, x, y);
-        out = compare(got, y.data(), A.rows);
+        out = compare(got, y.data(), A.rows, slack);
     }
     std::fprintf(stderr,
                  "{\"check\": {\"kernel\": \"%s\", \"against\": \"%s_matrix::spmv of the reference, %d multiplies from y = 0\", "
-                 "\"rows\": %ld, \"max_rel_err\": %.3e, \"worst_row_over_8d_bound\": %.3e, \"rows_outside_8d_bound\": %ld, "
-                 "\"bitexact\": %s, \"pass\": %s}}\n",
-                 kernel.name().c_str(), format.c_str(), multiplies, out.rows, out.worst_rel, out.worst_over_bound, out.outside,
-                 out.bitexact ? "true" : "false", out.outside == 0 ? "true" : "false");
+                 "\"rows\": %ld, \"max_rel_err\": %.3e, \"worst_row_over_8d_bound\": %.3e, \"rows_within_summation_bound_only\": %ld, "
+                 "\"rows_outside_both_bounds\": %ld, \"bitexact\": %s, \"pass\": %s}}\n",
+                 kernel.name().c_str(), format.c_str(), multiplies, out.rows, out.worst_rel, out.worst_over_bound, out.by_summation_bound,
+                 out.outside, out.bitexact ? "true" : "false", out.outside == 0 ? "true" : "false");
     return out.outside == 0 ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

@@ -2,7 +2,9 @@
 #pragma once
 
 #include "tile_common.hpp"
-#include "csr_hub.hpp"
+#ifdef SPMV_HIP_EXPERIMENTS
+#include "csr_hub.hpp" // retired from the product library (internal.hpp)
+#endif
 
 namespace spmv {
 
@@ -103,8 +105,10 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
         const int last = (k1 - 1 - kb) & ~3;
         if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, 0, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);
+#ifdef SPMV_HIP_EXPERIMENTS
         else if (HUB)
             tile_products_wide_hub<QUADS, VI>(prod, jh + kb, a + kb, x, hubx, last, lane, vidx + kb, vtab);
+#endif
         else
             tile_products_wide<QUADS, X32, VI>(prod, j + kb, a + kb, x, last, lane, vidx + kb, vtab);
         // (3) every non-empty row marks the slot of its first entry

@@ -37,15 +37,24 @@ void set_last_error_text(std::string const & text);
             return ::spmvi::fail_hip(e_, #call);        \
     } while (0)
 
+// Two kernel families were built, measured slower than the paths they were meant to replace, and retired from the product
+// library in round 5: hub columns for web graphs (csr_hub.hpp: 26.6 against 23.9 us) and a lane group per
+// row for stencil rows of 17 ... 64 entries (csr_rowgroup.hpp: 797 against 740 us).  They live on in
+// libspmv_hip_experiments.so (-DSPMV_HIP_EXPERIMENTS), with their parity tests (tests/experiments/); the product library
+// refuses both bits like any unknown flag.
+#define SPMV_HIP_FLAG_HUB_COLUMNS 0x4000000u
+#define SPMV_HIP_FLAG_ROW_GROUPS 0x10000000u
+
 // every documented SPMV_HIP_FLAG_* bit; anything else is refused (SPMV_HIP_ERR_INVALID)
 constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_BIG_TILE |
     SPMV_HIP_FLAG_NO_INDEX_COMPRESSION | SPMV_HIP_FLAG_COO_KEEP_ORDER | SPMV_HIP_FLAG_READ_ROW_PTR | SPMV_HIP_FLAG_ROWS64 |
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_NO_MULTI_WINDOW | SPMV_HIP_FLAG_ROW_GROUPS
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MULTI_WINDOW
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
+    | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_ROW_GROUPS // kernel families that were measured SLOWER than the default path (below)
 #endif
     ;
 

@@ -163,6 +163,7 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
 #define SPMV_SEG_X(C, R) do { if (x32) SPMV_SEG_LAUNCH(C, true, R); else SPMV_SEG_LAUNCH(C, false, R); } while (0)
 #define SPMV_SEG_C(R) do { if (c16) SPMV_SEG_X(true, R); else SPMV_SEG_X(false, R); } while (0)
             const bool vi = c16 && x32 && !xcd && pl->nvalues > 0 && pl->values_from == a;
+#ifdef SPMV_HIP_EXPERIMENTS
             if (c16 && x32 && !xcd && pl->nhubs > 0) {
                 // hub columns: the dense copy of their x entries first (every multiply: x is the caller's), then the tiles
                 hipLaunchKernelGGL(spmv::hub_gather_kernel, dim3((unsigned) ((pl->nhubs + 255) / 256)), dim3(256), 0, s, pl->nhubs, pl->d_hub_column, x,
@@ -174,7 +175,9 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                     hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j,
                                        pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, (const uint8_t *) nullptr, (const double *) nullptr, 0, pl->d_colh,
                                        pl->d_hubx);
-            } else if (vi)
+            } else
+#endif
+            if (vi)
                 // a value dictionary (pattern / graph matrices): one index byte per entry instead of eight bytes of value
                 hipLaunchKernelGGL((spmv::csr_segtile_kernel<true, true, false, true>), grid, dim3(256), 0, s, pl->ntiles, pl->d_tiles, p, j, pl->d_col16,
                                    a, x, y_in, y, pl->nnz, pl->cols, pl->d_vidx, pl->d_vtab, pl->nvalues);
@@ -234,7 +237,9 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                     hipLaunchKernelGGL((spmv::csr_wavetile_kernel<512, true, false, false, 0, 0, false, false, false, true>), grid, dim3(256), 0, s,
                                        pl->nrest_tiles, pl->d_tiles, p, j, pl->d_col16, a, x, y_in, y, pl->nnz, pl->cols, exact, pl->d_patterns,
                                        spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_rest_tiles);
-            } else if (pl->d_group_tiles && c16 && x32 && !xcd && !exact && pl->tile == 512 && (!peers || pl->split_rows == 0)) {
+            } else
+#ifdef SPMV_HIP_EXPERIMENTS
+            if (pl->d_group_tiles && c16 && x32 && !xcd && !exact && pl->tile == 512 && (!peers || pl->split_rows == 0)) {
                 // most tiles are rows of 17 ... 64 entries of a stencil or band: a group of lanes per row (csr_rowgroup.hpp),
                 // then the other tiles (the x-window variant over a list)
                 const dim3 grid((unsigned) ((pl->ngroup_tiles + 3) / 4)), rest((unsigned) ((pl->ngroup_rest + 3) / 4));
@@ -255,6 +260,7 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                                            spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_group_rest);
                 }
             } else
+#endif
             // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants
             // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -211,6 +212,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             *q = nullptr;
         }
     pl->ngroup_tiles = pl->ngroup_rest = 0;
+#ifdef SPMV_HIP_EXPERIMENTS
     if ((pl->flags & SPMV_HIP_FLAG_ROW_GROUPS) && compressed && pl->nvalues == 0 && !pl->d_blocks && !pl->d_segblocks && pl->tile == 512 && !pl->balanced && pl->cols < (1 << 29)
         && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_X_WINDOW | SPMV_HIP_FLAG_XCD_REMAP))) {
         std::vector<int32_t> group, rest;
@@ -230,6 +232,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             }
         }
     }
+#endif
     return SPMV_HIP_OK;
 }
 
@@ -261,6 +264,32 @@ int spmv_hip_plan_csr(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
 
 // Wave tiles of a plan from the HOST row_ptr: <= 64 (128) rows and <= tile entries (from the 4-aligned start) per wave.  Used by
 // plan_csr_internal and, once more, by spmv_hip_plan_csr_repack when the block hint taken here turned out to be wrong.
+
+// Runs `work` on up to n of the host's threads, the caller being one of them.  A thread that cannot be started (std::system_error
+// under a container's pid limit, std::bad_alloc) is simply not there: both users hand their items out through an atomic counter,
+// so whoever runs -- at worst the caller alone -- does all of them, and nothing is thrown across the C boundary for it.
+template <class Work>
+static void run_on_host_threads(int n, Work && work)
+{
+    std::vector<std::thread> pool;
+    try {
+        pool.reserve((size_t) std::max(0, n - 1));
+        for (int t = 1; t < n; ++t)
+            pool.emplace_back(work);
+    } catch (std::system_error const &) {
+    } catch (std::bad_alloc const &) {
+    }
+    try {
+        work();
+    } catch (...) {
+        for (auto & th : pool)
+            th.join();
+        throw;
+    }
+    for (auto & th : pool)
+        th.join();
+}
+
 static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flags, int32_t break_rows, int split_threshold, int split_chunk)
 {
     const int32_t rows = pl->rows;
@@ -495,20 +524,14 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
             const int nthreads = (int) std::min<unsigned>({(unsigned) nchunks, hw, 16u});
-            if (nthreads <= 1) {
-                for (int c = 0; c < nchunks; ++c)
+            // (column panels -- break_rows > 0 -- share next_panel and the Range vector across tile_range calls: one chunk only)
+            if (break_rows > 0 && nchunks != 1)
+                return fail(SPMV_HIP_ERR_STATE, "internal: a panel tiling must be cut in one chunk");
+            std::atomic<int> next{0};
+            run_on_host_threads(nthreads, [&] {
+                for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1))
                     tile_range(bound[(size_t) c], bound[(size_t) c + 1], allow_multi, part[(size_t) c]);
-            } else {
-                std::atomic<int> next{0};
-                std::vector<std::thread> pool;
-                for (int t = 0; t < nthreads; ++t)
-                    pool.emplace_back([&] {
-                        for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1))
-                            tile_range(bound[(size_t) c], bound[(size_t) c + 1], allow_multi, part[(size_t) c]);
-                    });
-                for (auto & th : pool)
-                    th.join();
-            }
+            });
         }
         desc.clear();
         stream_tiles = stream_tile_entries = 0;
@@ -624,22 +647,18 @@ int plan_csr_internal(spmv_hip_plan ** out, int32_t rows, int32_t cols, const in
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const int nthreads = rows < (1 << 18) ? 1 : (int) std::min(hw, 16u);
         std::atomic<int> decreasing{0};
-        auto check = [&](int32_t cb, int32_t ce) {
-            int bad = 0;
-            for (int32_t r = cb; r < ce; ++r)
-                bad |= p[r + 1] < p[r];
-            if (bad)
-                decreasing.store(1);
-        };
-        if (nthreads <= 1) {
-            check(0, rows);
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; ++t)
-                pool.emplace_back(check, (int32_t) ((long long) rows * t / nthreads), (int32_t) ((long long) rows * (t + 1) / nthreads));
-            for (auto & th : pool)
-                th.join();
-        }
+        const int nparts = nthreads <= 1 ? 1 : 4 * nthreads;
+        std::atomic<int> next{0};
+        run_on_host_threads(nthreads, [&] {
+            for (int c = next.fetch_add(1); c < nparts; c = next.fetch_add(1)) {
+                const int32_t cb = (int32_t) ((long long) rows * c / nparts), ce = (int32_t) ((long long) rows * (c + 1) / nparts);
+                int bad = 0;
+                for (int32_t r = cb; r < ce; ++r)
+                    bad |= p[r + 1] < p[r];
+                if (bad)
+                    decreasing.store(1);
+            }
+        });
         if (decreasing.load())
             return fail(SPMV_HIP_ERR_INVALID, "row_ptr is not non-decreasing");
     }
@@ -780,6 +799,7 @@ void spmv_hip_plan_destroy(spmv_hip_plan * pl)
 
 int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
 
+#ifdef SPMV_HIP_EXPERIMENTS // retired from the product library (internal.hpp)
 // Hub columns (csr_hub.hpp; opt-in, SPMV_HIP_FLAG_HUB_COLUMNS) for balanced plans -- graph matrices -- whose x does not fit an XCD's L2: in-degrees, the columns
 // with at least `threshold` references (8, doubled while more than 2^18 qualify), the plan's own column stream.  Nothing is kept
 // unless the hubs are few (<= 2^18: 2 MB of x, resident in every L2) and carry a share of the entries worth a second launch
@@ -856,6 +876,7 @@ static int plan_hub_columns(spmv_hip_plan * pl, const int32_t * d_column_index, 
         rc = fail_hip(e, "hub columns");
     return rc;
 }
+#endif
 
 int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
 {
@@ -1058,8 +1079,10 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->meta_bytes += bytes;
     pl->compressed_from = d_column_index;
     int rc = device_column_checksum(d_column_index, pl->nnz, &pl->column_checksum, s);
+#ifdef SPMV_HIP_EXPERIMENTS
     if (rc == SPMV_HIP_OK)
         rc = plan_hub_columns(pl, d_column_index, s);
+#endif
     if (rc == SPMV_HIP_OK)
         rc = plan_account(pl, true);
     pl->verify_pending = true;
@@ -1077,6 +1100,10 @@ int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, voi
 // defined in coo_sort.hip (hipCUB): out[i] = sum of in[0..i), n elements
 int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
 
+static void drop_value_dictionary(spmv_hip_plan * pl);
+static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, const double * d_value,
+                         void * stream, const double ** reindex);
+
 int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
                              const double * d_value, void * stream)
 {
@@ -1084,6 +1111,18 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
         return fail(SPMV_HIP_ERR_INVALID, "plan is null");
     if (pl->inner)
         return fail(SPMV_HIP_ERR_STATE, "plan is already repacked");
+    // A value dictionary built BEFORE this call (compress, index_values, repack -- the header allows the order) describes the
+    // tiling it was built on: when a stage below cuts the tiles anew it is dropped first and built again at the end.
+    const double * reindex = nullptr;
+    int rc = repack_stages(pl, d_row_ptr, d_column_index, d_value, stream, &reindex);
+    if (rc == SPMV_HIP_OK && reindex && !pl->inner)
+        rc = spmv_hip_plan_csr_index_values(pl, reindex, stream);
+    return rc;
+}
+
+static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, const double * d_value,
+                         void * stream, const double ** reindex)
+{
     // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
     if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
         && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
@@ -1130,6 +1169,9 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
             std::vector<int32_t> hp((size_t) pl->rows + 1);
             HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            // the dictionary's tile list (d_tiles_vi) and its constant-row marks number the OLD tiles and patterns
+            *reindex = pl->values_from;
+            drop_value_dictionary(pl);
             for (void * q : {(void *) pl->d_tiles, (void *) pl->d_col16, (void *) pl->d_patterns, (void *) pl->d_blocks, (void *) pl->d_segblocks,
                              (void *) pl->d_rest_tiles})
                 if (q)

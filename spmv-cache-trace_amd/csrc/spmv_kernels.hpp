@@ -13,7 +13,9 @@
 #include "tile_common.hpp"
 #include "csr_basic.hpp"
 #include "csr_wavetile.hpp"
-#include "csr_rowgroup.hpp"
+#ifdef SPMV_HIP_EXPERIMENTS
+#include "csr_rowgroup.hpp" // retired from the product library (internal.hpp)
+#endif
 #include "csr_segtile.hpp"
 #include "csr_panels.hpp"
 #include "csr_blockwin.hpp"

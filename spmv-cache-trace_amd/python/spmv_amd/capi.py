@@ -35,9 +35,9 @@ FLAG_BALANCE_ENTRIES = 0x400000
 FLAG_NO_SEGMENT_WINDOW = 0x800000
 FLAG_FUSED_PEER_STORE = 0x1000000
 FLAG_NO_BLOCK_TILES = 0x2000000
-FLAG_HUB_COLUMNS = 0x4000000
+FLAG_HUB_COLUMNS = 0x4000000  # libspmv_hip_experiments.so only (retired from the product: csrc/internal.hpp)
 FLAG_NO_MULTI_WINDOW = 0x8000000
-FLAG_ROW_GROUPS = 0x10000000  # opt-in (measured slower: include/spmv_hip.h)
+FLAG_ROW_GROUPS = 0x10000000  # libspmv_hip_experiments.so only (retired from the product: csrc/internal.hpp)
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

@@ -11,6 +11,8 @@ import sys
 
 import numpy as np
 
+EXPERIMENTS = os.environ.get("SPMV_HIP_EXPERIMENTS", "") not in ("", "0")  # the row-group flag exists in libspmv_hip_experiments.so only
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -70,7 +72,7 @@ def main():
         want = y0 + oracle.csr_spmv(rows, p, c, v, x, num_threads=1)
         scale = abs_products(rows, p, c, v, x) + np.abs(y0)
         tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
-        for f in (0, capi.FLAG_ROW_GROUPS, capi.FLAG_NO_X_WINDOW, capi.FLAG_EXACT_ORDER):
+        for f in (0, capi.FLAG_NO_X_WINDOW, capi.FLAG_EXACT_ORDER) + ((capi.FLAG_ROW_GROUPS,) if EXPERIMENTS else ()):
             plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, f | capi.FLAG_NO_VALUE_INDEX)
             plan.compress(tc.data_ptr(), stream)
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)

@@ -209,6 +209,63 @@ def test_wrong_hint_rebuilds_the_tiles(oracle):
     assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="scalar rows of 120", nterms=L)
 
 
+def test_dictionary_built_before_a_repack_that_cuts_the_tiles_anew(oracle):
+    """compress, index_values, THEN repack -- an order the header allows.  A constant-coefficient
+    27-point stencil has rows of 27 entries in equal triples (the block hint) that are no 3 x 3 blocks (the hint is wrong and
+    cost tile fill: repack cuts the tiles anew) and few distinct values (a dictionary with constant-row tiles).  The dictionary
+    built on the old tiling must not survive the re-cut: repack drops it and builds it again on the new tiles."""
+    import torch
+    n = 40
+    idx = np.arange(n ** 3).reshape(n, n, n)
+    inner = idx[1:-1, 1:-1, 1:-1].ravel()
+    offs = np.array([dz * n * n + dy * n + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
+    coef = np.where(offs == 0, 26.0, -1.0) * np.array([1.0 + 0.25 * (k % 3) for k in range(27)])  # 5 distinct values
+    rows = cols = len(inner)
+    remap = -np.ones(n ** 3, dtype=np.int64)
+    remap[inner] = np.arange(rows)
+    cc = remap[inner[:, None] + offs[None, :]]
+    keep = cc >= 0
+    # boundary rows of the interior block lose entries: keep whole rows only where all 27 neighbours exist, pad the rest to 27 with their own diagonal
+    cc = np.where(keep, cc, remap[inner][:, None])
+    vv = np.where(keep, coef[None, :], 0.0)
+    order = np.argsort(cc, axis=1, kind="stable")
+    c = np.take_along_axis(cc, order, axis=1).astype(np.int32).ravel()
+    v = np.take_along_axis(vv, order, axis=1).ravel()
+    p = (np.arange(rows + 1, dtype=np.int64) * 27).astype(np.int32)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got = {}
+    for name, order_of_calls in (("index_values before repack", ("compress", "index_values", "repack")),
+                                 ("the default order", ("compress", "repack", "index_values"))):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, 0)
+        before = None
+        for call in order_of_calls:
+            if call == "compress":
+                plan.compress(tc.data_ptr(), stream)
+            elif call == "index_values":
+                plan.index_values(tv.data_ptr(), stream)
+            else:
+                before = plan.info()
+                plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        info = plan.info()
+        assert info["block_tiles"] == 0 and info["row_blocks"] < before["row_blocks"], (name, before["row_blocks"], info["row_blocks"])
+        assert info["indexed_values"] > 0, (name, info)  # the dictionary is there AFTER the re-cut, whatever the order
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        for _ in range(2):
+            plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got[name] = ty.cpu().numpy()
+        plan.close()
+        want2 = oracle.csr_spmv(rows, p, c, v, x, y=want.copy(), num_threads=4)
+        assert_close(got[name], want2, 2 * scale, what=name, nterms=27)
+    assert_bitexact(got["index_values before repack"], got["the default order"], "both orders end in the same plan")
+
+
 def test_queen_like_generator_and_context_uploads(oracle):
     """The Queen_4147 stand-in at a small size through the Level-2 plan and through the context API (CSR and COO uploads: the
     sorted triplets run as the same row-major tiles)."""

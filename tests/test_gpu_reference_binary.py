@@ -54,9 +54,13 @@ def test_reference_program_with_the_adapter_matches_its_cpu_kernel(matrices, fmt
     assert doc["kernel"]["name"] == "hip-%s-spmv" % fmt and doc["kernel"]["matrix_format"] == fmt
     assert doc["execution_time"]["samples"] == 4 and doc["execution_time"]["min"] > 0
     check = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"check"')][-1])["check"]
-    assert check["pass"] is True and check["rows_outside_8d_bound"] == 0 and check["rows"] == doc["kernel"]["rows"]
+    assert check["pass"] is True and check["rows_outside_both_bounds"] == 0 and check["rows"] == doc["kernel"]["rows"]
     assert check["max_rel_err"] <= 1e-10
-    if name == "poisson2D":  # rows of <= 5 entries are summed by one lane in the reference's order
+    # rows whose products cancel may need the a-priori summation bound (2 k (n+1) 2^-53 (|A||x|)_i) when their sum is formed
+    # in another order than the reference's: only the reference's poisson2D fixture, whose COO triplets are not in column order
+    if not (name == "poisson2D" and fmt == "coo"):
+        assert check["rows_within_summation_bound_only"] == 0, check
+    if name == "poisson2D" and fmt != "coo":  # rows of <= 5 entries are summed by one lane in the reference's order
         assert check["bitexact"] is True
 
 

@@ -41,7 +41,6 @@ run kkt_csr_noshift --workload kkt --flags 0x400
 run kkt_csr_jitter50 --matrix synthetic:kkt:200,50
 run queen_csr_jitter6 --matrix synthetic:queen:110,71,177,6
 run queen_csr_noblocks --workload queen --flags 0x2000000
-run webbase_csr_hubs --workload webbase --flags 0x4000000
 # the launches of tests/test_gpu_perf_floor.py measured on this box -- measured and logged only: updating the committed table
 # (tests/golden/perf_floor.json) is an explicit, reviewed step (python3 tools/perf_floor.py --write), never a side effect of a
 # sweep, or a regressed build run through this script would loosen the very floor that exists to catch it
