@@ -368,7 +368,24 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
     nnz = A["nnz"]
     if fmt == "csr":
         p, c, v = A["p"], A["c"], A["v"]
-    if fmt == "csr" and oracle_py.RefLib.available():
+    spec, _ = workload_spec(args)
+    child = None
+    if fmt == "csr" and spec is not None and oracle_py.RefLib.available() and not args.cpu_threads and budget >= 2 and \
+            os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_profile.so")):
+        child = cpu_baseline_protocol(args, spec, threads, budget)
+    if fmt == "csr" and child is not None and "error" not in child:
+        # SURVEY 8(d)'s protocol, run in a process of its own (the OpenMP runtime reads its placement variables at start-up);
+        # here only the y for the parity gate is computed, by the same reference kernel
+        R = oracle_py.RefLib()
+        M = R.csr_from_arrays(rows, cols, p, c, v)
+        y_cpu = R.csr_spmv(M, x, num_threads=min(threads, 16)) if y_gpu is not None else None
+        R.csr_free(M)
+        threads = child["threads"]
+        ns = np.array([child["median_ns"], child["min_ns"]])
+        med_override = child["median_ns"] * 1e-9
+        ns1 = np.array([2.0 * nnz / child["single_thread_gflops"]])
+        kind = "reference"
+    elif fmt == "csr" and oracle_py.RefLib.available():
         R = oracle_py.RefLib()
         M = R.csr_from_arrays(rows, cols, p, c, v)
         t = time.perf_counter()
@@ -423,6 +440,8 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
         y_cpu = fresh(threads if fmt in ("csr", "ell") else 1) if y_gpu is not None else None
         kind = "port"
     med = float(np.median(ns)) * 1e-9
+    if child is not None and "error" not in child:
+        med = med_override
     parity = None
     if y_gpu is not None:
         diff = np.abs(y_gpu - y_cpu)
@@ -437,13 +456,44 @@ def cpu_baseline(args, fmt, rows, cols, A, x, y_gpu=None, budget=None):
                   "worst_row_over_8d_bound": round(worst_row, 4) if finite else "nan",
                   "rows_outside_8d_bound": int(np.count_nonzero(diff > row_bound)) if finite else None,
                   "bitexact": bool(np.array_equal(y_gpu, y_cpu))}
-    return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
-            "sample": "full workload (%s), %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
-                      % (fmt, len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
-            "gbs": round(A["bytes"] / med / 1e9, 2),
-            "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3),
-            "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
-            "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}}, parity
+    out = {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
+           "sample": "full workload (%s), %d timed runs after 1 warm-up, median %.2f ms (min %.2f ms), %d OpenMP threads"
+                     % (fmt, child["runs"] if (child and "error" not in child) else len(ns), med * 1e3, float(np.min(ns)) * 1e-6, threads),
+           "gbs": round(A["bytes"] / med / 1e9, 2),
+           "single_thread_gflops": round(2.0 * nnz / (float(np.median(ns1)) * 1e-9) / 1e9, 3),
+           "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+           "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}}
+    if child is not None and "error" not in child:
+        out.update({"omp": child["omp"], "sweep": child["sweep"], "cpus": child["cpus"], "numa_nodes_of_the_team": sorted(set(child["numa_nodes"])),
+                    "numa_nodes_configured": child["numa_nodes_configured"], "pages_distributed": child["pages_distributed"],
+                    "protocol": "SURVEY 8(d): a process of its own with OMP_PROC_BIND=close OMP_PLACES=cores; arrays first touched by the master as the "
+                                "reference's init does, then moved page by page to the NUMA node of the owning thread by the reference's own "
+                                "distribute_pages (src/util/aligned-allocator.hpp:216-271, as csr-spmv.cpp:48-62 calls it); 1 warm-up run, then runs timed "
+                                "like profile_kernel_run (src/profile-kernel.cpp:137-179); team size = the fastest of `sweep` (3 runs each)"})
+    elif child is not None:
+        out["protocol_error"] = child["error"]
+    return out, parity
+
+
+def cpu_baseline_protocol(args, spec, granted, budget):
+    """oracle/cpu_baseline_child.py in a process of its own: the OpenMP runtime must see OMP_PROC_BIND / OMP_PLACES when it starts."""
+    env = dict(os.environ)
+    env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    visible = len(os.sched_getaffinity(0))  # the affinity mask; `granted` is that capped by the cgroup CPU quota
+    teams = sorted({t for t in (16, 32, 64, granted) if 0 < t <= visible} | {granted})
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_child.py"), "--spec", spec, "--budget", str(budget),
+           "--threads", ",".join(str(t) for t in teams)]
+    if args.expand_symmetric:
+        cmd.append("--expand-symmetric")
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=max(120.0, 20 * budget))
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": str(e)[:300]}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout).strip()[-300:]}
+    return json.loads(lines[-1])
 
 
 def reference_protocol(args, fmt, runs, flush=False):

@@ -211,27 +211,29 @@ def test_wrong_hint_rebuilds_the_tiles(oracle):
 
 def test_dictionary_built_before_a_repack_that_cuts_the_tiles_anew(oracle):
     """compress, index_values, THEN repack -- an order the header allows.  A constant-coefficient
-    27-point stencil has rows of 27 entries in equal triples (the block hint) that are no 3 x 3 blocks (the hint is wrong and
-    cost tile fill: repack cuts the tiles anew) and few distinct values (a dictionary with constant-row tiles).  The dictionary
+    30-point stencil has rows of 30 entries in equal triples (the block hint) that are no 3 x 3 blocks (the hint is wrong and
+    cost tile fill -- 15 rows per tile instead of 17: repack cuts the tiles anew) and few distinct values (a dictionary with constant-row tiles).  The dictionary
     built on the old tiling must not survive the re-cut: repack drops it and builds it again on the new tiles."""
     import torch
     n = 40
     idx = np.arange(n ** 3).reshape(n, n, n)
     inner = idx[1:-1, 1:-1, 1:-1].ravel()
-    offs = np.array([dz * n * n + dy * n + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
-    coef = np.where(offs == 0, 26.0, -1.0) * np.array([1.0 + 0.25 * (k % 3) for k in range(27)])  # 5 distinct values
+    # 27 points + 3 more: rows of 30 entries, of which 17 fit a 512-entry tile -- the hint cuts that down to 15 (block_cuts > 0)
+    offs = np.array([dz * n * n + dy * n + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)] + [-2, 2, 2 * n])
+    L = len(offs)
+    coef = np.where(offs == 0, 26.0, -1.0) * np.array([1.0 + 0.25 * (k % 3) for k in range(L)])  # 5 distinct values
     rows = cols = len(inner)
     remap = -np.ones(n ** 3, dtype=np.int64)
     remap[inner] = np.arange(rows)
     cc = remap[inner[:, None] + offs[None, :]]
     keep = cc >= 0
-    # boundary rows of the interior block lose entries: keep whole rows only where all 27 neighbours exist, pad the rest to 27 with their own diagonal
+    # boundary rows of the interior block lose entries: pad them to the full length with zeros on their own diagonal
     cc = np.where(keep, cc, remap[inner][:, None])
     vv = np.where(keep, coef[None, :], 0.0)
     order = np.argsort(cc, axis=1, kind="stable")
     c = np.take_along_axis(cc, order, axis=1).astype(np.int32).ravel()
     v = np.take_along_axis(vv, order, axis=1).ravel()
-    p = (np.arange(rows + 1, dtype=np.int64) * 27).astype(np.int32)
+    p = (np.arange(rows + 1, dtype=np.int64) * L).astype(np.int32)
     x = synth.x_vector(cols, seed=3)
     y0 = synth.x_vector(rows, seed=4)
     dev = torch.device("cuda:0")
@@ -262,7 +264,7 @@ def test_dictionary_built_before_a_repack_that_cuts_the_tiles_anew(oracle):
         got[name] = ty.cpu().numpy()
         plan.close()
         want2 = oracle.csr_spmv(rows, p, c, v, x, y=want.copy(), num_threads=4)
-        assert_close(got[name], want2, 2 * scale, what=name, nterms=27)
+        assert_close(got[name], want2, 2 * scale, what=name, nterms=L)
     assert_bitexact(got["index_values before repack"], got["the default order"], "both orders end in the same plan")
 
 
