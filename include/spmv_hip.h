@@ -75,10 +75,11 @@ extern "C" {
                                             exceeds ~512 MB (streams from HBM), 64 while it is cache-resident */
 #define SPMV_HIP_FLAG_ELL_COLUMN_MAJOR 0x200u /* ctx: always transpose ELLPACK to column-major and use the one-lane-per-row
                                                 kernel (bit-exact for any row length).  Default: the row-major arrays in
-                                                place as uniform wave tiles for rows of up to 2048 entries (several lanes per
-                                                row of more than 16 entries: 1e-10 class; rows of 161..2048 entries in
-                                                multi-window tiles) and the column-major kernel -- bit-exact -- for longer
-                                                rows; with SPMV_HIP_FLAG_EXACT_ORDER the column-major kernel takes rows of
+                                                place as wave tiles for EVERY row length (several lanes per row of more than
+                                                16 entries: 1e-10 class; rows of 161..1024 entries in multi-window tiles,
+                                                longer rows a wave each in registers -- round 5; until round 4 rows of more
+                                                than 2048 entries took the column-major kernel); with
+                                                SPMV_HIP_FLAG_EXACT_ORDER the column-major kernel takes rows of
                                                 more than 80 entries.  Which path an upload took: spmv_hip_ctx_info [17] */
 #define SPMV_HIP_FLAG_NO_SHIFTED_TILES 0x400u /* plan_csr_compress: do not look for tiles whose rows all repeat the first
                                                  row's columns shifted by the row distance (stencil interiors, bands);
@@ -137,9 +138,9 @@ extern "C" {
  * entries, 797 vs 740 us: DESIGN.md sections 3.3, 3.1b) were retired from the product library in round 5 and are
  * refused like any unknown bit.  They live on in libspmv_hip_experiments.so (csrc/internal.hpp) for tools/ and
  * tests/experiments/. */
-#define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 161 ... 2048 entries, which fill a
-                                             512-entry tile badly (one row of 361: 70 %) or do not fit one at all (a wave per row, or
-                                             chunks that meet in atomics), are taken two to eight at a time by one wave that walks
+#define SPMV_HIP_FLAG_NO_MULTI_WINDOW 0x8000000u /* plan_csr: no multi-window tiles.  By default rows of 161 ... 1024 entries, which fill a
+                                             512-entry tile badly (one row of 361: 70 %) or do not fit one at all,
+                                             are taken two to eight at a time by one wave that walks
                                              them in windows of 512 entries and carries the row sums in registers (7 rows of 361 =
                                              4.94 windows): no atomics, the same y on every run.  1e-10 class like every row of more than 16 entries;
                                              never under SPMV_HIP_FLAG_EXACT_ORDER */
@@ -211,9 +212,13 @@ int spmv_hip_upload_coo(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t n
                         const double *value);
 
 /* ELLPACK in the reference's ROW-MAJOR padded layout, k = i*row_length + l
- * (src/matrix/ell-matrix.cpp:253-256).  With row_length <= 256 the arrays are used in place as
- * uniform wave tiles (one lane per row, padding multiplied like real entries); longer rows are
- * transposed to column-major on the device.  Either way the sums keep the reference's order. */
+ * (src/matrix/ell-matrix.cpp:253-256).  The arrays are used in place as uniform wave tiles, padding multiplied
+ * like real entries.  Summation order: rows of up to 16 entries are added by one lane in the reference's order
+ * (bit-exact); longer rows by 2..64 lanes (1e-10 class) -- rows of 161..1024 entries in multi-window tiles, longer
+ * rows a wave each (a small matrix: a few waves per row meeting in fp64 atomics).  The reference's order for every
+ * row length: SPMV_HIP_FLAG_EXACT_ORDER or SPMV_HIP_FLAG_ELL_COLUMN_MAJOR (a column-major copy, one lane per row).
+ * Behaviour changes: round 4 (rows of 161..2048 entries lost bit-exactness by default), round 5 (rows of more than
+ * 2048 entries too: they no longer take the column-major kernel unless asked). */
 int spmv_hip_upload_ell(spmv_hip_ctx *ctx, int32_t rows, int32_t cols, int32_t row_length,
                         const int32_t *column_index, const double *value);
 

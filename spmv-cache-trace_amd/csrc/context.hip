@@ -388,9 +388,10 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     const bool exact = (c->flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
     // (round 4: multi-window tiles -- a wave takes up to 8 such rows and walks them in windows of 512 entries -- fill the tiles of
     // these lengths again; SPMV_HIP_FLAG_NO_MULTI_WINDOW brings the column-major kernel back for them)
-    // Rows of more than 2048 entries -- a wave (or several, meeting in atomics) per row -- stay with the column-major kernel:
-    // 0.65-0.69 either way, and the column-major kernel keeps the reference's order (profiles/r04_ell_long_rows.md).
-    const bool poor_fill = (row_length > 160 && row_length <= 2048 && (c->flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) || row_length > 2048;
+    // Rows of more than 2048 entries (round 5): a wave per row walks them in place, in registers (long_row_sum, tile_common.hpp),
+    // with 16-bit columns where the row's columns allow; the column-major copy (0.60-0.69 of the roofline,
+    // profiles/r04_ell_long_rows.md) is left to SPMV_HIP_FLAG_ELL_COLUMN_MAJOR and to EXACT_ORDER (it keeps the reference's order).
+    const bool poor_fill = row_length > 160 && row_length <= 2048 && (c->flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW);
     c->ell_as_tiles = n > 0 && !(c->flags & SPMV_HIP_FLAG_ELL_COLUMN_MAJOR)
         && (exact ? row_length <= kEllInPlaceMaxLength : !poor_fill || c->ell_in_place_any_length);
     if (c->ell_in_place_any_length)

@@ -34,8 +34,10 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
     // (a tile of SEVERAL rows that holds more than `tile` entries is a multi-window tile, csr_wavetile.hpp: it may have 16-bit
     // columns like any other, but none of the classes below that park a whole tile's columns or x in LDS)
     const bool big = k1 - (k0 & ~3) > tile;
-    if ((d0.x & kTileFlagPartial) || k1 <= k0 || (big && (d1.x & ~kTileFlagPartial) - (d0.x & ~kTileFlagPartial) < 2))
-        return; // long rows and empty tiles keep 32-bit indices
+    if (k1 <= k0)
+        return; // empty tiles
+    // one long row, or one chunk of it (long_row_sum, tile_common.hpp): 16-bit columns where the chunk's columns allow, nothing else
+    const bool long_row = (d0.x & kTileFlagPartial) || (big && (d1.x & ~kTileFlagPartial) - (d0.x & ~kTileFlagPartial) < 2);
     int cmin = 0x7FFFFFFF, cmax = -1;
     for (int k = k0 + lane; k < k1; k += kWave) {
         const int c = j[k];
@@ -59,7 +61,7 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         for (int k = k0 + lane; k < k1; k += kWave)
             j16[k] = (uint16_t) (j[k] - cmin);
     const int len = d0.z & 0xFFFF;
-    int shifted = detect_shifted && !big && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
+    int shifted = detect_shifted && !big && !long_row && (d0.z & kTileMetaFast) && (d0.z & kTileMetaUniform) && len >= 1
                   && len <= kShiftedMaxLen && k1 - k0 >= 2 * len && tile <= 1024;
     if (shifted) {
         int ok = 1;
@@ -70,7 +72,7 @@ static __global__ __launch_bounds__(256) void csr_tile_compress_kernel(
         shifted = __all(ok);
     }
     int xwin = 0;
-    if (narrow && !big && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
+    if (narrow && !big && !long_row && cmax - cmin < 256 && k1 - k0 >= 2 * (cmax - cmin + 1))
         xwin = kTileMetaXWin | (((cmax - cmin) >> 6) << kTileMetaXChunksShift);
     if (shifted && fingerprint) {
         // the tile's shape: (row length, rows, first-row columns relative to the first row);

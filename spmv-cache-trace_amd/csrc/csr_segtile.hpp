@@ -229,20 +229,9 @@ __global__ __launch_bounds__(256, 6) void csr_segtile_kernel(
             y[r0 + r] = y_in[r0 + r] + z;
         }
     } else {
-        // ---- one long row, or one chunk of a very long row: the wave strides it
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-        int k = k0 + lane;
-        for (; k + 3 * kWave < k1; k += 4 * kWave) { // 4 independent gathers in flight
-            const int c0 = j[k], c1 = j[k + kWave], c2 = j[k + 2 * kWave], c3 = j[k + 3 * kWave];
-            const double v0 = a[k], v1 = a[k + kWave], v2 = a[k + 2 * kWave], v3 = a[k + 3 * kWave];
-            z0 += v0 * x[c0];
-            z1 += v1 * x[c1];
-            z2 += v2 * x[c2];
-            z3 += v3 * x[c3];
-        }
-        for (; k < k1; k += kWave)
-            z0 += a[k] * x[j[k]];
-        const double z = group_sum<kWave>((z0 + z1) + (z2 + z3));
+        // ---- one long row, or one chunk of a very long row: the whole wave, in registers (tile_common.hpp)
+        const bool narrow = C16 && (meta & kTileMetaNarrow);
+        const double z = long_row_sum<X32>(j, j16, narrow, a, x, narrow ? cbase : 0, (unsigned) (cols - 1 - (narrow ? cbase : 0)), k0, k1, lane);
         if (lane == 0) {
             if (partial)
                 unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ

@@ -174,6 +174,10 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         } else if (narrow || (compressed && stream_tile && (meta & spmv::kTileMetaBlockWin))) {
             col_bytes = 2 * entries; // 16-bit offsets from the tile's base, or window slots (segment windows: any column range)
             pl->narrow_entries += entries;
+        } else if (compressed && !(meta & spmv::kTileMetaFast) && (meta & spmv::kTileMetaNarrow) && entries > 0
+                   && ((d[(size_t) w].x & 0x80000000) || (long long) d[(size_t) w + 1].y - (d[(size_t) w].y & ~3) > pl->tile)) {
+            col_bytes = 2 * entries; // a long row (or a chunk of one) whose columns span less than 65536: long_row_sum reads the 16-bit stream
+            pl->narrow_entries += entries;
         }
         if (uniform)
             pl->uniform_rows += rows;
@@ -297,6 +301,18 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     const int tile = (flags & SPMV_HIP_FLAG_BIG_TILE) ? 1024 : 512;
     const bool exact = (flags & SPMV_HIP_FLAG_EXACT_ORDER) != 0;
     pl->tile = tile;
+    // A row longer than a tile is walked by ONE wave in registers (long_row_sum, tile_common.hpp: 512 entries per step).  It is cut
+    // into chunks -- one wave each, meeting in one fp64 atomic per chunk -- only as far as a wave walking it alone would be the
+    // tail of the launch: a chunk is 1/8192 of the matrix (the chip runs 8192 waves side by side), at least split_chunk entries.
+    // A web graph of 3 M entries keeps its chunks of 512; the 4096-entry rows of a 33 M-entry ELLPACK matrix stay whole (no
+    // atomics, the same y on every run), as do the rows of any matrix with more than 8192 equally long rows.
+    {
+        const long long per_wave = (((long long) p[rows] / 8192) + 511) & ~511LL;
+        if (per_wave > split_chunk) {
+            split_chunk = (int) std::min<long long>(per_wave, 1LL << 24);
+            split_threshold = std::max(split_threshold, split_chunk);
+        }
+    }
     // Block hint (csr_blocktile.hpp): rows in triples of equal length, divisible by 3 and longer than 16 entries -- three
     // unknowns per mesh node.  Only a hint: tiles are then cut on triple boundaries, and spmv_hip_plan_csr_repack checks the
     // columns of every tile before it marks it.
@@ -413,9 +429,12 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         int multi_lanes_log2 = -1;
         // (measured on ELLPACK bands, profiles/r04_ell_long_rows.md: 177 ... 441 per row 0.69-0.72 -> 0.76-0.84 of the roofline; rows
         // of up to 160 keep the plain tile -- three rows of 141 fill it to 83 % and have their x window, 0.93 against 0.90)
-        // (... and rows of 513 ... 2048 entries, which otherwise have a wave each -- or, beyond 512, chunks that meet in atomics --
-        // are taken two to eight at a time the same way: no atomics, the same y on every run)
-        const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= 2048;
+        // (... and rows of 513 ... 1024 entries are taken two to eight at a time the same way)
+        // (round 5: rows of more than kMultiWindowMaxRow = 1024 entries are better off with a wave each, in registers -- bands of
+        // 2001 per row 0.75 in multi-window tiles, 0.80 a wave per row; 1001 and 1501 per row the same either way; 601 and 801 per row
+        // 0.75 against 0.66 / 0.71: profiles/r05_csr_long_rows.log)
+        constexpr int kMultiWindowMaxRow = 1024;
+        const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= kMultiWindowMaxRow;
         // (under the block hint only rows that no block tile could hold: three rows of more than 170 entries exceed a tile)
         const bool hint_allows = !pl->block_hint || (r1 > r ? maxlen > 170 : true);
         if (!exact && tile == 512 && break_rows == 0 && hint_allows && multi_start && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
@@ -432,7 +451,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             int mx = 0;
             for (int32_t q = r; q < ce && q - r < 8; ++q) {
                 mx = std::max(mx, p[q + 1] - p[q]);
-                if (mx > 2048)
+                if (mx > kMultiWindowMaxRow)
                     break;
                 const long long e = (long long) p[q + 1] - kb;
                 const long long windows = (e + tile - 1) / tile;

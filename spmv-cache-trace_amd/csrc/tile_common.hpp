@@ -302,4 +302,66 @@ __device__ __forceinline__ void tile_products_narrow(
     }
 }
 
+// One LONG ROW (or one chunk of it), entries [k0, k1), summed by the whole wave IN REGISTERS (round 5).  Every lane of the wave
+// works for the same row, so nothing has to be parked: the 4-aligned interior [ka, kz) is read exactly like a tile's streams --
+// per lane and step one 16-byte quad of columns (8 bytes where the plan holds 16-bit offsets for this tile) and two 16-byte
+// loads of values, two quads per lane in flight, 512 entries per wave and step -- the products go straight into four
+// accumulators per lane, and ONE butterfly over the wave closes the row.  The up to three entries in front of ka and behind kz
+// are taken by single lanes with scalar-width loads from the 32-bit columns (always there).  This replaces a loop of 4-byte
+// column / 8-byte value loads (a quarter of the bytes per instruction) and, for ELLPACK rows of more than 2048 entries, the
+// column-major copy (src/matrix/ell-matrix.cpp:243-258: the row loop the reference runs; 1e-10 class, not its order).
+template <bool X32>
+__device__ __forceinline__ double long_row_sum(
+    const int32_t * __restrict__ j, const uint16_t * __restrict__ j16, bool narrow, const double * __restrict__ a,
+    const double * __restrict__ x, int cbase, unsigned limit /* last valid offset from cbase */, int k0, int k1, int lane)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+    const int ka = (k0 + 3) & ~3, kz = k1 & ~3;
+    if (ka >= kz) { // fewer than one whole quad: the lanes take an entry each
+        for (int k = k0 + lane; k < k1; k += kWave)
+            z0 += a[k] * x[j[k]];
+        return group_sum<kWave>(z0);
+    }
+    if (lane < ka - k0)
+        z0 += a[k0 + lane] * x[j[k0 + lane]];
+    if (lane >= 4 && lane - 4 < k1 - kz)
+        z1 += a[kz + lane - 4] * x[j[kz + lane - 4]];
+    const char * xb = reinterpret_cast<const char *>(x + cbase);
+    for (int o = ka + 4 * lane; o < kz; o += 2 * 4 * kWave) {
+        const bool two = o + 4 * kWave < kz;          // per lane: the second quad of this step exists
+        const int o2 = two ? o + 4 * kWave : o;        // (otherwise the first is read again and nothing added)
+        unsigned c[8];
+        if (narrow) {
+            const v2u ca = *reinterpret_cast<const v2u *>(j16 + o), cb = *reinterpret_cast<const v2u *>(j16 + o2);
+            c[0] = ca.x & 0xFFFFu; c[1] = ca.x >> 16; c[2] = ca.y & 0xFFFFu; c[3] = ca.y >> 16;
+            c[4] = cb.x & 0xFFFFu; c[5] = cb.x >> 16; c[6] = cb.y & 0xFFFFu; c[7] = cb.y >> 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                c[i] = min(c[i], limit);
+        } else {
+            const v4i ca = *reinterpret_cast<const v4i *>(j + o), cb = *reinterpret_cast<const v4i *>(j + o2);
+            c[0] = (unsigned) ca.x; c[1] = (unsigned) ca.y; c[2] = (unsigned) ca.z; c[3] = (unsigned) ca.w;
+            c[4] = (unsigned) cb.x; c[5] = (unsigned) cb.y; c[6] = (unsigned) cb.z; c[7] = (unsigned) cb.w;
+        }
+        const v2d a0 = *reinterpret_cast<const v2d *>(a + o), a1 = *reinterpret_cast<const v2d *>(a + o + 2);
+        const v2d b0 = *reinterpret_cast<const v2d *>(a + o2), b1 = *reinterpret_cast<const v2d *>(a + o2 + 2);
+        double xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            xv[i] = narrow ? *reinterpret_cast<const double *>(xb + (c[i] << 3)) : gather_x<X32>(x, (int) c[i]);
+        z0 += a0.x * xv[0];
+        z1 += a0.y * xv[1];
+        z2 += a1.x * xv[2];
+        z3 += a1.y * xv[3];
+        if (two) {
+            z0 += b0.x * xv[4];
+            z1 += b0.y * xv[5];
+            z2 += b1.x * xv[6];
+            z3 += b1.y * xv[7];
+        }
+    }
+    return group_sum<kWave>((z0 + z1) + (z2 + z3));
+}
+
 } // namespace spmv

@@ -440,8 +440,8 @@ csr_matrix::Matrix webbase(long long N, long long Z, long long maxrow, int local
 // ---- banded: SURVEY 8d "S-banded(N, b, seed)": N rows, the 2b + 1 diagonals -b .. +b, values U(-1, 1) ----------------
 csr_matrix::Matrix banded(long long N, long long b, std::uint64_t seed, long long rb, long long re, long long * total)
 {
-    if (N < 1 || b < 0 || 2 * b + 1 > 4096)
-        throw matrix::matrix_error("synthetic:banded:<N>,<b>[,seed]: N >= 1, 0 <= b <= 2047");
+    if (N < 1 || b < 0 || 2 * b + 1 > 32768)
+        throw matrix::matrix_error("synthetic:banded:<N>,<b>[,seed]: N >= 1, 0 <= b <= 16383");
     if (total) *total = N;
     if (re < 0) re = N;
     auto len = [=](long long r) { return std::min(N - 1, r + b) - std::max(0LL, r - b) + 1; };

@@ -844,7 +844,7 @@ def test_coo_kernels_on_device_pointers(oracle, variant, order):
             assert_close(ty.cpu().numpy(), want, scale + np.abs(y0), what="%s/coo variant %d/%s" % (name, variant, order))
 
 
-@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 479, 511, 512, 600, 1025, 2048, 2049])
+@pytest.mark.parametrize("L", [1, 16, 27, 160, 161, 255, 256, 257, 300, 361, 479, 511, 512, 600, 1025, 2048, 2049, 2051, 3333, 4096, 4999])
 def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
     """ELLPACK runs in place as wave tiles.  Default: rows of more than 16 entries are summed by several lanes (1e-10);
     EXACT_ORDER keeps one lane per row (in place up to 80 entries per row, column-major beyond) and ELL_COLUMN_MAJOR
@@ -872,12 +872,54 @@ def test_ell_row_lengths_either_side_of_the_tile_switch(oracle, L):
             c2.run()
             assert_ell(c2.get_y(), want, L, flags, ec, ev, x, y0, 2, "ell L=%d flags %x" % (L, flags))
             if flags == 0 and L > 16:
-                # several lanes per row on the row-major arrays in place (rows of 161..2048 entries in multi-window tiles, round 4);
-                # rows of more than 2048 entries: the column-major kernel (profiles/r04_ell_long_rows.md)
-                assert (c2.info()["row_blocks"] > 0) == (L <= 2048), (L, c2.info())
-                assert c2.info()["ell_path"] == (1 if L <= 2048 else 2)
+                # several lanes per row on the row-major arrays in place: rows of 161..2048 entries in multi-window tiles (round 4),
+                # longer rows a wave (or, in a small matrix like this one, a few waves meeting in atomics) per row, in
+                # registers (round 5; the column-major copy only on request)
+                assert c2.info()["row_blocks"] > 0, (L, c2.info())
+                assert c2.info()["ell_path"] == 1
         finally:
             c2.close()
+
+
+@pytest.mark.parametrize("kind", ["band", "scattered"])
+@pytest.mark.parametrize("L", [2052, 2049, 2563])
+def test_ell_whole_long_rows_one_wave_each(oracle, kind, L):
+    """ELLPACK rows of more than 2048 entries in a matrix with more than 8192 of them: every row is walked whole by one wave in
+    registers (no chunks, no atomics: the same y on every run), with 16-bit columns where a row's columns span less than 65536
+    (`band`) and 32-bit ones where they do not (`scattered`).  src/matrix/ell-matrix.cpp:243-258."""
+    rng = np.random.default_rng(L)
+    rows = 8300
+    cols = 9000 if kind == "band" else 200000
+    if kind == "band":
+        start = np.minimum(np.arange(rows), cols - L - 40)
+        ec = (start[:, None] + np.sort(np.argsort(rng.random((rows, L + 40)), axis=1)[:, :L], axis=1)).astype(np.int32)
+    else:
+        ec = np.sort(rng.integers(0, cols, size=(rows, L)), axis=1).astype(np.int32)
+    ev = rng.uniform(-1, 1, size=(rows, L))
+    ev[rng.random((rows, L)) < 0.01] = 0.0
+    ec, ev = np.ascontiguousarray(ec.reshape(-1)), np.ascontiguousarray(ev.reshape(-1))
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2)
+    c2 = capi.Context(0)
+    try:
+        c2.upload_ell(rows, cols, L, ec, ev)
+        info = c2.info()
+        # one tile per row (no chunks), and 10 instead of 12 streamed bytes per entry where the 16-bit columns apply
+        assert info["ell_path"] == 1 and info["row_blocks"] == rows and info["long_blocks"] == rows, info
+        per_entry = (info["streamed_bytes"] - 8 * cols - 32 * rows) / (rows * L)
+        assert abs(per_entry - (10.0 if kind == "band" else 12.0)) < 0.05, (per_entry, info)
+        ys = []
+        for _ in range(2):
+            c2.set_x(x)
+            c2.set_y(y0)
+            c2.run()
+            c2.run()
+            ys.append(c2.get_y())
+        assert_ell(ys[0], want, L, 0, ec, ev, x, y0, 2, "ell whole long rows %s L=%d" % (kind, L))
+        assert np.array_equal(ys[0].view(np.uint64), ys[1].view(np.uint64)), "no atomics: the same bits on every run"
+    finally:
+        c2.close()
 
 
 @pytest.mark.parametrize("name", ["band31", "band81", "band200", "tridiagonal", "poisson2d", "ragged_band", "stencil27", "stencil7"])
@@ -1444,7 +1486,7 @@ def test_coo_and_hybrid_column_panels(oracle):
         c2.close()
 
 
-@pytest.mark.parametrize("length", [201, 257, 361, 600, 1025, 2048])
+@pytest.mark.parametrize("length", [201, 257, 361, 600, 1024, 1025, 2048])
 def test_multi_window_tiles_of_equal_rows(oracle, length):
     """Multi-window tiles of equally long rows that are copies of each other moved along the diagonal (a wide band, a stencil with
     long rows; 600 and 201 are divisible by 3: the plan's block hint must not keep such rows out of the multi-window tiles --
@@ -1480,7 +1522,8 @@ def test_multi_window_tiles_of_equal_rows(oracle, length):
             plan.compress(tc.data_ptr(), stream)
             plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
             info = plan.info()
-            assert info["multi_window_tiles"] > 0, (length, flags, info)
+            # (rows of more than 1024 entries: a wave each, in registers -- round 5)
+            assert (info["multi_window_tiles"] > 0) == (length <= 1024), (length, flags, info)
             ty = torch.from_numpy(y0.copy()).to(dev)
             plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
             tout = torch.full((n,), np.nan, dtype=torch.float64, device=dev)
