@@ -1349,6 +1349,15 @@ def main():
         # cheaper encoding of the columns (shifted tiles read one row of them), so `frac` may pass the rate HBM delivered.
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    #  `achieved` / `frac` are SURVEY 8(d)'s ALGORITHMIC figure, not a bandwidth HBM delivered: where the
+                    # plan streams fewer bytes than the formula counts they pass the ~6.3 TB/s a copy reaches.  The bandwidth
+                    # figures to read beside them: frac_streamed (bytes the tile classes move / time / 8 TB/s), its ratio to the
+                    # triad timed in this process, and frac_traffic (PMC bytes / time / 8 TB/s, from a committed profile of the
+                    # same device code -- counters cannot be read inside this run: traffic_measured_in_this_run is always false)
+                    "achieved_is": "algorithmic bytes / time (SURVEY 8(d)); not a measured bandwidth: see frac_streamed, frac_streamed_of_triad, frac_traffic",
+                    "frac_streamed": round(streamed_gbs / HBM_PEAK_GBS, 4),
+                    "frac_streamed_of_triad": round(streamed_gbs / triad_gbs, 4) if triad_gbs else None,
+                    "frac_traffic": None, "traffic_measured_in_this_run": False,
                     "kernel": kernel_name, "kernel_us": round(kern_s * 1e6, 2),
                     "kernel_us_min": round(float(kernel_ms.min()) * 1e3, 2) if per_launch else None,
                     "events": "per launch" if per_launch else "one pair around the %d timed launches" % args.steps,
@@ -1425,6 +1434,7 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_over_bytes"] = round(tr[0] / max(1, int(streamed)), 3)
+            out["roofline"]["frac_traffic"] = round(tr[0] / kern_s / 1e9 / HBM_PEAK_GBS, 4)
             out["roofline"]["traffic_source"] = ("profiles/%s, kernel %s (%.1f us average under rocprofv3; PMC passes of the same command on the "
                                                  "same device code: source_sha256 %s matches%s)" % (tr[1], tr[3], tr[4], build["source_sha256"],
                                                                                                     "" if tr[2] else "; the .so was rebuilt from it since"))

@@ -144,6 +144,13 @@ extern "C" {
                                              them in windows of 512 entries and carries the row sums in registers (7 rows of 361 =
                                              4.94 windows): no atomics, the same y on every run.  1e-10 class like every row of more than 16 entries;
                                              never under SPMV_HIP_FLAG_EXACT_ORDER */
+#define SPMV_HIP_FLAG_NO_MASKED_BLOCKS 0x20000000u /* plan_csr_repack: no MASKED block tiles.  By default a tile of row triples that is
+                                             not made of dense, aligned 3 x 3 blocks -- explicit zeros dropped from some blocks, a node
+                                             with one or two unknowns that shifts the grid of column triples, rows of a triple that
+                                             differ in length -- is covered greedily with blocks of three consecutive columns and a
+                                             9-bit mask each (a 32-bit word per block instead of a column index per entry) if that
+                                             takes at most 64 blocks holding 6 stored entries on average; with this flag such a tile
+                                             keeps its 16-bit columns (round 4's behaviour: one broken block demotes its tile) */
 /* Any other bit is refused with SPMV_HIP_ERR_INVALID by spmv_hip_create and spmv_hip_plan_csr. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
@@ -365,8 +372,10 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])
  *        [25] block tiles (dense 3 x 3 blocks: one 16-bit number per block, see spmv_hip_plan_csr_repack)  [26] their entries
  *        [27], [28] 0 in this library (hub columns and their entries in libspmv_hip_experiments.so)
- *        [29] multi-window tiles (several rows of 161 ... 512 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW),
- *        [30] 0 in this library (row-group tiles in libspmv_hip_experiments.so) */
+ *        [29] multi-window tiles (several rows of 161 ... 1024 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW),
+ *        [30] 0 in this library (row-group tiles in libspmv_hip_experiments.so)
+ *        [31] of the block tiles [25]: MASKED ones (blocks with entries missing or off the grid of column triples: a 32-bit word
+ *             per block, SPMV_HIP_FLAG_NO_MASKED_BLOCKS)  [32] their entries */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

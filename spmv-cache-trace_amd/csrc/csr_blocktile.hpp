@@ -38,6 +38,41 @@ __host__ __device__ __forceinline__ size_t block_stream_offset(long long nnz_tot
 // ... and where a tile's blocks start in it: every tile in front of it holds at most (its entries / 9) blocks
 __host__ __device__ __forceinline__ int block_stream_index(int k0) { return k0 / 9; }
 
+// MASKED block tiles (round 5): what real finite-element files do to the picture above -- explicit zeros dropped from a block
+// (7 or 8 of its 9 entries stored), a node with one or two unknowns that shifts the grid of column triples, rows of a triple
+// that differ in length.  Such a tile keeps one lane per block, but a block is now ANY three consecutive columns [c, c + 3) in
+// the tile's three-row strip together with a 9-bit mask of the entries that are stored, one 32-bit word per block:
+//     bits 0-15  c - the tile's smallest column      bits 16-24  mask (bit 3 a + b: row a of the triple has column c + b)
+//     bit 31     a block row begins here             bits 25-30  (first word of the tile only) number of blocks - 1
+// The blocks of a block row are the greedy cover of the union of its three rows' columns (csr_block3m_mark_kernel): for dense
+// aligned blocks that is the blocks themselves, otherwise a cover that is merely a little less full.  Where a block's entries
+// lie in the value array follows from the masks in front of it: a prefix sum over the lanes of the three per-row counts
+// (three 10-bit fields in one integer, one DPP scan), so the values are still read IN PLACE (8 bytes per stored entry) and the
+// column information costs 4 bytes per block -- 0.44 ... 0.67 bytes per entry instead of 2.  Tiles whose blocks are all dense
+// and aligned keep the 16-bit stream above (0.22 bytes per entry, no scan).
+constexpr int kTileMetaBlock3Masked = 1 << 29; // only together with kTileMetaBlock3 (a block tile has no x window: the window bits are free)
+constexpr unsigned kMaskedRowBegin = 0x80000000u;
+constexpr int kMaskedMinFill = 6; // entries per block a masked tile must reach to be worth it (and <= 64 blocks)
+__host__ __device__ __forceinline__ size_t mask_stream_offset(long long nnz_total) // in 16-bit units from d_col16; 128-byte aligned
+{
+    return (block_stream_offset(nnz_total) + (size_t) (nnz_total / 9) + 128 + 63) & ~(size_t) 63;
+}
+__host__ __device__ __forceinline__ size_t mask_stream_words(long long nnz_total) { return (size_t) (nnz_total / 4) + 192; }
+// a tile's words start at k0 / 4: every tile in front of it holds at most (its entries / kMaskedMinFill) < (its entries / 4) blocks
+__host__ __device__ __forceinline__ int mask_stream_index(int k0) { return k0 >> 2; }
+
+// inclusive prefix sum over the 64 lanes (every lane active): DPP row shifts inside the rows of 16, then the two row broadcasts
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <int LPR>
 __device__ __forceinline__ double block_row_sum(const double * part, int first, int nb, int t)
 {
@@ -49,31 +84,62 @@ __device__ __forceinline__ double block_row_sum(const double * part, int first, 
 
 typedef double v2d_u8 __attribute__((ext_vector_type(2), aligned(8)));
 
-template <typename YStore>
+template <bool MASKED, typename YStore>
 __device__ __forceinline__ void tile_rows_block3(
-    double * lds, const uint16_t * __restrict__ bc, const double * __restrict__ a, const double * __restrict__ xt /* x + tile base */,
-    const double * y_in, int r0, int k0, int k1, int nrows, int lane, YStore && store)
+    double * lds, const void * __restrict__ stream /* uint16 per block, or (MASKED) uint32 per block */, const double * __restrict__ a,
+    const double * __restrict__ xt /* x + tile base */, const double * y_in, int r0, int k0, int k1, int nrows, int lane, YStore && store)
 {
-    const int nblk = __builtin_amdgcn_readfirstlane((k1 - k0) / 9); // 2 .. 56
+    unsigned e;
+    int nblk;
+    if (MASKED) {
+        e = reinterpret_cast<const unsigned *>(stream)[lane]; // (words past the tile's last block: allocated, never used)
+        nblk = (int) ((__builtin_amdgcn_readfirstlane(e) >> 25) & 63u) + 1;
+    } else {
+        nblk = __builtin_amdgcn_readfirstlane((k1 - k0) / 9); // 2 .. 56
+    }
     const bool mine = lane < nblk;
     const int L = mine ? lane : nblk - 1; // idle lanes repeat the last block's loads (same addresses: no traffic) and add nothing
-    const unsigned e = bc[L];
-    const unsigned long long starts = __ballot(mine && (e & kBlockRowBegin)); // bit 0 is always set
+    if (!MASKED)
+        e = reinterpret_cast<const uint16_t *>(stream)[L];
+    const unsigned long long starts = __ballot(mine && (e & (MASKED ? kMaskedRowBegin : kBlockRowBegin))); // bit 0 is always set
     const unsigned long long upto = starts & (~0ull >> (63 - L));
     const int first = 63 - __builtin_clzll(upto);
     const unsigned long long after = L < 63 ? (starts >> (L + 1)) : 0ull;
     const int next = after ? L + 1 + __builtin_ctzll(after) : nblk;
     const int nb = next - first;
     // (1) everything that depends on the block stream only: the lane's nine values and three x entries
+    // (scalars, not arrays: an array indexed in an unrolled loop cost this kernel 80 bytes of scratch per lane)
     const char * va = reinterpret_cast<const char *>(a + k0);
-    const unsigned o0 = (unsigned) (9 * first + 3 * (L - first)) * 8u, step = (unsigned) (3 * nb) * 8u;
-    const v2d_u8 p0 = *reinterpret_cast<const v2d_u8 *>(va + o0);
-    const double q0 = *reinterpret_cast<const double *>(va + o0 + 16);
-    const v2d_u8 p1 = *reinterpret_cast<const v2d_u8 *>(va + o0 + step);
-    const double q1 = *reinterpret_cast<const double *>(va + o0 + step + 16);
-    const v2d_u8 p2 = *reinterpret_cast<const v2d_u8 *>(va + o0 + 2 * step);
-    const double q2 = *reinterpret_cast<const double *>(va + o0 + 2 * step + 16);
-    const unsigned xo = 3u * (e & 0x7FFFu) * 8u;
+    unsigned mask = 0x1FFu;
+    unsigned b0, b1, b2; // byte offsets of the three rows' pieces
+    if (MASKED) {
+        mask = mine ? (e >> 16) & 0x1FFu : 0u;
+        // stored entries of this block per row, three 10-bit fields; their prefix sums say where the block's values lie
+        const int cnt = __builtin_popcount(mask & 7u) | (__builtin_popcount(mask & 0x38u) << 10) | (__builtin_popcount(mask & 0x1C0u) << 20);
+        const int incl = wave_inclusive_scan(cnt);
+        const int before_row = __builtin_amdgcn_ds_bpermute(first << 2, incl - cnt); // what lies in front of my block row
+        const int row_total = __builtin_amdgcn_ds_bpermute((next - 1) << 2, incl) - before_row; // my block row's three row lengths
+        const int mine_before = incl - cnt - before_row;                                  // ... and my place in each of them
+        const int base = (before_row & 0x3FF) + ((before_row >> 10) & 0x3FF) + ((before_row >> 20) & 0x3FF);
+        // (idle lanes: the tile's first entries -- their own offsets would point past the tile's end)
+        // three consecutive doubles per row whatever the mask says (a row's next block, or the next row, follows: the mark
+        // kernel makes sure two doubles past the tile's end are still inside the array); the mask picks below
+        b0 = mine ? (unsigned) (base + (mine_before & 0x3FF)) * 8u : 0u;
+        b1 = mine ? (unsigned) (base + (row_total & 0x3FF) + ((mine_before >> 10) & 0x3FF)) * 8u : 0u;
+        b2 = mine ? (unsigned) (base + (row_total & 0x3FF) + ((row_total >> 10) & 0x3FF) + ((mine_before >> 20) & 0x3FF)) * 8u : 0u;
+    } else {
+        const unsigned step = (unsigned) (3 * nb) * 8u;
+        b0 = (unsigned) (9 * first + 3 * (L - first)) * 8u;
+        b1 = b0 + step;
+        b2 = b1 + step;
+    }
+    const v2d_u8 p0 = *reinterpret_cast<const v2d_u8 *>(va + b0);
+    const double q0 = *reinterpret_cast<const double *>(va + b0 + 16);
+    const v2d_u8 p1 = *reinterpret_cast<const v2d_u8 *>(va + b1);
+    const double q1 = *reinterpret_cast<const double *>(va + b1 + 16);
+    const v2d_u8 p2 = *reinterpret_cast<const v2d_u8 *>(va + b2);
+    const double q2 = *reinterpret_cast<const double *>(va + b2 + 16);
+    const unsigned xo = MASKED ? (mine ? (e & 0xFFFFu) * 8u : 0u) : 3u * (e & 0x7FFFu) * 8u;
     const v2d_u8 x01 = *reinterpret_cast<const v2d_u8 *>(reinterpret_cast<const char *>(xt) + xo);
     const double x2 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xt) + xo + 16);
     // (2) the row lanes: LPR lanes per row, old y requested now
@@ -83,13 +149,30 @@ __device__ __forceinline__ void tile_rows_block3(
     const int rowc = row_lane ? row : nrows - 1;
     const double yv = y_in[r0 + rowc];
     // (3) the block's three partial sums, left to right
-    double s0 = p0.x * x01.x, s1 = p1.x * x01.x, s2 = p2.x * x01.x;
-    s0 += p0.y * x01.y;
-    s1 += p1.y * x01.y;
-    s2 += p2.y * x01.y;
-    s0 += q0 * x2;
-    s1 += q1 * x2;
-    s2 += q2 * x2;
+    double s0, s1, s2;
+    if (MASKED) {
+        // a row's stored entries are w0, w1, w2 in column order: column b holds the (number of stored columns in front of b)-th
+        // of them.  A product is formed only where an entry is stored (x may hold anything elsewhere).
+        auto masked_row = [&](unsigned m, double w0, double w1, double w2) {
+            const double c1 = (m & 1u) ? w1 : w0;
+            const double c2 = (m & 1u) ? ((m & 2u) ? w2 : w1) : ((m & 2u) ? w1 : w0);
+            double z = (m & 1u) ? w0 * x01.x : 0.0;
+            z += (m & 2u) ? c1 * x01.y : 0.0;
+            z += (m & 4u) ? c2 * x2 : 0.0;
+            return z;
+        };
+        s0 = masked_row(mask & 7u, p0.x, p0.y, q0);
+        s1 = masked_row((mask >> 3) & 7u, p1.x, p1.y, q1);
+        s2 = masked_row((mask >> 6) & 7u, p2.x, p2.y, q2);
+    } else {
+        s0 = p0.x * x01.x, s1 = p1.x * x01.x, s2 = p2.x * x01.x;
+        s0 += p0.y * x01.y;
+        s1 += p1.y * x01.y;
+        s2 += p2.y * x01.y;
+        s0 += q0 * x2;
+        s1 += q1 * x2;
+        s2 += q2 * x2;
+    }
     int * info = reinterpret_cast<int *>(lds + 3 * kWave);
     if (mine) {
         lds[lane] = s0;
@@ -116,14 +199,105 @@ __device__ __forceinline__ void tile_rows_block3(
         store(r0 + row, yv + z);
 }
 
+// The greedy cover of one block row (three rows whose columns, minus the tile's smallest, lie in `col` at [pr[a], er[a])): blocks
+// [c, c + 3) with c = the smallest column not covered yet (never beyond `limit`, so that three x entries can always be read),
+// one word each (see above) into `out` if given.  Returns the number of blocks; *ok = 0 for a row with descending columns or a
+// column twice, or when more than 64 blocks are needed.  One lane; always terminates (every round consumes its smallest column).
+__device__ __forceinline__ int block3_greedy_cover(const int * col, int (&pr)[3], const int (&er)[3], int limit, uint32_t * out, int * ok_out)
+{
+    int cnt = 0, ok = 1;
+    while (ok && (pr[0] < er[0] || pr[1] < er[1] || pr[2] < er[2])) {
+        int s = 0x7FFFFFFF;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (pr[a] < er[a])
+                s = min(s, col[pr[a]]);
+        s = min(s, limit);
+        unsigned mask = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int t = 0; t < 3 && pr[a] < er[a]; ++t) {
+                const int d = col[pr[a]] - s;
+                if (d > 2)
+                    break;
+                const unsigned bit = 1u << (3 * a + (d < 0 ? 0 : d));
+                if (d < 0 || (mask & bit))
+                    ok = 0; // descending columns, or a column twice
+                mask |= bit;
+                ++pr[a];
+            }
+        if (cnt >= kWave || s < 0)
+            ok = 0;
+        else if (out)
+            out[cnt] = (unsigned) s | (mask << 16) | (cnt == 0 ? kMaskedRowBegin : 0u);
+        ++cnt;
+    }
+    *ok_out = ok;
+    return cnt;
+}
+
+// Plan time: which rows belong to the same mesh node?  For a CANDIDATE matrix (rows of similar length, spmv_hip_plan_csr) one
+// thread per row compares row r with row r - 1: the same node if both are longer than 16 entries, their lengths within a
+// quarter, and their first and their last columns within 2 of each other (identical unless an explicit zero was dropped at
+// an end; two different nodes of a mesh differ by a whole node -- 3 columns -- at least at one end; the rows of a band or of a
+// stencil differ by 1 at both and form one endless group, i.e. no triples).  Bit r of `starts` = row r begins a group.
+static __global__ __launch_bounds__(256) void csr_row_group_kernel(
+    int rows, const int32_t * __restrict__ p, const int32_t * __restrict__ j, uint32_t * __restrict__ starts)
+{
+    const int r = (int) (blockIdx.x * 256 + threadIdx.x); // (the grid covers whole 64-row words: lanes past the end vote 0)
+    int start = 0;
+    if (r < rows) {
+        start = 1;
+        if (r > 0) {
+            const int a0 = p[r - 1], a1 = p[r], a2 = p[r + 1];
+            const int la = a1 - a0, lb = a2 - a1;
+            const int hi = la > lb ? la : lb, lo = la > lb ? lb : la;
+            if (lo > 16 && hi - lo <= hi / 4) {
+                const int fa = j[a0], fb = j[a1], ea = j[a1 - 1], eb = j[a2 - 1];
+                const int df = fa > fb ? fa - fb : fb - fa, de = ea > eb ? ea - eb : eb - ea;
+                if (df <= 2 && de <= 2)
+                    start = 0;
+            }
+        }
+    }
+    const unsigned long long vote = __ballot(start);
+    if ((threadIdx.x & 63) == 0 && r < rows) {
+        starts[r >> 5] = (uint32_t) vote; // (the words are allocated in pairs: 2 * ceil(rows / 64))
+        starts[(r >> 5) + 1] = (uint32_t) (vote >> 32);
+    }
+}
+
+// ... and how many groups are TRIPLES (a start, two rows that continue, a start -- or the end of the matrix -- behind them)
+__device__ __forceinline__ bool group_start_bit(const uint32_t * starts, int rows, int q)
+{
+    return q >= rows || ((starts[q >> 5] >> (q & 31)) & 1u);
+}
+static __global__ __launch_bounds__(256) void csr_row_triple_count_kernel(int rows, const uint32_t * __restrict__ starts, unsigned long long * __restrict__ count)
+{
+    const int q = (int) (blockIdx.x * 256 + threadIdx.x);
+    const bool triple = q + 3 <= rows && group_start_bit(starts, rows, q) && !group_start_bit(starts, rows, q + 1)
+        && !group_start_bit(starts, rows, q + 2) && group_start_bit(starts, rows, q + 3);
+    const unsigned long long vote = __ballot(triple);
+    if ((threadIdx.x & 63) == 0 && vote)
+        striped_add(count, 0, (unsigned long long) __builtin_popcountll(vote));
+}
+
 // Plan time, one wave per tile (spmv_hip_plan_csr_repack: the pass that has row_ptr on the device): a stream tile with
 // 16-bit columns, rows of more than 16 entries and 3, 6, ... kBlockTileMaxRows rows is checked ENTRY BY ENTRY for the block
-// structure described above; where it holds the tile's block stream is written and the tile marked.  count[0] += tiles,
-// count[1] += their entries, count[2], count[3]: the same for the tiles no block window has claimed.
+// structure described above; where it holds the tile's block stream is written and the tile marked.  A tile that is not made
+// of dense aligned blocks gets a second chance as a MASKED block tile: lane b walks the three rows of block row b through the
+// tile's columns (staged in LDS) and covers them greedily with blocks [c, c + 3), c = the smallest column not covered yet;
+// the tile is taken if that needs at most 64 blocks holding kMaskedMinFill entries on average.  Rows with a column twice or
+// with descending columns never qualify (a mask has one bit per place).
+// count[0] += tiles, count[1] += their entries, count[2], count[3]: the same for the tiles no block window has claimed;
+// count[4], count[5]: masked tiles among them and their entries.
 static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     int ntiles, int tile, int4 * __restrict__ desc, const int32_t * __restrict__ p, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ bstream, unsigned long long * __restrict__ count)
+    uint16_t * __restrict__ bstream, uint32_t * __restrict__ mstream, int nnz_total, int cols, int allow_masked,
+    unsigned long long * __restrict__ count)
 {
+    __shared__ int col_all[4][512];
+    __shared__ uint32_t word_all[4][kBlockTileMaxRows / 3][kWave];
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
     const int w = blockIdx.x * 4 + wave;
@@ -138,40 +312,40 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     // (tiles marked for a block window are checked too: where block tiles turn out to be the majority the plan drops the windows)
     const int other = kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | (1 << 21) /* balanced tiles */;
     if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || !(meta & kTileMetaNarrow) || (meta & other)
-        || nrows < 3 || nrows > kBlockTileMaxRows || nrows % 3 != 0 || n % 9 != 0 || n < 18 || n / 9 > kWave || k1 - (k0 & ~3) > tile)
+        || nrows < 3 || nrows > kBlockTileMaxRows || nrows % 3 != 0 || n < 18 || k1 - (k0 & ~3) > tile || tile > 512)
         return;
     const int cmin = d0.w;
     // row starts in lanes 0 .. nrows (nrows <= 30)
     const int ps = p[r0 + (lane <= nrows ? lane : nrows)];
     const int len = __shfl_down(ps, 1) - ps; // lanes < nrows
+    if (!__all(lane >= nrows || len > 16))
+        return; // rows of up to 16 entries keep their one-lane-per-row, bit-exact path
     const int len0 = __shfl(len, lane - lane % 3);
-    int ok = lane >= nrows || (len == len0 && len % 3 == 0 && len > 16);
-    ok = __all(ok);
-    if (!ok)
-        return;
-    // row by row (the row number is wave-uniform: its bounds come out of lane r with a readlane, not a shuffle per entry --
-    // the first version looked every entry's row up with a loop of shuffles: 38.8 ms for the queen-like matrix's 808 K tiles)
-    for (int r = 0; r < nrows; ++r) {
-        const int start = __shfl(ps, r), rl = __shfl(len, r), a = r % 3;
-        for (int k = start + lane; k < start + rl; k += kWave) {
-            const int pos = k - start;
-            const int c = j[k];
-            int good = 1;
-            if (a != 0)
-                good &= c == j[k - a * rl];
-            if (pos % 3 != 0)
-                good &= c == j[k - 1] + 1;
-            else
-                good &= (c - cmin) % 3 == 0 && (c - cmin) / 3 < 0x8000;
-            ok &= good;
+    int dense = n % 9 == 0 && n / 9 <= kWave && __all(lane >= nrows || (len == len0 && len % 3 == 0));
+    if (dense) {
+        // row by row (the row number is wave-uniform: its bounds come out of lane r with a readlane, not a shuffle per entry --
+        // the first version looked every entry's row up with a loop of shuffles: 38.8 ms for the queen-like matrix's 808 K tiles)
+        int ok = 1;
+        for (int r = 0; r < nrows; ++r) {
+            const int start = __shfl(ps, r), rl = __shfl(len, r), a = r % 3;
+            for (int k = start + lane; k < start + rl; k += kWave) {
+                const int pos = k - start;
+                const int c = j[k];
+                int good = 1;
+                if (a != 0)
+                    good &= c == j[k - a * rl];
+                if (pos % 3 != 0)
+                    good &= c == j[k - 1] + 1;
+                else
+                    good &= (c - cmin) % 3 == 0 && (c - cmin) / 3 < 0x8000;
+                ok &= good;
+            }
         }
+        dense = __all(ok);
     }
-    ok = __all(ok);
-    if (!ok)
-        return;
-    // the block stream: lane = block, block rows one after the other
-    const int nblk = n / 9;
-    {
+    if (dense) {
+        // the block stream: lane = block, block rows one after the other
+        const int nblk = n / 9;
         int cum = 0, entry = k0, begin = 0;
         for (int r = 0; r < nrows; r += 3) {
             const int nb = __shfl(len, r) / 3, st = __shfl(ps, r);
@@ -183,14 +357,66 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
         }
         if (lane < nblk)
             bstream[block_stream_index(k0) + lane] = (uint16_t) (((j[entry] - cmin) / 3) | (begin ? kBlockRowBegin : 0u));
+    } else {
+        // ---- masked blocks -------------------------------------------------------------------------------------------
+        // (two doubles past the tile's end must be inside the value array: the multiply reads three per row and block)
+        const int limit = cols - 3 - cmin; // the last place a block may start
+        if (!allow_masked || (long long) k1 + 2 > (long long) nnz_total || limit < 0 || n > 512)
+            return;
+        int * col = col_all[wave];
+        for (int k = k0 + lane; k < k1; k += kWave)
+            col[k - k0] = j[k] - cmin;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nbr = nrows / 3;
+        const int b = lane < nbr ? lane : nbr - 1;
+        int pr[3], er[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            pr[a] = __shfl(ps, 3 * b + a) - k0;
+            er[a] = __shfl(ps, 3 * b + a + 1) - k0;
+        }
+        int cnt = 0, ok = 1;
+        if (lane < nbr)
+            cnt = block3_greedy_cover(col, pr, er, limit, word_all[wave][lane], &ok);
+        if (!__all(ok))
+            return;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { // nbr <= 10
+            const int up = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += up;
+        }
+        const int total = __shfl(incl, nbr - 1);
+        if (total > kWave || total * kMaskedMinFill > n)
+            return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t word = 0;
+        for (int q = 0; q < nbr; ++q) {
+            const int e1 = __shfl(incl, q), c1 = __shfl(cnt, q);
+            if (lane >= e1 - c1 && lane < e1)
+                word = word_all[wave][q][lane - (e1 - c1)];
+        }
+        if (lane == 0)
+            word |= (unsigned) (total - 1) << 25;
+        if (lane < total)
+            mstream[mask_stream_index(k0) + lane] = word;
     }
     if (lane == 0) {
-        desc[w].z = meta | kTileMetaBlock3;
+        desc[w].z = meta | kTileMetaBlock3 | (dense ? 0 : kTileMetaBlock3Masked);
         striped_add(count, 0, 1ull);
         striped_add(count, 1, (unsigned long long) n);
         if (!(meta & kTileMetaBlockWin)) {
             striped_add(count, 2, 1ull);
             striped_add(count, 3, (unsigned long long) n);
+        }
+        if (!dense) {
+            striped_add(count, 4, 1ull);
+            striped_add(count, 5, (unsigned long long) n);
         }
     }
 }

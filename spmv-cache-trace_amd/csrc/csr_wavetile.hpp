@@ -700,8 +700,12 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
         }
         if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !exact_order) {
             // dense 3 x 3 blocks (csr_blocktile.hpp): one 16-bit number per block instead of a column per entry, no row_ptr
-            tile_rows_block3(prod, j16 + block_stream_offset(nnz_total) + block_stream_index(k0), a, x + cbase, y_in, r0, k0, k1, nrows, lane,
-                             [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+            if (meta & kTileMetaBlock3Masked) // blocks with entries missing, off the grid of column triples: a 32-bit word per block
+                tile_rows_block3<true>(prod, reinterpret_cast<const uint32_t *>(j16 + mask_stream_offset(nnz_total)) + mask_stream_index(k0), a,
+                                       x + cbase, y_in, r0, k0, k1, nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+            else
+                tile_rows_block3<false>(prod, j16 + block_stream_offset(nnz_total) + block_stream_index(k0), a, x + cbase, y_in, r0, k0, k1, nrows,
+                                        lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
             return;
         }
         // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row

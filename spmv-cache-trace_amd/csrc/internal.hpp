@@ -51,7 +51,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MULTI_WINDOW
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MULTI_WINDOW | SPMV_HIP_FLAG_NO_MASKED_BLOCKS
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
     | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_ROW_GROUPS // kernel families that were measured SLOWER than the default path (below)
@@ -134,10 +134,15 @@ struct spmv_hip_plan {
     int multi_window_tiles = 0; // tiles of several long rows walked in windows of 512 entries
     int block_hint = 0;
     int block_offset = 0; // the row (0, 1 or 2) at which the grid of triples starts
+    int block_candidate = 0; // rows in triples of merely similar length: repack samples the columns before it believes in blocks
+    const uint32_t * group_bits = nullptr; // ... and has confirmed them: bit r = row r begins a group of rows with the same columns
+                                           // (host memory, alive only while repack cuts the tiles once more)
     int block_cuts = 0; // tiles the hint made shorter (0: the tiling is what it would have been without the hint)
     int break_rows = 0; // (what the tiles were built with: a rebuild needs them again)
     int block_tiles = 0;
     long long block_entries = 0;
+    int masked_block_tiles = 0; // ... of which: blocks with entries missing or off the grid of column triples (a 32-bit word per block)
+    long long masked_block_entries = 0;
     size_t meta_bytes = 0;
     // what one multiply streams with the tile classes chosen (plan_account): roofline bookkeeping
     long long streamed_bytes = 0, shifted_entries = 0, narrow_entries = 0, uniform_rows = 0;

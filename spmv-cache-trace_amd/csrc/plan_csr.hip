@@ -162,9 +162,9 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         const bool uniform = stream_tile && (meta & spmv::kTileMetaUniform);
         const bool block3 = compressed && stream_tile && (meta & spmv::kTileMetaBlock3) && !(meta & spmv::kTileMetaBlockWin) && pl->nvalues == 0
             && !(pl->flags & SPMV_HIP_FLAG_EXACT_ORDER);
-        if (block3) { // one 16-bit number per 3 x 3 block, no row_ptr
+        if (block3) { // one 16-bit number per 3 x 3 block (masked block tiles: a 32-bit word per block, about one per 8 entries), no row_ptr
             pl->narrow_entries += entries;
-            bytes += 8 * entries + 2 * (entries / 9) + 16 + 16 * rows;
+            bytes += 8 * entries + ((meta & spmv::kTileMetaBlock3Masked) ? 4 * ((entries + 7) / 8) : 2 * (entries / 9)) + 16 + 16 * rows;
             continue;
         }
         long long col_bytes = 4 * entries;
@@ -318,23 +318,57 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     // columns of every tile before it marks it.
     // (The triples need not start at row 0: a rank's row block of a partitioned matrix starts wherever ceil(rows / G) puts it, so
     // the three possible offsets are tried and the tiles cut on THAT grid.)
-    pl->block_hint = 0;
-    pl->block_offset = 0;
-    if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
-        for (int o = 0; o < 3 && !pl->block_hint; ++o) {
-            // (an offset is given up as soon as a fifth of all triples have failed: a matrix without blocks -- most -- pays for a
-            // fifth of one pass per offset, not for three passes over row_ptr)
-            const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
-            long long good = 0, bad = 0;
-            for (int32_t q = o; q + 2 < rows && bad <= allowed_bad; q += 3) {
-                const int l0 = p[q + 1] - p[q];
-                const bool ok = l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
-                good += ok;
-                bad += !ok;
+    // Real files are less tidy: explicit zeros dropped from some blocks make the rows of a triple differ in length, nothing
+    // obliges a row length to be divisible by 3, and a node with one or two unknowns moves the grid of triples behind it.  A
+    // matrix most of whose rows are longer than 16 entries and about as long as the row behind them is therefore remembered as
+    // a CANDIDATE: its tiles are cut without the hint, and spmv_hip_plan_csr_repack -- which sees the columns -- works out
+    // which rows belong to the same node (csr_row_group_kernel); only if half of the rows then stand in groups of three does
+    // it cut the tiles once more, on the boundaries of those groups (pl->group_bits), for the masked block tiles of
+    // csr_blocktile.hpp.  A matrix that merely has rows of similar length pays for that one pass over row_ptr, nothing else.
+    auto similar_triple = [p, rows](int32_t q) {
+        if (q < 0 || q + 3 > rows)
+            return false;
+        const int l0 = p[q + 1] - p[q], l1 = p[q + 2] - p[q + 1], l2 = p[q + 3] - p[q + 2];
+        const int lo = std::min(l0, std::min(l1, l2)), hi = std::max(l0, std::max(l1, l2));
+        return lo > 16 && hi - lo <= hi / 4;
+    };
+    const uint32_t * const gb = pl->group_bits; // bit r: row r begins a group of rows with the same columns (repack's second cut only)
+    auto group_start = [gb, rows](int32_t q) { return q >= rows || ((gb[q >> 5] >> (q & 31)) & 1u) != 0; };
+    auto triple_at = [&](int32_t q) { return q + 3 <= rows && group_start(q) && !group_start(q + 1) && !group_start(q + 2) && group_start(q + 3); };
+    pl->block_candidate = 0;
+    if (gb) {
+        pl->block_hint = 3;
+        pl->block_offset = 0;
+    } else {
+        pl->block_hint = 0;
+        pl->block_offset = 0;
+        if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
+            for (int o = 0; o < 3 && !pl->block_hint; ++o) {
+                // (an offset is given up as soon as a fifth of all triples have failed: a matrix without blocks -- most -- pays for a
+                // fifth of one pass per offset, not for three passes over row_ptr)
+                const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
+                long long good = 0, bad = 0;
+                for (int32_t q = o; q + 2 < rows && bad <= allowed_bad; q += 3) {
+                    const int l0 = p[q + 1] - p[q];
+                    const bool ok = l0 > 16 && l0 % 3 == 0 && p[q + 2] - p[q + 1] == l0 && p[q + 3] - p[q + 2] == l0;
+                    good += ok;
+                    bad += !ok;
+                }
+                if (bad <= allowed_bad && good * 5 >= triples * 4) {
+                    pl->block_hint = 3;
+                    pl->block_offset = o;
+                }
             }
-            if (bad <= allowed_bad && good * 5 >= triples * 4) {
-                pl->block_hint = 3;
-                pl->block_offset = o;
+            if (!pl->block_hint && !(flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS)) {
+                // (given up as soon as two fifths of the rows have failed)
+                const long long allowed_bad = 2LL * rows / 5;
+                long long bad = 0;
+                for (int32_t q = 0; q + 1 < rows && bad <= allowed_bad; ++q) {
+                    const int l0 = p[q + 1] - p[q], l1 = p[q + 2] - p[q + 1];
+                    const int lo = std::min(l0, l1), hi = std::max(l0, l1);
+                    bad += !(lo > 16 && hi - lo <= hi / 4);
+                }
+                pl->block_candidate = bad <= allowed_bad ? 1 : 0;
             }
         }
     }
@@ -352,7 +386,31 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     std::vector<int4> & desc = o.desc;
     desc.reserve((size_t) (ce - cb) / 48 + 16);
     int32_t r = cb;
+    // With repack's groups (gb): a tile of long rows starts on a triple and holds whole triples only; rows of other groups (a node
+    // with one or two unknowns, a boundary row) get tiles of their own up to the next triple.  With the hint from row_ptr alone:
+    // the grid of triples at pl->block_offset, followed locally where the row lengths show that it moved.
+    int phase = pl->block_offset;
     while (r < ce) {
+        int32_t row_limit = ce;
+        bool triples_only = false;
+        if (gb) {
+            if (triple_at(r)) {
+                triples_only = true;
+                phase = r % 3;
+            } else {
+                int32_t q = r + 1;
+                while (q < ce && q - r < 128 && !triple_at(q))
+                    ++q;
+                row_limit = q;
+            }
+        } else if (pl->block_hint && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !similar_triple(r)) {
+            for (int d = 1; d <= 2; ++d)
+                if (similar_triple(r + d) && similar_triple(r + d + 3)) {
+                    phase = (r + d) % 3;
+                    row_limit = r + d;
+                    break;
+                }
+        }
         if (break_rows > 0) // the first tile of each panel (tiles never straddle a panel boundary)
             while (next_panel <= 8 && next_panel <= r / break_rows)
                 pl->pinfo.first[next_panel++] = (int) desc.size();
@@ -374,8 +432,10 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                 ++l;
             return l;
         };
-        while (r1 < ce && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
+        while (r1 < row_limit && (r1 - r) < row_cap && (long long) p[r1 + 1] - kb <= tile) {
             if (break_rows > 0 && r1 > r && r1 % break_rows == 0)
+                break;
+            if (triples_only && r1 > r && (r1 - r) % 3 == 0 && !triple_at(r1))
                 break;
             const int len = p[r1 + 1] - p[r1];
             o.longest = std::max(o.longest, len);
@@ -409,7 +469,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
             int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows);
             if (cut < ce)
-                cut -= ((cut - pl->block_offset) % 3 + 3) % 3;
+                cut -= ((cut - phase) % 3 + 3) % 3;
             if (cut > r && cut < r1) {
                 o.block_cuts++;
                 r1 = cut;
@@ -449,7 +509,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             // run at 0.85, profiles/r04_ell_long_rows.md)
             double best_fill = r1 - r >= 2 ? std::max(plain + 0.1, 0.75) : 0.75;
             int mx = 0;
-            for (int32_t q = r; q < ce && q - r < 8; ++q) {
+            for (int32_t q = r; q < row_limit && q - r < 8; ++q) {
                 mx = std::max(mx, p[q + 1] - p[q]);
                 if (mx > kMultiWindowMaxRow)
                     break;
@@ -909,7 +969,8 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
         return fail(SPMV_HIP_ERR_STATE, "plan is already compressed");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // (with a block hint the block stream of csr_blocktile.hpp lives behind the 16-bit columns, in the same allocation)
-    const size_t bytes = pl->block_hint ? (spmv::block_stream_offset(pl->nnz) + (size_t) pl->nnz / 9 + 128) * sizeof(uint16_t)
+    // (... and behind that the 32-bit words of the masked block tiles)
+    const size_t bytes = pl->block_hint ? spmv::mask_stream_offset(pl->nnz) * sizeof(uint16_t) + spmv::mask_stream_words(pl->nnz) * sizeof(uint32_t)
                                         : (size_t) pl->nnz * sizeof(uint16_t) + 64;
     const bool want_patterns = !(pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES);
     int * d_count = nullptr;
@@ -1139,24 +1200,108 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     return rc;
 }
 
+// The tiles of a compressed plan cut once more from row_ptr fetched back from the device, and classified again (plan time only):
+// without the block hint (it was wrong and cost tile fill), or on the grid of triples a candidate matrix turned out to have.
+static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, void * stream,
+                         const uint32_t * group_bits /* null: without block tiles */, const double ** reindex)
+{
+    const bool with_blocks = group_bits != nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<int32_t> hp((size_t) pl->rows + 1);
+    HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // the dictionary's tile list (d_tiles_vi) and its constant-row marks number the OLD tiles and patterns
+    if (pl->values_from)
+        *reindex = pl->values_from;
+    drop_value_dictionary(pl);
+    for (void * q : {(void *) pl->d_tiles, (void *) pl->d_col16, (void *) pl->d_patterns, (void *) pl->d_blocks, (void *) pl->d_segblocks,
+                     (void *) pl->d_rest_tiles})
+        if (q)
+            (void) hipFree(q);
+    pl->d_tiles = nullptr; pl->d_col16 = nullptr; pl->d_patterns = nullptr; pl->d_blocks = nullptr; pl->d_segblocks = nullptr;
+    pl->d_rest_tiles = nullptr;
+    pl->ntiles = pl->nblk = pl->workgroups = 0;
+    pl->narrow_tiles = pl->shifted_tiles = pl->xwin_tiles = pl->longest_tile_row = pl->spread_tiles = 0;
+    pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
+    pl->uniform_tiles = pl->split_rows = pl->long_blocks = pl->multi_window_tiles = 0;
+    pl->balanced = false;
+    pl->block_hint = pl->block_cuts = pl->block_tiles = pl->masked_block_tiles = pl->block_candidate = 0;
+    pl->block_entries = pl->masked_block_entries = 0;
+    pl->meta_bytes = 0;
+    pl->compressed_from = nullptr;
+    if (!with_blocks)
+        pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
+    pl->group_bits = group_bits;
+    int rc = build_wave_tiles(pl, hp.data(), pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
+    pl->group_bits = nullptr;
+    if (rc == SPMV_HIP_OK)
+        rc = plan_account(pl, false);
+    if (rc == SPMV_HIP_OK)
+        rc = spmv_hip_plan_csr_compress(pl, d_column_index, stream);
+    return rc;
+}
+
 static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, const double * d_value,
                          void * stream, const double ** reindex)
 {
+    // a CANDIDATE for block tiles (rows of similar length, spmv_hip_plan_csr): which rows have the same columns as the row in
+    // front of them?  If half of the rows stand in groups of three the tiles are cut again on those groups, and the block stage
+    // below marks them
+    if (pl->block_candidate && !pl->block_hint && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
+        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0 && pl->rows >= 192
+        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS))) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        pl->block_candidate = 0; // asked once
+        const size_t words = 2 * (((size_t) pl->rows + 63) / 64);
+        uint32_t * d_bits = nullptr;
+        unsigned long long * d_count = nullptr;
+        unsigned long long triples[1] = {0};
+        HIP_TRY(hipMalloc((void **) &d_bits, words * sizeof(uint32_t)));
+        hipError_t e = hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
+        if (e == hipSuccess) {
+            const unsigned grid = (unsigned) (((size_t) pl->rows + 255) / 256);
+            hipLaunchKernelGGL(spmv::csr_row_group_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_row_ptr, d_column_index, d_bits);
+            hipLaunchKernelGGL(spmv::csr_row_triple_count_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_bits, d_count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = read_striped(d_count, triples, 1, s);
+        std::vector<uint32_t> bits;
+        const bool confirmed = e == hipSuccess && 6 * triples[0] >= (unsigned long long) pl->rows; // half of the rows in triples
+        if (confirmed) {
+            bits.resize(words);
+            e = hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+        (void) hipFree(d_bits);
+        if (d_count) (void) hipFree(d_count);
+        if (e != hipSuccess)
+            return fail_hip(e, "row groups");
+        if (confirmed) {
+            int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, bits.data(), reindex);
+            if (rc != SPMV_HIP_OK)
+                return rc;
+        }
+    }
     // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
     if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
         && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
         && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES))) {
         hipStream_t s = static_cast<hipStream_t>(stream);
         unsigned long long * d_count = nullptr;
-        unsigned long long count[4] = {0, 0, 0, 0};
+        unsigned long long count[6] = {0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
         hipError_t e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
-                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count);
+                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),
+                               reinterpret_cast<uint32_t *>(pl->d_col16 + spmv::mask_stream_offset(pl->nnz)), pl->nnz, pl->cols,
+                               (pl->flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS) ? 0 : 1, d_count);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = read_striped(d_count, count, 4, s);
+        if (e == hipSuccess) e = read_striped(d_count, count, 6, s);
+        pl->masked_block_tiles = (int) count[4];
+        pl->masked_block_entries = (long long) count[5];
         (void) hipFree(d_count);
         if (e != hipSuccess)
             return fail_hip(e, "block tiles");
@@ -1185,33 +1330,7 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             // The hint was wrong (rows in equal triples, but no 3 x 3 blocks: a scalar mesh, a band) AND it made tiles shorter
             // than they would have been: the tiles are built once more without it, from row_ptr fetched back from the device,
             // and classified again -- plan time only, and only for such matrices.
-            std::vector<int32_t> hp((size_t) pl->rows + 1);
-            HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            // the dictionary's tile list (d_tiles_vi) and its constant-row marks number the OLD tiles and patterns
-            *reindex = pl->values_from;
-            drop_value_dictionary(pl);
-            for (void * q : {(void *) pl->d_tiles, (void *) pl->d_col16, (void *) pl->d_patterns, (void *) pl->d_blocks, (void *) pl->d_segblocks,
-                             (void *) pl->d_rest_tiles})
-                if (q)
-                    (void) hipFree(q);
-            pl->d_tiles = nullptr; pl->d_col16 = nullptr; pl->d_patterns = nullptr; pl->d_blocks = nullptr; pl->d_segblocks = nullptr;
-            pl->d_rest_tiles = nullptr;
-            pl->ntiles = pl->nblk = pl->workgroups = 0;
-            pl->narrow_tiles = pl->shifted_tiles = pl->xwin_tiles = pl->longest_tile_row = pl->spread_tiles = 0;
-            pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
-            pl->uniform_tiles = pl->split_rows = pl->long_blocks = pl->multi_window_tiles = 0;
-            pl->balanced = false;
-            pl->block_hint = pl->block_cuts = pl->block_tiles = 0;
-            pl->block_entries = 0;
-            pl->meta_bytes = 0;
-            pl->compressed_from = nullptr;
-            pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
-            int rc = build_wave_tiles(pl, hp.data(), pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
-            if (rc == SPMV_HIP_OK)
-                rc = plan_account(pl, false);
-            if (rc == SPMV_HIP_OK)
-                rc = spmv_hip_plan_csr_compress(pl, d_column_index, stream);
+            int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, nullptr, reindex);
             if (rc != SPMV_HIP_OK)
                 return rc;
         } else if (pl->block_tiles > 0) {
@@ -1570,7 +1689,7 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[31] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[33] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
@@ -1578,8 +1697,8 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
                            pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles,
-                           pl->ngroup_tiles};
-    for (int i = 0; i < n && i < 31; ++i)
+                           pl->ngroup_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_entries};
+    for (int i = 0; i < n && i < 33; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -172,6 +172,10 @@ std::vector<int> find_new_order_GP(Matrix const & m, int nparts, std::ostream & 
                 adjacency[fill[(std::size_t) ci[k] - 1]++] = ri[k] - 1;
             }
     }
+    // (always on the log, not only when verbose -- ADVICE r04: a "__GP<n>" order from this build must not be mistaken for a METIS
+    // ordering; a reference build without METIS prints its own warning here and leaves the order unchanged)
+    log << "Warning: METIS is not part of this build: '__GP" << nparts << "' orders the rows with the partitioner 'greedy-bfs-kway' "
+           "(parts grown breadth-first), not with METIS_PartGraphKway\n";
     if (verbose)
         log << "Number of rows=" << n << " columns=" << m.columns() << " entries=" << ri.size() << '\n'
             << "Growing " << nparts << " parts breadth-first (this build's stand-in for METIS_PartGraphKway)\n";

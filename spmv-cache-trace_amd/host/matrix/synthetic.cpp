@@ -222,18 +222,43 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
 }
 
 // ---- queen: 3 unknowns per node of a jittered mesh, symmetric structure, dense 3x3 blocks ------------
-csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total, long long jitter_nodes = 3)
+// The less tidy twins (round 5; what real finite-element files do): `broken` per mille of the off-diagonal 3 x 3 blocks have one
+// or two of their nine entries missing (explicit zeros the assembly dropped), and with `odd_every` = K > 0 every K-th node has
+// only one or two unknowns (a constraint node, a pressure node), which moves the grid of row and column triples behind it.
+csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total, long long jitter_nodes = 3,
+                         long long broken = 0, long long odd_every = 0)
 {
     if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
         throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
     if (jitter_nodes < 3 || jitter_nodes > 4096)
         throw matrix::matrix_error("synthetic:queen:gx,gy,gz,<J>: a jittered link ends J nodes away, 3 <= J <= 4096");
+    if (broken < 0 || broken > 1000 || odd_every < 0 || odd_every == 1)
+        throw matrix::matrix_error("synthetic:queen:gx,gy,gz,J,<broken per mille>,<odd node every K>: 0 <= broken <= 1000, K = 0 or K >= 2");
     long long const nodes = gx * gy * gz;
-    long long const N = 3 * nodes;
+    std::uint64_t const seedJ = 0x51DE, seedQ = 0x0EE2, seedB = 0xB20CE, seedO = 0x0DD;
+    // unknowns per node and the first row (= column) of every node
+    auto dofs = [=](long long n) -> int {
+        if (odd_every == 0 || n % odd_every != odd_every / 2)
+            return 3;
+        return 1 + (int) (h2(seedO, (std::uint64_t) n) & 1);
+    };
+    std::vector<long long> first_row;
+    if (odd_every > 0) {
+        first_row.resize((std::size_t) nodes + 1);
+        first_row[0] = 0;
+        for (long long n = 0; n < nodes; ++n)
+            first_row[(std::size_t) n + 1] = first_row[(std::size_t) n] + dofs(n);
+    }
+    auto row0 = [&](long long n) { return odd_every > 0 ? first_row[(std::size_t) n] : 3 * n; };
+    long long const N = row0(nodes);
     if (total) *total = N;
     if (re < 0) re = N;
+    auto node_of = [&](long long r) {
+        if (odd_every == 0)
+            return r / 3;
+        return (long long) (std::upper_bound(first_row.begin(), first_row.end(), r) - first_row.begin()) - 1;
+    };
     long long const J = jitter_nodes; // a jittered link's far end is moved by J nodes (3 by default; more = the pessimistic twin)
-    std::uint64_t const seedJ = 0x51DE, seedQ = 0x0EE2;
     // the 13 "forward" neighbour offsets (x fastest); the other 13 are their mirror images
     int fd[13][3];
     long long foff[13];
@@ -279,6 +304,18 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
         std::sort(out, out + c);
         return (int) (std::unique(out, out + c) - out);
     };
+    // entries of block (n, m) that are NOT stored: bit 3 a + b; only off-diagonal blocks of two full nodes are ever broken
+    auto dropped = [=](long long n, long long m) -> unsigned {
+        if (broken == 0 || n == m)
+            return 0u;
+        std::uint64_t const h = h2(h2(seedB, (std::uint64_t) n), (std::uint64_t) m);
+        if ((long long) (h % 1000) >= broken)
+            return 0u;
+        unsigned mask = 1u << ((h >> 10) % 9);
+        if ((h >> 20) & 1)
+            mask |= 1u << ((h >> 24) % 9);
+        return mask;
+    };
     // node graph first (150 MB at full size), then the rows asked for
     std::vector<long long> node_ptr((std::size_t) nodes + 1, 0);
 #pragma omp parallel for schedule(static)
@@ -296,14 +333,32 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
         for (int i = 0; i < c; ++i)
             nbr[(std::size_t) node_ptr[(std::size_t) n] + i] = (index_type) tmp[i];
     }
-    auto len = [&](long long r) { return 3 * (node_ptr[(std::size_t) (r / 3) + 1] - node_ptr[(std::size_t) (r / 3)]); };
+    bool const plain = broken == 0 && odd_every == 0;
+    auto len = [&](long long r) -> long long {
+        long long const n = node_of(r);
+        if (plain)
+            return 3 * (node_ptr[(std::size_t) n + 1] - node_ptr[(std::size_t) n]);
+        int const a = (int) (r - row0(n));
+        long long c = 0;
+        for (long long q = node_ptr[(std::size_t) n]; q < node_ptr[(std::size_t) n + 1]; ++q) {
+            long long const m = nbr[(std::size_t) q];
+            unsigned const gone = dropped(n, m) >> (3 * a);
+            for (int b = 0; b < dofs(m); ++b)
+                c += !((gone >> b) & 1u);
+        }
+        return c;
+    };
     auto fill = [&](long long r, index_type * col, double * val) {
-        long long const n = r / 3;
-        int const a = (int) (r % 3);
+        long long const n = node_of(r);
+        int const a = (int) (r - row0(n));
         for (long long q = node_ptr[(std::size_t) n]; q < node_ptr[(std::size_t) n + 1]; ++q) {
             long long const m = nbr[(std::size_t) q];
             std::uint64_t const edge = h2(h2(seedQ, (std::uint64_t) std::min(n, m)), (std::uint64_t) std::max(n, m));
-            for (int b = 0; b < 3; ++b) {
+            unsigned const gone = plain ? 0u : dropped(n, m) >> (3 * a);
+            int const mb = plain ? 3 : dofs(m);
+            for (int b = 0; b < mb; ++b) {
+                if ((gone >> b) & 1u)
+                    continue;
                 // block(lo, hi)[a][b]; the mirrored block is its transpose, the diagonal block symmetric
                 int const ia = n < m ? a : b, ib = n < m ? b : a;
                 double v;
@@ -314,7 +369,7 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
                 } else {
                     v = u11(h2(edge, (std::uint64_t) (ia * 3 + ib)));
                 }
-                *col++ = (index_type) (3 * m + b);
+                *col++ = (index_type) (row0(m) + b);
                 *val++ = v;
             }
         }
@@ -585,13 +640,13 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
         check_range(2 * n * n * n + 6 * n * n);
         A = kkt(n, rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "queen") {
-        if (!v.empty() && v.size() != 3 && v.size() != 4)
-            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz[,J]] takes three or four numbers");
+        if (!v.empty() && (v.size() < 3 || v.size() > 6))
+            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz[,J[,broken per mille[,odd node every K]]]] takes three to six numbers");
         long long const gx = v.empty() ? 110 : v[0], gy = v.empty() ? 71 : v[1], gz = v.empty() ? 177 : v[2];
         if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
             throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
         check_range(3 * gx * gy * gz);
-        A = queen(gx, gy, gz, rb, re, &tot, v.size() > 3 ? v[3] : 3);
+        A = queen(gx, gy, gz, rb, re, &tot, v.size() > 3 ? v[3] : 3, v.size() > 4 ? v[4] : 0, v.size() > 5 ? v[5] : 0);
     } else if (family == "webbase" || family == "powerlaw") {
         bool const web = family == "webbase";
         if (v.size() > (web ? 4u : 3u))

@@ -37,6 +37,7 @@ FLAG_FUSED_PEER_STORE = 0x1000000
 FLAG_NO_BLOCK_TILES = 0x2000000
 FLAG_HUB_COLUMNS = 0x4000000  # libspmv_hip_experiments.so only (retired from the product: csrc/internal.hpp)
 FLAG_NO_MULTI_WINDOW = 0x8000000
+FLAG_NO_MASKED_BLOCKS = 0x20000000
 FLAG_ROW_GROUPS = 0x10000000  # libspmv_hip_experiments.so only (retired from the product: csrc/internal.hpp)
 CSR_ALGORITHM_NAMES = {1: "scalar", 2: "vector", 3: "adaptive", 4: "wavetile"}
 
@@ -311,12 +312,13 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(31, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 31))
+        out = np.zeros(33, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 33))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
                 "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
-                "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles"]
+                "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles",
+                "masked_block_tiles", "masked_block_entries"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

@@ -127,10 +127,22 @@ def test_broken_tiles_fall_back_alone(oracle):
         else:
             q = int(p[r])
             c2[q:q + 3] = c2[q + 3:q + 6]  # first block repeats the second one's columns in this row only
-        got, info = run_plan(rows, cols, p, c2, v, x, y0)
+        # (round 4's rule, SPMV_HIP_FLAG_NO_MASKED_BLOCKS: any damage demotes the tile)
+        got, info = run_plan(rows, cols, p, c2, v, x, y0, flags=capi.FLAG_NO_MASKED_BLOCKS)
         assert clean["block_tiles"] - 2 <= info["block_tiles"] < clean["block_tiles"], (what, clean["block_tiles"], info["block_tiles"])
+        assert info["masked_block_tiles"] == 0
         damaged += 1
-        assert_close(got, oracle.csr_spmv(rows, p, c2, v, x, y=y0, num_threads=4), abs_products(rows, p, c2, v, x) + np.abs(y0), what=what)
+        want2 = oracle.csr_spmv(rows, p, c2, v, x, y=y0, num_threads=4)
+        assert_close(got, want2, abs_products(rows, p, c2, v, x) + np.abs(y0), what=what)
+        # default (round 5): a block off the grid is still a block -- the tile becomes a MASKED block tile; so does the row that
+        # repeats a block's columns (the greedy cover simply opens the same block twice: every entry still meets its own x);
+        # a column twice INSIDE one block cannot be expressed by a mask: that tile falls back as before
+        got, info = run_plan(rows, cols, p, c2, v, x, y0)
+        if what == "column moved":
+            assert clean["block_tiles"] - 2 <= info["block_tiles"] < clean["block_tiles"] and info["masked_block_tiles"] == 0, (what, clean, info)
+        else:
+            assert info["block_tiles"] == clean["block_tiles"] and 1 <= info["masked_block_tiles"] <= 2, (what, clean, info)
+        assert_close(got, want2, abs_products(rows, p, c2, v, x) + np.abs(y0), what=what + " (masked allowed)")
     assert damaged == 3
     # a triple whose rows differ in LENGTH: the hint survives (one triple in 6000), the tile does not qualify
     lens = np.diff(p).astype(np.int64)
@@ -142,10 +154,15 @@ def test_broken_tiles_fall_back_alone(oracle):
     np.cumsum(lens, out=p3[1:])
     p3 = p3.astype(np.int32)
     c3, v3 = c[keep], v[keep]
-    got, info = run_plan(rows, cols, p3, c3, v3, x, y0)
+    got, info = run_plan(rows, cols, p3, c3, v3, x, y0, flags=capi.FLAG_NO_MASKED_BLOCKS)
     assert info["block_tiles"] > 0.9 * clean["block_tiles"], (clean, info)
     assert info["row_blocks"] - info["block_tiles"] > clean["row_blocks"] - clean["block_tiles"], (clean, info)
-    assert_close(got, oracle.csr_spmv(rows, p3, c3, v3, x, y=y0, num_threads=4), abs_products(rows, p3, c3, v3, x) + np.abs(y0), what="ragged triple")
+    want3 = oracle.csr_spmv(rows, p3, c3, v3, x, y=y0, num_threads=4)
+    assert_close(got, want3, abs_products(rows, p3, c3, v3, x) + np.abs(y0), what="ragged triple")
+    # ... and by default that tile is a masked block tile (the third row's mask lacks one block)
+    got, info = run_plan(rows, cols, p3, c3, v3, x, y0)
+    assert info["masked_block_tiles"] >= 1 and info["row_blocks"] - info["block_tiles"] <= clean["row_blocks"] - clean["block_tiles"] + 1, (clean, info)
+    assert_close(got, want3, abs_products(rows, p3, c3, v3, x) + np.abs(y0), what="ragged triple (masked)")
 
 
 @pytest.mark.parametrize("first", [1, 2, 3001, 4499])
@@ -377,3 +394,115 @@ def test_block_patchwork(oracle, seed):
     assert_close(got_n, want, scale, what="block patchwork %d, no block tiles" % seed, nterms=2100)
     got_e, _ = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER)
     assert_bitexact(got_e, want, "block patchwork %d, exact order" % seed)
+
+
+def fem_ragged(nodes, nbr_lo, nbr_hi, seed, drop=0.0, odd_every=0, reach=1500):
+    """fem3 with what real files do: every stored entry of an off-diagonal block is dropped with probability `drop` (explicit
+    zeros the assembly left out), and with odd_every = K every K-th node has one or two unknowns instead of three (the grid of
+    row and column triples moves behind it)."""
+    rng = np.random.default_rng(seed)
+    dofs = np.full(nodes, 3, dtype=np.int64)
+    if odd_every:
+        odd = np.arange(odd_every // 2, nodes, odd_every)
+        dofs[odd] = rng.integers(1, 3, size=len(odd))
+    first = np.zeros(nodes + 1, dtype=np.int64)
+    np.cumsum(dofs, out=first[1:])
+    rows = int(first[-1])
+    row_cols, row_vals = [], []
+    for n in range(nodes):
+        lo, hi = max(0, n - reach), min(nodes, n + reach + 1)
+        k = int(rng.integers(nbr_lo, nbr_hi + 1))
+        pick = np.unique(np.append(rng.choice(hi - lo, size=min(k, hi - lo), replace=False) + lo, n))
+        cols_n = np.concatenate([first[m] + np.arange(dofs[m]) for m in pick])
+        diag = np.concatenate([np.full(dofs[m], m == n) for m in pick])
+        for a in range(dofs[n]):
+            keep = diag | (rng.random(len(cols_n)) >= drop)
+            row_cols.append(cols_n[keep])
+            row_vals.append(rng.uniform(-1.0, 1.0, size=int(keep.sum())))
+    lens = np.array([len(r) for r in row_cols], dtype=np.int64)
+    p = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    return rows, rows, p.astype(np.int32), np.concatenate(row_cols).astype(np.int32), np.concatenate(row_vals)
+
+
+@pytest.mark.parametrize("name,lo,hi,nodes,drop,odd", [
+    ("2 % of the entries dropped", 24, 30, 6000, 0.02, 0),
+    ("10 % dropped", 20, 34, 6000, 0.10, 0),
+    ("25 % dropped", 27, 27, 5000, 0.25, 0),
+    ("an odd node every 40", 24, 30, 6000, 0.0, 40),
+    ("odd nodes and 5 % dropped", 20, 30, 6000, 0.05, 97),
+    ("few blocks per row, 10 % dropped", 8, 12, 9000, 0.10, 0),
+    ("many blocks per row, 3 % dropped", 40, 52, 3000, 0.03, 0)])
+def test_masked_block_tiles_against_oracle(oracle, name, lo, hi, nodes, drop, odd):
+    """Blocks with entries missing, rows of a triple that differ in length, nodes with one or two unknowns: the tiles are covered
+    with blocks of three consecutive columns and a 9-bit mask each (csr_blocktile.hpp) and multiplied with one lane per block,
+    the values read in place.  Against the oracle (src/matrix/csr-matrix-spmv.cpp:21-33), against the same plan without masked
+    blocks, accumulating, y_out != y_in, with another column array, and never under EXACT_ORDER."""
+    rows, cols, p, c, v = fem_ragged(nodes, lo, hi, seed=len(name), drop=drop, odd_every=odd)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert info["masked_block_tiles"] > 0 and info["block_tiles"] >= 0.8 * info["row_blocks"], (name, info)
+    assert_close(got, want, scale, what=name, nterms=3 * hi + 3)
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_MASKED_BLOCKS)
+    assert info_n["masked_block_tiles"] == 0
+    assert info["streamed_bytes"] < info_n["streamed_bytes"] - 0.8 * info["masked_block_entries"], (info, info_n)
+    assert_close(got_n, want, scale, what=name + ", no masked blocks", nterms=3 * hi + 3)
+    got_e, info_e = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER)
+    assert info_e["block_tiles"] == 0
+    assert_bitexact(got_e, want, name + ", exact order")
+    got2, _ = run_plan(rows, cols, p, c, v, x, y0, runs=2)
+    assert_close(got2, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), 2 * scale, what=name + ", two runs", nterms=6 * hi + 6)
+    got_o, _ = run_plan(rows, cols, p, c, v, x, y0, out_of_place=True)
+    assert np.array_equal(got_o.view(np.uint64), got.view(np.uint64)), name + ": y_out differs from the in-place result"
+    got_c, _ = run_plan(rows, cols, p, c, v, x, y0, other_columns=True)
+    assert_close(got_c, want, scale, what=name + ", other column array", nterms=3 * hi + 3)
+
+
+def test_candidate_without_blocks_pays_for_a_sample_only(oracle):
+    """Rows in triples of SIMILAR length whose columns have nothing to do with each other (a scalar mesh: 20 ... 26 random columns
+    per row): the plan notes a candidate, repack's sample of triples finds three entries per block, and nothing else happens --
+    the tiles are the ones the plan without block tiles has, the result its bits."""
+    rng = np.random.default_rng(12)
+    rows = cols = 30000
+    lens = np.repeat(rng.integers(20, 27, size=rows // 3), 3) + rng.integers(0, 2, size=rows)
+    p = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    c = np.concatenate([np.sort(rng.choice(np.arange(max(0, r - 3000), min(cols, r + 3000)), size=n, replace=False)) for r, n in enumerate(lens)]).astype(np.int32)
+    v = rng.uniform(-1.0, 1.0, size=len(c))
+    p = p.astype(np.int32)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES)
+    assert info["block_tiles"] == 0 and info["row_blocks"] == info_n["row_blocks"], (info, info_n)
+    assert_bitexact(got, got_n, "candidate turned down against the plan without block tiles")
+    assert_close(got, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4), abs_products(rows, p, c, v, x) + np.abs(y0), what="scalar mesh", nterms=30)
+
+
+@pytest.mark.parametrize("spec", ["synthetic:queen:14,12,10,3,20", "synthetic:queen:14,12,10,3,300", "synthetic:queen:14,12,10,3,0,50",
+                                  "synthetic:queen:14,12,10,6,20,97"])
+def test_queen_twins_through_the_context(oracle, spec):
+    """The less tidy twins of the Queen_4147 stand-in (blocks with dropped entries, nodes with one or two unknowns) through
+    the context API, CSR and COO uploads, against the oracle."""
+    Q = hostapi.load(spec, "csr")
+    rows, cols = Q.rows, Q.cols
+    p, c, v = np.array(Q.row_ptr), np.array(Q.column_index), np.array(Q.value)
+    Q.close()
+    x = synth.x_vector(cols, seed=3)
+    want = oracle.csr_spmv(rows, p, c, v, x, num_threads=4)
+    scale = abs_products(rows, p, c, v, x)
+    _, info = run_plan(rows, cols, p, c, v, x, np.zeros(rows))
+    assert info["masked_block_tiles"] > 0 and info["block_tiles"] >= 0.7 * info["row_blocks"], (spec, info)
+    with capi.Context(0) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what=spec + " csr upload", nterms=110)
+        i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+        ctx.upload_coo(rows, cols, i - 1, j - 1, a)
+        ctx.set_x(x)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what=spec + " coo upload", nterms=110)

@@ -1594,7 +1594,8 @@ def test_multi_window_tiles(oracle, case):
         results[flags] = (ty.cpu().numpy(), tout.cpu().numpy(), tz.cpu().numpy(), info)
         plan.close()
     got, got_out, got_other, info = results[0]
-    assert info["row_blocks"] < 0.75 * results[capi.FLAG_NO_MULTI_WINDOW][3]["row_blocks"], "fewer, fuller tiles"
+    # (very_long: only its rows of 513 ... 1024 entries pair up since round 5 -- longer rows are a wave each in registers either way)
+    assert info["row_blocks"] < (0.95 if case == "very_long" else 0.75) * results[capi.FLAG_NO_MULTI_WINDOW][3]["row_blocks"], "fewer, fuller tiles"
     assert_close(got, want, scale, what=case, nterms=4096)
     assert_close(got_other, want, scale, what=case + ", other column array", nterms=4096)
     assert_close(got_out, oracle.csr_spmv(rows, p, c, v, x, y=want, num_threads=4), 2 * scale, what=case + ", y_out", nterms=8192)

@@ -171,7 +171,7 @@ def test_banded_and_random_families():
     assert not np.array_equal(np.asarray(other.column_index), c)
     tiny = hostapi.load("synthetic:random:30,30", "csr")  # k = N: every row holds every column
     assert np.array_equal(np.asarray(tiny.column_index).reshape(30, 30), np.tile(np.arange(30), (30, 1)))
-    for bad in ("synthetic:banded:10", "synthetic:random:10,11", "synthetic:banded:10,3000"):
+    for bad in ("synthetic:banded:10", "synthetic:random:10,11", "synthetic:banded:10,17000"):
         with pytest.raises(hostapi.HostError):
             hostapi.load(bad, "csr")
 
