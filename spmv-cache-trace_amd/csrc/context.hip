@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <new>
+#include <system_error>
+#include <thread>
 
 using namespace spmvi;
 
@@ -51,6 +53,66 @@ int dev_alloc(spmv_hip_ctx * c, T ** out, size_t n)
     c->bytes += bytes;
     return SPMV_HIP_OK;
 }
+
+// ---- host arrays -> HBM beside the host tiler (round 5) ---------------------------------------------------------------------------
+// A copy from pageable host memory occupies the thread that issues it until the data has left (hipMemcpyAsync from pageable
+// memory is synchronous for the host), and Kernel::init used to do everything in a row: cut the tiles from row_ptr (11 ms for
+// Poisson 4096^2), THEN copy the arrays (1.07 GB: 20 ms at the 49-56 GB/s a pageable copy reaches on these boxes).  The copies
+// now run on a helper thread while the caller's thread cuts the tiles (src/kernels/csr-spmv.cpp:26-62 is what this stands in
+// for: load, convert, first touch).  Measured and rejected: page-locked staging (four threads copying 2 MiB chunks into pinned
+// buffers, each with its own stream) reaches 35-43 GB/s -- SLOWER than the plain pageable copy; what made the first pageable
+// copy of a process look slow in the probe (14 GB/s) was the runtime's own start-up, not the pages
+// (profiles/r05_h2d_probe.log, profiles/r05_host_boundary.md).  If the helper thread cannot be started the caller copies itself.
+struct UploadJob {
+    void * dst;
+    const void * src;
+    size_t bytes;
+};
+
+class StagedUpload {
+  public:
+    StagedUpload(int device, hipStream_t stream) : device_(device), stream_(stream) {}
+    ~StagedUpload() { (void) finish(); }
+    void start(std::vector<UploadJob> jobs)
+    {
+        jobs_ = std::move(jobs);
+        size_t total = 0;
+        for (auto const & j : jobs_)
+            total += j.bytes;
+        if (total >= (8u << 20)) {
+            try {
+                worker_ = std::thread([this] { copy_all(); });
+                return;
+            } catch (std::system_error const &) {
+            } catch (std::bad_alloc const &) {
+            }
+        }
+        copy_all();
+    }
+    hipError_t finish()
+    {
+        if (worker_.joinable())
+            worker_.join();
+        return error_;
+    }
+
+  private:
+    void copy_all()
+    {
+        hipError_t e = hipSetDevice(device_);
+        for (auto const & j : jobs_)
+            if (j.bytes > 0 && e == hipSuccess)
+                e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream_);
+        error_ = e;
+    }
+    int device_;
+    hipStream_t stream_;
+    std::vector<UploadJob> jobs_;
+    std::thread worker_;
+    hipError_t error_ = hipSuccess;
+};
 
 int ctx_common_vectors(spmv_hip_ctx * c)
 {
@@ -172,19 +234,30 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_ctx_matrix(c);
-    int rc = spmv_hip_plan_csr(&c->plan, rows, cols, row_ptr, c->csr_algorithm, c->csr_lanes, c->flags);
-    if (rc != 0)
-        return rc;
     c->rows = rows;
     c->cols = cols;
     c->nnz = nnz;
+    int rc;
     if ((rc = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0) return rc;
     if ((rc = dev_alloc(c, &c->d_col, (size_t) nnz)) != 0) return rc;
     if ((rc = dev_alloc(c, &c->d_val, (size_t) nnz)) != 0) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr, ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    if (nnz > 0) {
-        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    {
+        // the arrays travel on a helper thread while this thread cuts the tiles from row_ptr
+        StagedUpload up(c->device, c->stream);
+        up.start({{c->d_ptr, row_ptr, ((size_t) rows + 1) * sizeof(int32_t)},
+                  {c->d_col, column_index, (size_t) nnz * sizeof(int32_t)},
+                  {c->d_val, value, (size_t) nnz * sizeof(double)}});
+        rc = spmv_hip_plan_csr(&c->plan, rows, cols, row_ptr, c->csr_algorithm, c->csr_lanes, c->flags);
+        const hipError_t e = up.finish();
+        if (rc != 0 || e != hipSuccess) {
+            const std::string why = rc != 0 ? last_error_text() : std::string();
+            free_ctx_matrix(c);
+            if (rc != 0) {
+                set_last_error_text(why);
+                return rc;
+            }
+            return fail_hip(e, "upload (host arrays -> device)");
+        }
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
     // the column indices are range-checked where they now are, at HBM speed (row_ptr was checked by
@@ -312,9 +385,11 @@ int spmv_hip_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     if ((rc = dev_alloc(c, &c->d_col, (size_t) nnz)) != 0) return rc;
     if ((rc = dev_alloc(c, &c->d_val, (size_t) nnz)) != 0) return rc;
     if (nnz > 0) {
-        HIP_TRY(hipMemcpyAsync(c->d_idx, row_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        StagedUpload up(c->device, c->stream);
+        up.start({{c->d_idx, row_index, (size_t) nnz * sizeof(int32_t)},
+                  {c->d_col, column_index, (size_t) nnz * sizeof(int32_t)},
+                  {c->d_val, value, (size_t) nnz * sizeof(double)}});
+        HIP_TRY(up.finish());
     }
     if ((rc = ctx_common_vectors(c)) != 0) return rc;
     {
@@ -405,9 +480,13 @@ int spmv_hip_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
                                         | (row_length <= 16 || c->ell_in_place_any_length ? SPMV_HIP_FLAG_EXACT_ORDER : 0u))) != 0)
             return rc;
         if ((rc = dev_alloc(c, &c->d_ptr, (size_t) rows + 1)) != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_ptr, row_ptr.data(), ((size_t) rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_col, column_index, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_val, value, (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        {
+            StagedUpload up(c->device, c->stream);
+            up.start({{c->d_ptr, row_ptr.data(), ((size_t) rows + 1) * sizeof(int32_t)},
+                      {c->d_col, column_index, (size_t) n * sizeof(int32_t)},
+                      {c->d_val, value, (size_t) n * sizeof(double)}});
+            HIP_TRY(up.finish());
+        }
         bool bad = false;
         if ((rc = device_index_check(c->d_col, n, cols, false, &bad, nullptr, c->stream)) != 0) return rc;
         if (bad) {

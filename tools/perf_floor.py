@@ -59,9 +59,15 @@ LATENCY_BOUND = {"webbase_coo", "webbase_hybrid"}
 TOLERANCE = {"bandwidth": 1.07, "latency": 1.15}
 
 
-def measure_triad(rounds=3, reps=20):
-    """STREAM triad of this box in GB/s: the best of a few rounds of 20 launches over 3 x 512 MiB."""
+_TRIAD = {}
+
+
+def measure_triad(rounds=6, reps=20):
+    """STREAM triad of this box in GB/s: the best of a few rounds of 20 launches over 3 x 512 MiB, measured once per process
+    (single measurements scatter by 3 %: half of the gate; the best of six is what the box can do)."""
     import torch
+    if "gbs" in _TRIAD:
+        return _TRIAD["gbs"]
     from spmv_amd import capi
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
@@ -81,6 +87,7 @@ def measure_triad(rounds=3, reps=20):
             best = max(best, 24.0 * nt * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del ta, tb, tc
     torch.cuda.empty_cache()
+    _TRIAD["gbs"] = best
     return best
 
 
