@@ -1169,6 +1169,9 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     return rc;
 }
 
+int spmv_hip_internal_plan_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                                          const int32_t * host_row_ptr, void * stream);
+
 int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
 {
     if (!pl)
@@ -1203,13 +1206,19 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
 // The tiles of a compressed plan cut once more from row_ptr fetched back from the device, and classified again (plan time only):
 // without the block hint (it was wrong and cost tile fill), or on the grid of triples a candidate matrix turned out to have.
 static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, void * stream,
-                         const uint32_t * group_bits /* null: without block tiles */, const double ** reindex)
+                         const uint32_t * group_bits /* null: without block tiles */, const double ** reindex,
+                         const int32_t * host_row_ptr = nullptr /* the caller still has it: no copy back */)
 {
     const bool with_blocks = group_bits != nullptr;
+    const bool was_compressed = pl->d_col16 != nullptr; // (a plan that has not been classified yet is not classified here either)
     hipStream_t s = static_cast<hipStream_t>(stream);
-    std::vector<int32_t> hp((size_t) pl->rows + 1);
-    HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int32_t> hp;
+    if (!host_row_ptr) {
+        hp.resize((size_t) pl->rows + 1);
+        HIP_TRY(hipMemcpyAsync(hp.data(), d_row_ptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        host_row_ptr = hp.data();
+    }
     // the dictionary's tile list (d_tiles_vi) and its constant-row marks number the OLD tiles and patterns
     if (pl->values_from)
         *reindex = pl->values_from;
@@ -1232,56 +1241,75 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
     if (!with_blocks)
         pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
     pl->group_bits = group_bits;
-    int rc = build_wave_tiles(pl, hp.data(), pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
+    int rc = build_wave_tiles(pl, host_row_ptr, pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
     pl->group_bits = nullptr;
     if (rc == SPMV_HIP_OK)
         rc = plan_account(pl, false);
-    if (rc == SPMV_HIP_OK)
+    if (rc == SPMV_HIP_OK && was_compressed)
         rc = spmv_hip_plan_csr_compress(pl, d_column_index, stream);
     return rc;
+}
+
+// A CANDIDATE for block tiles (rows of similar length, spmv_hip_plan_csr): which rows have the same columns as the row in front of
+// them (csr_row_group_kernel)?  If half of the rows stand in groups of three the tiles are cut again on those groups; the block
+// stage of repack marks them later.  Asked once per plan: by spmv_hip_plan_csr_repack, or -- where the caller owns all the
+// arrays (spmv_hip_upload_csr) -- BEFORE the tiles are classified, which saves classifying them twice.
+static int confirm_block_candidate(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, void * stream,
+                                   const double ** reindex, const int32_t * host_row_ptr)
+{
+    if (!pl->block_candidate || pl->block_hint || !d_row_ptr || !d_column_index
+        || pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->balanced || pl->ntiles == 0 || pl->rows < 192 || pl->nnz == 0
+        || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS)))
+        return SPMV_HIP_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pl->block_candidate = 0; // asked once
+    const size_t words = 2 * (((size_t) pl->rows + 63) / 64);
+    uint32_t * d_bits = nullptr;
+    unsigned long long * d_count = nullptr;
+    unsigned long long triples[1] = {0};
+    HIP_TRY(hipMalloc((void **) &d_bits, words * sizeof(uint32_t)));
+    hipError_t e = hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned) (((size_t) pl->rows + 255) / 256);
+        hipLaunchKernelGGL(spmv::csr_row_group_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_row_ptr, d_column_index, d_bits);
+        hipLaunchKernelGGL(spmv::csr_row_triple_count_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_bits, d_count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = read_striped(d_count, triples, 1, s);
+    std::vector<uint32_t> bits;
+    const bool confirmed = e == hipSuccess && 6 * triples[0] >= (unsigned long long) pl->rows; // half of the rows in triples
+    if (confirmed) {
+        bits.resize(words);
+        e = hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void) hipFree(d_bits);
+    if (d_count) (void) hipFree(d_count);
+    if (e != hipSuccess)
+        return fail_hip(e, "row groups");
+    if (confirmed)
+        return rebuild_tiles(pl, d_row_ptr, d_column_index, stream, bits.data(), reindex, host_row_ptr);
+    return SPMV_HIP_OK;
+}
+
+// (not part of the public header: spmv_hip_upload_csr calls it between spmv_hip_plan_csr and spmv_hip_plan_csr_compress)
+int spmv_hip_internal_plan_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+                                          const int32_t * host_row_ptr, void * stream)
+{
+    if (!pl || pl->d_col16)
+        return SPMV_HIP_OK;
+    const double * reindex = nullptr; // (no dictionary yet)
+    return confirm_block_candidate(pl, d_row_ptr, d_column_index, stream, &reindex, host_row_ptr);
 }
 
 static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, const double * d_value,
                          void * stream, const double ** reindex)
 {
-    // a CANDIDATE for block tiles (rows of similar length, spmv_hip_plan_csr): which rows have the same columns as the row in
-    // front of them?  If half of the rows stand in groups of three the tiles are cut again on those groups, and the block stage
-    // below marks them
-    if (pl->block_candidate && !pl->block_hint && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
-        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0 && pl->rows >= 192
-        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS))) {
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        pl->block_candidate = 0; // asked once
-        const size_t words = 2 * (((size_t) pl->rows + 63) / 64);
-        uint32_t * d_bits = nullptr;
-        unsigned long long * d_count = nullptr;
-        unsigned long long triples[1] = {0};
-        HIP_TRY(hipMalloc((void **) &d_bits, words * sizeof(uint32_t)));
-        hipError_t e = hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
-        if (e == hipSuccess) {
-            const unsigned grid = (unsigned) (((size_t) pl->rows + 255) / 256);
-            hipLaunchKernelGGL(spmv::csr_row_group_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_row_ptr, d_column_index, d_bits);
-            hipLaunchKernelGGL(spmv::csr_row_triple_count_kernel, dim3(grid), dim3(256), 0, s, pl->rows, d_bits, d_count);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = read_striped(d_count, triples, 1, s);
-        std::vector<uint32_t> bits;
-        const bool confirmed = e == hipSuccess && 6 * triples[0] >= (unsigned long long) pl->rows; // half of the rows in triples
-        if (confirmed) {
-            bits.resize(words);
-            e = hipMemcpyAsync(bits.data(), d_bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-        }
-        (void) hipFree(d_bits);
-        if (d_count) (void) hipFree(d_count);
-        if (e != hipSuccess)
-            return fail_hip(e, "row groups");
-        if (confirmed) {
-            int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, bits.data(), reindex);
-            if (rc != SPMV_HIP_OK)
-                return rc;
-        }
+    if (pl->d_col16 && pl->compressed_from == d_column_index) {
+        int rc = confirm_block_candidate(pl, d_row_ptr, d_column_index, stream, reindex, nullptr);
+        if (rc != SPMV_HIP_OK)
+            return rc;
     }
     // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
     if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
