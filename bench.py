@@ -335,7 +335,10 @@ def pmc_traffic(kernel_name, workload, algorithmic_bytes, streamed_bytes=None, b
     return best
 
 
-MULTIPLY_KERNELS = ("csr_wavetile", "csr_segtile", "csr_segwin", "csr_blockwin", "coo_wide", "ell_kernel")
+# (whole kernel names: "csr_blockwin" alone would also match the plan-time csr_blockwin_mark_kernel, whose duration on the
+# queen-like matrix happens to equal the multiply's)
+MULTIPLY_KERNELS = ("csr_wavetile_kernel", "csr_segtile_kernel", "csr_segwin_kernel", "csr_blockwin_kernel", "csr_blockwin_stream_kernel",
+                    "coo_wide_kernel", "spmv::ell_kernel")
 
 
 def attach_traffic(d, build, triad_gbs):
