@@ -693,6 +693,13 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                                                 vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);
             return;
         }
+        if (TILE == 512 && !PANELS && nrows > 1 && k1 - kb > TILE && lanes_log2 == 6) {
+            // several rows of more than 512 entries each: in registers, one butterfly per row (tile_common.hpp)
+            const bool narrow = C16 && (meta & kTileMetaNarrow);
+            tile_rows_long_registers<X32>(p, j, j16, narrow, a, x, narrow ? cbase : 0, (unsigned) (cols - 1 - (narrow ? cbase : 0)), y_in, r0, k0, k1,
+                                          nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+            return;
+        }
         if (TILE == 512 && !PANELS && nrows > 1 && k1 - kb > TILE) {
             tile_rows_multi_window<TILE, QUADS, C16, X32, VI>(prod, p, j, j16, a, x, y_in, r0, k0, k1, nrows, meta, cbase, cols, lane, vidx, vtab,
                                                               [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });

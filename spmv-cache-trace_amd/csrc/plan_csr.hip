@@ -493,35 +493,58 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         // (round 5: rows of more than kMultiWindowMaxRow = 1024 entries are better off with a wave each, in registers -- bands of
         // 2001 per row 0.75 in multi-window tiles, 0.80 a wave per row; 1001 and 1501 per row the same either way; 601 and 801 per row
         // 0.75 against 0.66 / 0.71: profiles/r05_csr_long_rows.log)
-        constexpr int kMultiWindowMaxRow = 1024;
-        const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= kMultiWindowMaxRow;
+        // (later in round 5: SEVERAL rows of more than 512 entries each per wave, in registers -- tile_rows_long_registers, one
+        // butterfly per row and no LDS: the fill of a multi-window tile without its round trip.  ELLPACK bands of 601 / 801 / 1001
+        // per row 0.76 / 0.77 / 0.81 -> 0.82 / 0.83 / 0.86.  Such a tile may hold rows of up to 16384 entries in up to 40 steps of
+        // 512 (profiles/r05_long_pair_ab.log, r05_long_cap_ab.log) -- but never more than 1/8192 of the matrix, so that a small
+        // matrix keeps its waves; rows of up to 1024 entries that the cap keeps out of the registers still share a tile through LDS)
+        constexpr int kMultiWindowMaxRow = 1024, kRegisterTileMaxRow = 16384, kRegisterTileMaxSteps = 40;
+        long long cap_div = 8192;
+#ifdef SPMV_HIP_EXPERIMENTS
+        if (const char * v = std::getenv("SPMV_HIP_REGISTER_TILE_CAP_DIV")) cap_div = std::max(1LL, std::atoll(v)); // tools/long_pair_ab.sh
+#endif
+        const long long register_tile_cap = std::max<long long>(2 * tile, (long long) p[rows] / cap_div);
+        const bool multi_start = r1 > r ? maxlen > 160 : (long long) p[r + 1] - p[r] <= kRegisterTileMaxRow;
         // (under the block hint only rows that no block tile could hold: three rows of more than 170 entries exceed a tile)
         const bool hint_allows = !pl->block_hint || (r1 > r ? maxlen > 170 : true);
         if (!exact && tile == 512 && break_rows == 0 && hint_allows && multi_start && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW))
             ++o.multi_candidates;
         if (allow_multi && !exact && tile == 512 && break_rows == 0 && hint_allows && multi_start
             && !(flags & SPMV_HIP_FLAG_NO_MULTI_WINDOW)) {
-            const double plain = r1 > r ? (double) ((long long) p[r1] - kb) / tile : 0.0;
+            // what the rows would fill without this: the plain tile, or -- a row longer than a tile -- the steps of its own wave
+            const long long alone = (long long) p[r + 1] - kb;
+            const double plain = r1 > r ? (double) ((long long) p[r1] - kb) / tile : (double) alone / (double) (((alone + tile - 1) / tile) * tile);
             int best = 0;
             // (rows of 257: no row count up to 8 reaches 0.9 -- 7 rows are 0.88 -- and one row per tile is 0.50.  A plain tile of ONE
             // row is given up for any two rows that fill their windows to 3/4: a row of 479 has a tile 94 % full to itself and runs
             // at 0.67 of the roofline -- a descriptor, a y access and a 64-lane sum per row -- where two rows of 511 in two windows
             // run at 0.85, profiles/r04_ell_long_rows.md)
-            double best_fill = r1 - r >= 2 ? std::max(plain + 0.1, 0.75) : 0.75;
-            int mx = 0;
+            // (a row of up to 1536 entries with steps to itself shares a tile whenever that tile is 3/4 full -- 1001 / 1501 per row:
+            // 0.79 / 0.81 a wave each, 0.85 / 0.85 two per wave at the same fill; longer rows only where sharing fills the steps
+            // better: in CSR, same process, 2001 / 3001 / 4001 per row ran 8 / 4 / 8 % SLOWER shared, profiles/r05_csr_shared_vs_alone.log)
+            double alone_gain = (long long) p[r + 1] - p[r] <= 1536 ? -1.0 : 0.04;
+#ifdef SPMV_HIP_EXPERIMENTS
+            if (const char * v = std::getenv("SPMV_HIP_LONG_PAIR_GAIN")) alone_gain = std::atof(v); // tools/ell_long_rows.sh: -1 = share a tile whenever it is 3/4 full
+#endif
+            double best_fill = r1 - r >= 2 ? std::max(plain + 0.1, 0.75) : (r1 > r ? 0.75 : std::max(plain + alone_gain, 0.75));
+            int mx = 0, mn = INT32_MAX;
+            bool best_in_registers = false;
             for (int32_t q = r; q < row_limit && q - r < 8; ++q) {
                 mx = std::max(mx, p[q + 1] - p[q]);
-                if (mx > kMultiWindowMaxRow)
-                    break;
+                mn = std::min(mn, p[q + 1] - p[q]);
                 const long long e = (long long) p[q + 1] - kb;
                 const long long windows = (e + tile - 1) / tile;
-                if (windows > 8)
+                // in registers: every row so far is longer than a step (at most one row ends per step); through LDS: round 4's limits
+                const bool in_registers = mn > tile && mx <= kRegisterTileMaxRow && windows <= kRegisterTileMaxSteps && (q == r || e <= register_tile_cap);
+                const bool through_lds = mx <= kMultiWindowMaxRow && windows <= 8;
+                if (!in_registers && !through_lds)
                     break;
                 const bool inside = ((e + kb - 1) | 3) < (long long) p[rows]; // the last quad's 16-byte loads stay inside the arrays
                 const double fill = (double) e / (double) (windows * tile);
                 if (q + 1 > r1 && q + 1 - r >= 2 && inside && fill > best_fill) {
                     best_fill = fill;
                     best = (int) (q + 1 - r);
+                    best_in_registers = in_registers;
                 }
             }
             if (best > 0) {
@@ -533,6 +556,8 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     minlen = std::min(minlen, p[q + 1] - p[q]);
                 }
                 multi_lanes_log2 = best <= 2 ? 5 : (best <= 4 ? 4 : 3); // 64 / (rows rounded up to a power of two)
+                if (best_in_registers)
+                    multi_lanes_log2 = 6; // "all 64 lanes": the tile is walked in registers
                 o.multi_window_tiles++;
             }
         }

@@ -364,4 +364,74 @@ __device__ __forceinline__ double long_row_sum(
     return group_sum<kWave>((z0 + z1) + (z2 + z3));
 }
 
+// SEVERAL long rows (each of more than 512 entries) owned by one wave, in registers (round 5): the multi-window tiles' fill --
+// five rows of 601 entries are 5.9 windows of 512, where one such row alone leaves its second window 83 % empty -- without
+// their LDS round trip.  The wave walks the tile's entries in steps of 512 like long_row_sum; a lane adds those of its eight
+// products that belong to the row that is currently open to ONE accumulator; where a row ends inside a step (wave-uniform: at
+// most twice per step for rows of this length) the accumulator is summed over the wave, lane `row` keeps the result, and the
+// next row opens on the same products.  One butterfly per row, no LDS, no atomics, the same y on every run.
+template <bool X32, typename YStore>
+__device__ __forceinline__ void tile_rows_long_registers(
+    const int32_t * __restrict__ p, const int32_t * __restrict__ j, const uint16_t * __restrict__ j16, bool narrow,
+    const double * __restrict__ a, const double * __restrict__ x, int cbase, unsigned limit, const double * y_in,
+    int r0, int k0, int k1, int nrows, int lane, YStore && store)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const int kb = k0 & ~3, lastq = (k1 - 1) & ~3;
+    const double yv = y_in[r0 + (lane < nrows ? lane : nrows - 1)];
+    const char * xb = reinterpret_cast<const char *>(x + cbase);
+    int row = 0;
+    int ps = k0, pe = __builtin_amdgcn_readfirstlane(p[r0 + 1]);
+    double acc = 0.0, zmine = 0.0;
+    for (int base = kb; base < k1; base += 2 * 4 * kWave) { // wave-uniform
+        const int oA = base + 4 * lane, oB = oA + 4 * kWave;   // this lane's two quads (their entries: the masks below)
+        const int cA = oA < lastq ? oA : lastq, cB = oB < lastq ? oB : lastq; // (past the tile's end: its last quad again, masked out)
+        unsigned c[8];
+        if (narrow) {
+            const v2u ca = *reinterpret_cast<const v2u *>(j16 + cA), cb = *reinterpret_cast<const v2u *>(j16 + cB);
+            c[0] = ca.x & 0xFFFFu; c[1] = ca.x >> 16; c[2] = ca.y & 0xFFFFu; c[3] = ca.y >> 16;
+            c[4] = cb.x & 0xFFFFu; c[5] = cb.x >> 16; c[6] = cb.y & 0xFFFFu; c[7] = cb.y >> 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                c[i] = min(c[i], limit);
+        } else {
+            const v4i ca = *reinterpret_cast<const v4i *>(j + cA), cb = *reinterpret_cast<const v4i *>(j + cB);
+            c[0] = (unsigned) ca.x; c[1] = (unsigned) ca.y; c[2] = (unsigned) ca.z; c[3] = (unsigned) ca.w;
+            c[4] = (unsigned) cb.x; c[5] = (unsigned) cb.y; c[6] = (unsigned) cb.z; c[7] = (unsigned) cb.w;
+        }
+        const v2d a0 = *reinterpret_cast<const v2d *>(a + cA), a1 = *reinterpret_cast<const v2d *>(a + cA + 2);
+        const v2d b0 = *reinterpret_cast<const v2d *>(a + cB), b1 = *reinterpret_cast<const v2d *>(a + cB + 2);
+        double q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            q[i] = narrow ? *reinterpret_cast<const double *>(xb + (c[i] << 3)) : gather_x<X32>(x, (int) c[i]);
+        q[0] *= a0.x; q[1] *= a0.y; q[2] *= a1.x; q[3] *= a1.y;
+        q[4] *= b0.x; q[5] *= b0.y; q[6] *= b1.x; q[7] *= b1.y;
+        for (;;) { // the rows that have entries in this step, one after the other
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                part += (oA + i >= ps && oA + i < pe) ? q[i] : 0.0;
+                part += (oB + i >= ps && oB + i < pe) ? q[4 + i] : 0.0;
+            }
+            acc += part;
+            if (pe > base + 2 * 4 * kWave)
+                break; // the open row goes on in the next step
+            const double z = group_sum<kWave>(acc);
+            if (lane == row)
+                zmine = z;
+            acc = 0.0;
+            ++row;
+            if (row >= nrows)
+                break;
+            ps = pe;
+            pe = __builtin_amdgcn_readfirstlane(p[r0 + row + 1]);
+            if (ps >= base + 2 * 4 * kWave)
+                break; // the next row begins with the next step
+        }
+    }
+    if (lane < nrows)
+        store(r0 + lane, yv + zmine);
+}
+
 } // namespace spmv
