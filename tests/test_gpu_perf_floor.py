@@ -40,7 +40,7 @@ def test_launch_time_within_the_floor(name):
     table = _table()
     us, info = perf_floor.measure(name)
     row = table["workloads"][name]
-    allowed = table["tolerance"][row["bound"]]
+    allowed = row.get("tolerance", table["tolerance"][row["bound"]])  # (a row may carry its own: see the table's "what")
     ratio = us * info["triad_gbs"] / (row["us"] * row["triad_gbs"])
     if us <= 1.02 * row["us"]:
         return  # not slower in microseconds than the table's box: no regression, whatever this box's triad says

@@ -57,6 +57,9 @@ WORKLOADS = {
 # the workloads whose launch is too short to follow the box's bandwidth: held to the looser gate
 LATENCY_BOUND = {"webbase_coo", "webbase_hybrid"}
 TOLERANCE = {"bandwidth": 1.07, "latency": 1.15}
+# a wave per long row spreads more between boxes than the triad does (bands of 2001 per row: 0.76 ... 0.86 of the roofline on
+# five boxes of one afternoon, profiles/r05_results.md): these rows carry their own gate
+ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12}
 
 
 _TRIAD = {}
@@ -173,6 +176,8 @@ def main():
         spec, fmt, flags = WORKLOADS[name]
         row = {"matrix": spec, "format": fmt, "flags": flags, "us": round(us, 2), "triad_gbs": triad,
                "bound": "latency" if name in LATENCY_BOUND else "bandwidth"}
+        if name in ROW_TOLERANCE:
+            row["tolerance"] = ROW_TOLERANCE[name]
         # the slower of old and new IN UNITS OF THE BOX'S TRIAD survives: the table is a floor for every box, not a record
         if old_units > us * triad and (old.get("matrix"), old.get("format"), old.get("flags")) == (spec, fmt, flags):
             row["us"], row["triad_gbs"] = old["us"], old["triad_gbs"]
