@@ -59,7 +59,9 @@ LATENCY_BOUND = {"webbase_coo", "webbase_hybrid"}
 TOLERANCE = {"bandwidth": 1.07, "latency": 1.15}
 # a wave per long row spreads more between boxes than the triad does (bands of 2001 per row: 0.76 ... 0.86 of the roofline on
 # five boxes of one afternoon, profiles/r05_results.md): these rows carry their own gate
-ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12}
+# ... and so do the queen-like and kkt-like launches (full size: 462 ... 510 us and 743 ... 803 us on boxes with the same triad)
+ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12,
+                 "queen_small_csr": 1.10, "queen_small_ell": 1.10, "queen_small_broken_csr": 1.10}
 
 
 _TRIAD = {}
