@@ -28,6 +28,8 @@ run --threads 2 --coo "$G/test_mtx.gz" --profile 2
 run --threads 2 --spmv-format hybrid --matrix "$G/poisson2D.mtx" --profile 2 --check
 run --threads 1 --matrix synthetic:webbase:20000,62000,300,75 --spmv-format coo --profile 2 --check
 run --matrix synthetic:kkt:10 --write-mtx "$OUT/k.mtx.gz"
+run --threads 2 --matrix synthetic:queen:9,8,7,3,150,40 --spmv-format csr --profile 2 --check
+run --threads 2 --matrix synthetic:queen:9,8,7,3,0,11 --spmv-format ell --profile 2 --check
 run --threads 2 --csr "$OUT/k.mtx.gz" --profile 1 --expand-symmetric
 run --threads 2 --csr "$G/bus1138_like.mtx__RCM" --profile 1
 run --threads 1 --synthetic queen:5,4,6 --spmv-format csr --profile 1 --x uniform
