@@ -450,10 +450,15 @@ struct PeerY {
     int n;
 };
 
+// NT: the store goes past the caches (non-temporal).  y is read once and written once per launch; written normally it takes room
+// in the L2 that x and the streams want: the dictionary variant and the value-reading stencil tiles always store it that way
+// (143 -> 139 us, 192.2 -> 189.9 us), every other tile class when the launch says so (`nt`: the matrix streams from HBM --
+// 27 diagonals 171.6 -> 165.7 us, kkt-like and queen-like unchanged: profiles/r05_ab_y_nt_all.log; a cache-resident matrix keeps
+// its y in the caches between launches).
 template <bool PEER, bool NT>
-__device__ __forceinline__ void y_store(double * y, const PeerY & peers, long long idx, double v)
+__device__ __forceinline__ void y_store(double * y, const PeerY & peers, long long idx, double v, bool nt = false)
 {
-    if (NT)
+    if (NT || nt)
         __builtin_nontemporal_store(v, y + idx);
     else
         y[idx] = v;
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
     int ntiles, const int4 * __restrict__ desc, const int32_t * __restrict__ p,
     const int32_t * __restrict__ j, const uint16_t * __restrict__ j16,
     const double * __restrict__ a, const double * __restrict__ x, const double * y_in_arg, double * y_arg,
-    int nnz_total, int cols, int exact_order, const int32_t * __restrict__ patterns, PanelInfo pinfo,
+    int nnz_total, int cols, int exact_order_and_nt, const int32_t * __restrict__ patterns, PanelInfo pinfo,
     const uint8_t * __restrict__ vidx = nullptr, const double * __restrict__ vtable = nullptr, int nvalues = 0,
     PeerY peers = PeerY{}, const int32_t * __restrict__ tile_list = nullptr)
 {
@@ -619,6 +624,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
     // different ones (a partitioned multiply whose previous result is still being gathered); every
     // row is read and written by the same lane, so the in-place case needs no ordering.
     constexpr int QUADS = TILE / 256; // 16-byte column loads per lane
+    // exact_order_and_nt: bit 0 = SPMV_HIP_FLAG_EXACT_ORDER, bit 1 = write y non-temporally (the matrix streams from HBM)
+    const int exact_order = exact_order_and_nt & 1;
+    const bool nt_y = (exact_order_and_nt & 2) != 0;
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ __attribute__((aligned(16))) uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
@@ -697,22 +705,22 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             // several rows of more than 512 entries each: in registers, one butterfly per row (tile_common.hpp)
             const bool narrow = C16 && (meta & kTileMetaNarrow);
             tile_rows_long_registers<X32>(p, j, j16, narrow, a, x, narrow ? cbase : 0, (unsigned) (cols - 1 - (narrow ? cbase : 0)), y_in, r0, k0, k1,
-                                          nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+                                          nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v, nt_y); });
             return;
         }
         if (TILE == 512 && !PANELS && nrows > 1 && k1 - kb > TILE) {
             tile_rows_multi_window<TILE, QUADS, C16, X32, VI>(prod, p, j, j16, a, x, y_in, r0, k0, k1, nrows, meta, cbase, cols, lane, vidx, vtab,
-                                                              [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+                                                              [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v, nt_y); });
             return;
         }
         if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !exact_order) {
             // dense 3 x 3 blocks (csr_blocktile.hpp): one 16-bit number per block instead of a column per entry, no row_ptr
             if (meta & kTileMetaBlock3Masked) // blocks with entries missing, off the grid of column triples: a 32-bit word per block
                 tile_rows_block3<true>(prod, reinterpret_cast<const uint32_t *>(j16 + mask_stream_offset(nnz_total)) + mask_stream_index(k0), a,
-                                       x + cbase, y_in, r0, k0, k1, nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+                                       x + cbase, y_in, r0, k0, k1, nrows, lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v, nt_y); });
             else
                 tile_rows_block3<false>(prod, j16 + block_stream_offset(nnz_total) + block_stream_index(k0), a, x + cbase, y_in, r0, k0, k1, nrows,
-                                        lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v); });
+                                        lane, [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v, nt_y); });
             return;
         }
         // (1) loads nobody waits for yet: row_ptr pair and old y of this lane's row
@@ -734,6 +742,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
         const double * yin_t = y_in + r0;
         // (value-dictionary variant: y is read once and written once per launch -- non-temporal, to keep it out of
         // the way of x in the caches: 143 -> 139 us)
+        // (the value-reading stencil tiles WRITE y non-temporally too, round 5; reading it that way as well was measured 0.8 % slower)
+        const bool stencil_values = !VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
+            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen;
         const double yv = (PANELS || (VI && (kViAblate & 2))) ? 0.0 // panels: the partial sums are added atomically
             : ((VI && !(kViAblate & 16)) ? __builtin_nontemporal_load(yin_t + rowi) : yin_t[rowi]);
         // a tile of short rows may hold up to 128 of them: lanes then own a second row, 64 further on
@@ -770,16 +781,18 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                 y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + lane + kWave, yvB + zB);
             return;
         }
-        if (!VI && C16 && TILE == 512 && !PANELS && XW == 0 && ABL == 0 && (meta & kTileMetaShifted) && (meta & kTileMetaUniform)
-            && lanes_log2 == 0 && maxlen <= kLanePerRowMaxLen) {
+        if (stencil_values) {
             const bool pattern = (meta & kTileMetaPattern) != 0;
             double zA, zB;
             tile_rows_uniform_values<QUADS, X32>(prod, pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                  a + kb, x, last, lane, maxlen, k0 - kb, nrows, second, zA, zB);
+            // (y written past the caches -- non-temporal, like the dictionary variant does: it is read once and written once per
+            // launch, and x wants the room: Poisson 4096^2 192.2 -> 189.9 us in alternating processes, profiles/r05_ab_misc.log,
+            // r05_ab_y_nt.log)
             if (lane < nrows)
-                y_store<PEER, false>(y, peers, r0 + lane, yv + zA);
+                y_store<PEER, true>(y, peers, r0 + lane, yv + zA);
             if (second && lane + kWave < nrows)
-                y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB);
+                y_store<PEER, true>(y, peers, r0 + lane + kWave, yvB + zB);
             return;
         }
         // (2) the tile's column/value quads, (3) gather x and park the rounded products; entries
@@ -841,7 +854,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             else if (VI)
                 y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + sub, yv + z);
             else
-                y_store<PEER, false>(y, peers, r0 + sub, yv + z);
+                y_store<PEER, false>(y, peers, r0 + sub, yv + z, nt_y);
         }
         if (second) {
             const double zB = ((ABL & 2) || (VI && (kViAblate & 4))) ? prod[psB - kb] : tile_row_sum<1>(prod, psB - kb, peB - kb, 0, maxlen);
@@ -851,7 +864,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                 else if (VI)
                     y_store<PEER, !(kViAblate & 32)>(y, peers, r0 + lane + kWave, yvB + zB);
                 else
-                    y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB);
+                    y_store<PEER, false>(y, peers, r0 + lane + kWave, yvB + zB, nt_y);
             }
         }
     } else if (!partial && k1 - kb <= TILE) {
@@ -870,7 +883,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             if (PANELS)
                 unsafeAtomicAdd(y + r0 + r, z);
             else
-                y_store<PEER, false>(y, peers, r0 + r, y_in[r0 + r] + z);
+                y_store<PEER, false>(y, peers, r0 + r, y_in[r0 + r] + z, nt_y);
         }
     } else if (!exact_order) {
         // ---- one long row, or one chunk of a very long row: the whole wave, in registers (tile_common.hpp) ----------
@@ -880,7 +893,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             if (partial || PANELS)
                 unsafeAtomicAdd(y + r0, z); // the host made y_out a copy of y_in first if they differ (never under PEER)
             else
-                y_store<PEER, false>(y, peers, r0, y_in[r0] + z);
+                y_store<PEER, false>(y, peers, r0, y_in[r0] + z, nt_y);
         }
     } else {
         // ---- one long row in the reference's order: lane 0 adds tiles of products ---------
@@ -903,7 +916,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             if (PANELS)
                 unsafeAtomicAdd(y + r0, z);
             else
-                y_store<PEER, false>(y, peers, r0, y_in[r0] + z);
+                y_store<PEER, false>(y, peers, r0, y_in[r0] + z, nt_y);
         }
     }
 }

@@ -187,7 +187,10 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
 #undef SPMV_SEG_LAUNCH
         } else if (pl->ntiles > 0) {
             const int xcd = (pl->flags & SPMV_HIP_FLAG_XCD_REMAP) ? 1 : 0;
-            const int exact = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
+            const int exact_order = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
+            // what the kernels get: bit 0 = exact order, bit 1 = y written non-temporally -- when the matrix streams from HBM (twice
+            // the Infinity Cache: the same threshold as for the 128-row tiles); a cache-resident matrix keeps its y in the caches
+            const int exact = exact_order | ((12.0 * (double) pl->nnz + 20.0 * (double) pl->rows >= 512e6) ? 2 : 0);
             // the 16-bit index stream is only valid for the column array it was derived from
             const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
             // x below 4 GiB: 32-bit gather offsets from a scalar base
@@ -239,7 +242,7 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
                                        spmv::PanelInfo{}, (const uint8_t *) nullptr, (const double *) nullptr, 0, spmv::PeerY{}, pl->d_rest_tiles);
             } else
 #ifdef SPMV_HIP_EXPERIMENTS
-            if (pl->d_group_tiles && c16 && x32 && !xcd && !exact && pl->tile == 512 && (!peers || pl->split_rows == 0)) {
+            if (pl->d_group_tiles && c16 && x32 && !xcd && !exact_order && pl->tile == 512 && (!peers || pl->split_rows == 0)) {
                 // most tiles are rows of 17 ... 64 entries of a stencil or band: a group of lanes per row (csr_rowgroup.hpp),
                 // then the other tiles (the x-window variant over a list)
                 const dim3 grid((unsigned) ((pl->ngroup_tiles + 3) / 4)), rest((unsigned) ((pl->ngroup_rest + 3) / 4));
@@ -264,7 +267,7 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             // x staged through LDS when most tiles have a window.  With one lane per row (EXACT_ORDER,
             // the in-place ELLPACK path) long row sums want the occupancy more than the gather wants
             // the window (L = 81: 339 vs 333 us; L = 27: 199 vs 223 us), so only up to 32 entries per row
-            if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact || pl->longest_tile_row <= 32) && c16 && x32
+            if (!(pl->flags & SPMV_HIP_FLAG_NO_X_WINDOW) && (!exact_order || pl->longest_tile_row <= 32) && c16 && x32
                 && pl->tile == 512 && !xcd && 2 * (long long) pl->xwin_tiles > pl->ntiles
                 && !(pl->nvalues > 0 && pl->values_from == a) /* a dictionary kept in spite of the windows: constant-row tiles (plan_csr.hip) */) {
                 if (peers && pl->split_rows == 0 && !pl->d_blocks && !pl->d_segblocks) { // one process per GPU: row sums forwarded (see below)

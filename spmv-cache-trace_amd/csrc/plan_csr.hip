@@ -426,9 +426,15 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         // lanes per row follow the tile's LONGEST row (<= 16 entries per lane), and a tile takes
         // only as many rows as the wave has lanes for: a 400-entry row among 63 short ones would
         // otherwise be summed by one lane while the others wait (power-law rows 3/row: 50 -> 44 us)
-        auto lanes_for = [](int len) {
+        int per_lane = 16;
+#ifdef SPMV_HIP_EXPERIMENTS
+        // (tools/ab.py, round 5: 8 entries per lane -- 4 lanes per row of 28 -- kkt-like 730.1 against 734.6 us, 27 diagonals 161.8 against
+        // 163.0, queen-like without block tiles 768.7 against 624.6: profiles/r05_ab_misc.log; 16 stays)
+        if (const char * v = std::getenv("SPMV_HIP_ENTRIES_PER_LANE")) per_lane = std::max(4, std::min(64, std::atoi(v)));
+#endif
+        auto lanes_for = [per_lane](int len) {
             int l = 0;
-            while (l < 6 && (16 << l) < len)
+            while (l < 6 && (per_lane << l) < len)
                 ++l;
             return l;
         };
