@@ -375,7 +375,10 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [29] multi-window tiles (several rows of 161 ... 1024 entries walked in windows of 512: SPMV_HIP_FLAG_NO_MULTI_WINDOW),
  *        [30] 0 in this library (row-group tiles in libspmv_hip_experiments.so)
  *        [31] of the block tiles [25]: MASKED ones (blocks with entries missing or off the grid of column triples: a 32-bit word
- *             per block, SPMV_HIP_FLAG_NO_MASKED_BLOCKS)  [32] their entries */
+ *             per block, SPMV_HIP_FLAG_NO_MASKED_BLOCKS)  [32] their entries
+ *        [33] masked stencil tiles (the boundary rows of a structured grid: rows that follow a stencil pattern of at most 16
+ *             positions with some of them missing -- a 16-bit mask per row instead of column indices and row_ptr; marked by
+ *             spmv_hip_plan_csr_repack; never with SPMV_HIP_FLAG_NO_SHIFTED_TILES)  [34] their entries */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

@@ -32,6 +32,10 @@ __device__ __forceinline__ int scalar_load_i32(const int32_t * p)
     typedef const int32_t __attribute__((address_space(4))) * const_ptr;
     return *reinterpret_cast<const_ptr>(reinterpret_cast<uintptr_t>(p));
 }
+} // namespace spmv
+#include "csr_stenciltile.hpp" // (uses scalar_load_i32)
+namespace spmv {
+
 template <int QUADS, bool X32, bool VI = false>
 __device__ __forceinline__ void tile_products_shifted(
     double * prod, uint32_t * tab, const int32_t * __restrict__ first_row, int first_row_base,
@@ -699,6 +703,22 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             const bool pattern = (meta & kTileMetaPattern) != 0;
             tile_rows_pairs_constant<X32, PEER>(pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                                 vidx + kb, vtab, x, y_in, y, peers, r0, lane, maxlen, k0 - kb, nrows);
+            return;
+        }
+        if (C16 && TILE == 512 && !PANELS && is_masked_stencil_tile(meta)) {
+            // rows that follow the stencil's pattern with some positions missing (the boundary of a structured grid): a lane per row,
+            // the rows' masks in the tile's 16-bit column slots (csr_stenciltile.hpp); values from the value array, dictionary or not
+            const double * yin_t = y_in + r0;
+            const double yA = yin_t[lane < nrows ? lane : nrows - 1];
+            const double yB = yin_t[lane + kWave < nrows ? lane + kWave : nrows - 1];
+            const int32_t * pat = patterns + (size_t) cbase * kPatStride;
+            double zA, zB;
+            tile_rows_masked_stencil<QUADS, X32>(prod, pat + kPatRel, __builtin_amdgcn_readfirstlane(pat[0]), j16 + k0, a + kb, x, cols, r0,
+                                                 (k1 - 1 - kb) & ~3, lane, k0 - kb, nrows, zA, zB);
+            if (lane < nrows)
+                y_store<PEER, false>(y, peers, r0 + lane, yA + zA, nt_y);
+            if (lane + kWave < nrows)
+                y_store<PEER, false>(y, peers, r0 + lane + kWave, yB + zB, nt_y);
             return;
         }
         if (TILE == 512 && !PANELS && nrows > 1 && k1 - kb > TILE && lanes_log2 == 6) {

@@ -141,6 +141,8 @@ struct spmv_hip_plan {
     int break_rows = 0; // (what the tiles were built with: a rebuild needs them again)
     int block_tiles = 0;
     long long block_entries = 0;
+    int stencil_mask_tiles = 0; // tiles whose rows follow a stencil pattern with positions missing (csr_stenciltile.hpp), and their entries
+    long long stencil_mask_entries = 0;
     int masked_block_tiles = 0; // ... of which: blocks with entries missing or off the grid of column triples (a 32-bit word per block)
     long long masked_block_entries = 0;
     size_t meta_bytes = 0;

@@ -162,6 +162,11 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         const bool uniform = stream_tile && (meta & spmv::kTileMetaUniform);
         const bool block3 = compressed && stream_tile && (meta & spmv::kTileMetaBlock3) && !(meta & spmv::kTileMetaBlockWin) && pl->nvalues == 0
             && !(pl->flags & SPMV_HIP_FLAG_EXACT_ORDER);
+        if (compressed && stream_tile && spmv::is_masked_stencil_tile(meta)) { // no columns, no row_ptr: a 16-bit mask per row
+            pl->shifted_entries += entries;
+            bytes += 8 * entries + 2 * rows + 16 + 16 * rows;
+            continue;
+        }
         if (block3) { // one 16-bit number per 3 x 3 block (masked block tiles: a 32-bit word per block, about one per 8 entries), no row_ptr
             pl->narrow_entries += entries;
             bytes += 8 * entries + ((meta & spmv::kTileMetaBlock3Masked) ? 4 * ((entries + 7) / 8) : 2 * (entries / 9)) + 16 + 16 * rows;
@@ -293,6 +298,11 @@ static void run_on_host_threads(int n, Work && work)
     for (auto & th : pool)
         th.join();
 }
+
+// (7 entries per row: 73 rows per tile, the second pass 14 % full.  3-D 7-point Laplacian on a 256^3 grid, same process pair:
+// 278.0 / 278.9 -> 255.9 / 252.8 us (0.84 -> 0.92 of the roofline) with 64-row tiles, which also sit four to a grid line there;
+// 7 diagonals through the x window 169.0 -> 167.5 us: profiles/r05_results.md)
+constexpr int kSecondPassMinRows = 80;
 
 static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flags, int32_t break_rows, int split_threshold, int split_chunk)
 {
@@ -470,6 +480,24 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             maxlen = std::max(maxlen, len);
             minlen = std::min(minlen, len);
             ++r1;
+        }
+        // A tile of short rows with a handful of rows beyond the wave's 64 lanes: the lane-per-row paths then run every position twice
+        // (rows 0 .. 63, rows 64 ...) for those few rows -- 7 entries per row: 73 rows, the second pass 14 % full.  Below
+        // kSecondPassMinRows rows such a tile ends at 64 rows instead.
+        {
+            int second_min = kSecondPassMinRows;
+#ifdef SPMV_HIP_EXPERIMENTS
+            if (const char * v = std::getenv("SPMV_HIP_SECOND_PASS_MIN_ROWS")) second_min = std::atoi(v); // tools/ab.py
+#endif
+            if (r1 - r > 64 && r1 - r < second_min && maxlen <= spmv::kLanePerRowMaxLen && break_rows == 0 && !triples_only) {
+                r1 = r + 64;
+                maxlen = 0;
+                minlen = INT32_MAX;
+                for (int32_t q = r; q < r1; ++q) {
+                    maxlen = std::max(maxlen, p[q + 1] - p[q]);
+                    minlen = std::min(minlen, p[q + 1] - p[q]);
+                }
+            }
         }
         // block hint: a tile of long rows ends on a triple boundary and holds at most kBlockTileMaxRows rows
         if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
@@ -1265,7 +1293,8 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
     pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
     pl->uniform_tiles = pl->split_rows = pl->long_blocks = pl->multi_window_tiles = 0;
     pl->balanced = false;
-    pl->block_hint = pl->block_cuts = pl->block_tiles = pl->masked_block_tiles = pl->block_candidate = 0;
+    pl->block_hint = pl->block_cuts = pl->block_tiles = pl->masked_block_tiles = pl->block_candidate = pl->stencil_mask_tiles = 0;
+    pl->stencil_mask_entries = 0;
     pl->block_entries = pl->masked_block_entries = 0;
     pl->meta_bytes = 0;
     pl->compressed_from = nullptr;
@@ -1341,6 +1370,147 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
         int rc = confirm_block_candidate(pl, d_row_ptr, d_column_index, stream, reindex, nullptr);
         if (rc != SPMV_HIP_OK)
             return rc;
+    }
+    // masked stencil tiles (csr_stenciltile.hpp): the boundary rows of a structured grid
+    if (pl->stencil_mask_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr && pl->rows >= 64
+        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0 && pl->shifted_tiles < pl->ntiles
+        && !(pl->flags & (SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_READ_ROW_PTR))) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        // (1) the stencils of the matrix, from a sample of its rows
+        constexpr int kSamples = 2048, kRecord = spmv::kStencilMaskMaxLen + 1;
+        const int nsamples = std::min(kSamples, (int) pl->rows);
+        std::vector<int32_t> sample((size_t) nsamples * kRecord);
+        int32_t * d_sample = nullptr;
+        HIP_TRY(hipMalloc((void **) &d_sample, sample.size() * sizeof(int32_t)));
+        hipLaunchKernelGGL(spmv::csr_row_pattern_sample_kernel, dim3((unsigned) ((nsamples + 255) / 256)), dim3(256), 0, s, pl->rows, nsamples, d_row_ptr,
+                           d_column_index, d_sample);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(sample.data(), d_sample, sample.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(d_sample);
+        if (e != hipSuccess)
+            return fail_hip(e, "row pattern sample");
+        std::vector<std::pair<int, std::vector<int32_t>>> found; // (count, {len, rel...})
+        for (int i = 0; i < nsamples; ++i) {
+            const int32_t * o = sample.data() + (size_t) i * kRecord;
+            if (o[0] < 2)
+                continue;
+            std::vector<int32_t> key(o, o + 1 + o[0]);
+            auto it = std::find_if(found.begin(), found.end(), [&](auto const & f) { return f.second == key; });
+            if (it == found.end())
+                found.push_back({1, key});
+            else
+                it->first++;
+        }
+        // frequent = at least 2 % of the sample; the longest first (a boundary row's stencil is a subset of the interior one's)
+        found.erase(std::remove_if(found.begin(), found.end(), [&](auto const & f) { return f.first * 50 < nsamples; }), found.end());
+        std::sort(found.begin(), found.end(), [](auto const & a, auto const & b) {
+            return a.second[0] != b.second[0] ? a.second[0] > b.second[0] : a.first > b.first;
+        });
+        if (found.size() > 4)
+            found.resize(4);
+        // (2) the patterns to try: the sampled ones (appended to the plan's records unless they are there already), then the plan's own
+        std::vector<int32_t> pat;
+        if (pl->npatterns > 0) {
+            pat.resize((size_t) pl->npatterns * spmv::kPatStride);
+            HIP_TRY(hipMemcpy(pat.data(), pl->d_patterns, pat.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        spmv::StencilTryList list{0, {0, 0, 0, 0, 0, 0, 0, 0}};
+        int np = pl->npatterns;
+        for (auto const & f : found) {
+            const int len = f.second[0];
+            int at = -1;
+            for (int q = 0; q < np && at < 0; ++q)
+                if (pat[(size_t) q * spmv::kPatStride] == len
+                    && std::equal(f.second.begin() + 1, f.second.end(), pat.begin() + (size_t) q * spmv::kPatStride + spmv::kPatRel))
+                    at = q;
+            if (at < 0) {
+                at = np++;
+                pat.resize((size_t) np * spmv::kPatStride, 0);
+                int32_t * rec = pat.data() + (size_t) at * spmv::kPatStride;
+                rec[0] = len;
+                rec[1] = 0;       // (no tile shape: a record for masked stencil tiles only)
+                rec[2] = 1 << 20; // no window of runs worked out
+                rec[3] = *std::min_element(f.second.begin() + 1, f.second.end());
+                std::copy(f.second.begin() + 1, f.second.end(), rec + spmv::kPatRel);
+            }
+            list.pattern[list.n++] = at;
+        }
+        for (int q = 0; q < pl->npatterns && list.n < 8; ++q)
+            if (pat[(size_t) q * spmv::kPatStride] <= spmv::kStencilMaskMaxLen
+                && std::find(list.pattern, list.pattern + list.n, q) == list.pattern + list.n)
+                list.pattern[list.n++] = q;
+        if (list.n > 0) {
+            if (np > pl->npatterns) { // the records grew: a new array replaces the plan's
+                int32_t * d_new = nullptr;
+                HIP_TRY(hipMalloc((void **) &d_new, pat.size() * sizeof(int32_t)));
+                e = hipMemcpy(d_new, pat.data(), pat.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    (void) hipFree(d_new);
+                    return fail_hip(e, "stencil patterns");
+                }
+                if (pl->d_patterns)
+                    (void) hipFree(pl->d_patterns);
+                pl->d_patterns = d_new;
+                pl->meta_bytes += (size_t) (np - pl->npatterns) * spmv::kPatStride * sizeof(int32_t);
+                pl->npatterns = np;
+            }
+            // (3) the tiles whose rows all follow one of them.  Where block windows have claimed tiles (a grid with lines so short
+            // that 16 tiles span fewer than 8192 columns), a dry run counts first: if stencil tiles -- shifted and masked -- would be
+            // nine tenths of the matrix, the windows are given up (8 bytes per entry and no second launch against 10)
+            unsigned long long * d_count = nullptr;
+            unsigned long long count[2] = {0, 0};
+            HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
+            for (int dry = (pl->d_blocks || pl->d_segblocks) ? 1 : 0; dry >= 0; --dry) {
+                e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(spmv::csr_stencil_mask_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
+                                       pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16, pl->d_patterns, list, dry, d_count);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = read_striped(d_count, count, 2, s);
+                if (e != hipSuccess)
+                    break;
+                if (dry && 10 * ((long long) count[0] + pl->shifted_tiles) >= 9LL * pl->ntiles) {
+                    if (pl->d_blocks)
+                        hipLaunchKernelGGL(spmv::csr_clear_blockwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
+                    else // (segment windows rewrote their tiles' 16-bit stream to window slots: those tiles go back to 32-bit columns)
+                        hipLaunchKernelGGL(spmv::csr_clear_segwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(s);
+                    if (e != hipSuccess)
+                        break;
+                    if (pl->d_blocks) {
+                        (void) hipFree(pl->d_blocks);
+                        pl->d_blocks = nullptr;
+                        pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nblocks16 * sizeof(int2));
+                        pl->nblocks16 = 0;
+                    }
+                    if (pl->d_segblocks) {
+                        (void) hipFree(pl->d_segblocks);
+                        pl->d_segblocks = nullptr;
+                        pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nsegblocks * sizeof(spmv::SegWinBlock));
+                        pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = 0;
+                    }
+                    pl->blockwin_tiles = 0;
+                    if (pl->d_rest_tiles) {
+                        (void) hipFree(pl->d_rest_tiles);
+                        pl->d_rest_tiles = nullptr;
+                        pl->nrest_tiles = 0;
+                    }
+                }
+            }
+            (void) hipFree(d_count);
+            if (e != hipSuccess)
+                return fail_hip(e, "masked stencil tiles");
+            pl->stencil_mask_tiles = (int) count[0];
+            pl->stencil_mask_entries = (long long) count[1];
+            if (count[0] > 0) {
+                int rc = plan_account(pl, true);
+                if (rc != SPMV_HIP_OK)
+                    return rc;
+            }
+        }
     }
     // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
     if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
@@ -1748,7 +1918,7 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[33] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[35] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
@@ -1756,8 +1926,9 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
                            pl->segwin_tiles, pl->segwin_slots, pl->nvalues > 0 ? pl->value_row_tiles : 0,
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
                            pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles,
-                           pl->ngroup_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_entries};
-    for (int i = 0; i < n && i < 33; ++i)
+                           pl->ngroup_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_entries,
+                           pl->stencil_mask_tiles, pl->stencil_mask_entries};
+    for (int i = 0; i < n && i < 35; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -312,13 +312,13 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(33, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 33))
+        out = np.zeros(35, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 35))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
                 "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
                 "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles",
-                "masked_block_tiles", "masked_block_entries"]
+                "masked_block_tiles", "masked_block_entries", "stencil_mask_tiles", "stencil_mask_entries"]
         return dict(zip(keys, out.tolist()))
 
     def compress(self, d_col, stream=0):

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""A zoo of matrix structures that are NOT among BASELINE's configurations, each through the default plan (Level 2, values read):
+launch time, SURVEY 8(d)'s fraction (algorithmic bytes / time / 8 TB/s), streamed bytes of the triad, and the tile classes the plan
+chose -- a look-out for cliffs between the classes (a structure one step away from a stand-in that falls to half its speed).
+
+    python tools/structure_zoo.py [name ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spmv-cache-trace_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def stencil3d(n, offsets, seed=1):
+    """n^3 grid, one unknown per cell, the given (dz, dy, dx) neighbours where they exist."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    z, y, x = z.ravel(), y.ravel(), x.ravel()
+    cols, ok = [], []
+    for dz, dy, dx in sorted(offsets):
+        zz, yy, xx = z + dz, y + dy, x + dx
+        good = (zz >= 0) & (zz < n) & (yy >= 0) & (yy < n) & (xx >= 0) & (xx < n)
+        cols.append(np.where(good, (zz * n + yy) * n + xx, 0))
+        ok.append(good)
+    cols, ok = np.stack(cols, axis=1), np.stack(ok, axis=1)
+    lens = ok.sum(axis=1)
+    p = np.zeros(n ** 3 + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    c = cols[ok].astype(np.int32)
+    return n ** 3, n ** 3, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
+
+
+def zoo():
+    from spmv_amd import synth
+    seven = [(0, 0, 0), (0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)]
+    nineteen = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if abs(a) + abs(b) + abs(c) <= 2]
+    out = {
+        "stencil7_256^3": lambda: stencil3d(256, seven),
+        "stencil19_160^3": lambda: stencil3d(160, nineteen),
+        "stencil27_160^3": lambda: synth.stencil27_like(160, 160, 160),
+        "band9": lambda: synth.banded(8000000, list(range(-4, 5)), seed=2),
+        "band17": lambda: synth.banded(6000000, list(range(-8, 9)), seed=2),
+        "band18": lambda: synth.banded(6000000, list(range(-8, 10)), seed=2),
+        "band65": lambda: synth.banded(2000000, list(range(-32, 33)), seed=2),
+        "band129": lambda: synth.banded(1000000, list(range(-64, 65)), seed=2),
+        "band161": lambda: synth.banded(800000, list(range(-80, 81)), seed=2),
+        "far_diagonals_11": lambda: synth.banded(6000000, [-2000000, -70000, -300, -2, -1, 0, 1, 2, 300, 70000, 2000000], seed=5),
+    }
+
+    def ragged(rows, lo, hi, reach, seed):
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(lo, hi + 1, size=rows)
+        p = np.zeros(rows + 1, dtype=np.int64)
+        np.cumsum(lens, out=p[1:])
+        base = np.repeat(np.arange(rows, dtype=np.int64), lens)
+        c = np.clip(base + rng.integers(-reach, reach + 1, size=int(p[-1])), 0, rows - 1)
+        # ascending within a row
+        order = np.lexsort((c, base))
+        c = c[order].astype(np.int32)
+        return rows, rows, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
+    out["ragged_1-8_near"] = lambda: ragged(8000000, 1, 8, 2000, 3)
+    out["ragged_4-40_near"] = lambda: ragged(3000000, 4, 40, 5000, 4)
+    out["ragged_20-100_near"] = lambda: ragged(1200000, 20, 100, 20000, 5)
+    out["ragged_4-40_far"] = lambda: ragged(3000000, 4, 40, 1500000, 6)
+    return out
+
+
+def main():
+    import torch
+    from spmv_amd import capi, synth
+    import perf_floor
+    names = sys.argv[1:]
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    triad = perf_floor.measure_triad()
+    print("triad %.0f GB/s" % triad)
+    for name, make in zoo().items():
+        if names and name not in names:
+            continue
+        t0 = time.perf_counter()
+        rows, cols, p, c, v = make()
+        nnz = int(p[-1])
+        tp, tc, tv = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v))
+        tx = torch.from_numpy(synth.x_vector(cols, seed=3)).to(dev)
+        ty = torch.zeros(rows, dtype=torch.float64, device=dev)
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_NO_VALUE_INDEX)
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        info = plan.info()
+        ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr())
+        best = None
+        for rnd in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                plan.spmv(*ptrs, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 10 * 1e3
+            if rnd > 0:
+                best = us if best is None else min(best, us)
+        alg = synth.csr_bytes(rows, cols, nnz)
+        print("%-22s %9d rows %6.1f/row  %8.1f us  frac(8d) %.3f  streamed/triad %.3f  tiles %d: narrow %d shifted %d xwin %d blockwin %d segwin %d panels %d block %d multi %d long %d balanced %d stencil-masked %d  (setup %.0f s)"
+              % (name, rows, nnz / rows, best, alg / (best * 1e-6) / 8e12, info["streamed_bytes"] / (best * 1e-6) / 1e9 / triad, info["row_blocks"],
+                 info["narrow_tiles"], info["shifted_tiles"], info["xwin_tiles"], info["blockwin_tiles"], info["segwin_tiles"], info["panel_tiles"],
+                 info["block_tiles"], info["multi_window_tiles"], info["long_blocks"], info["balanced"], info["stencil_mask_tiles"], time.perf_counter() - t0), flush=True)
+        plan.close()
+        del tp, tc, tv, tx, ty
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
