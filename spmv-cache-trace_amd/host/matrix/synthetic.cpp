@@ -221,6 +221,37 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
     return build(N, N, rb, re, len, fill);
 }
 
+// ---- poisson3d: the 7-point Laplacian on an n^3 grid (x fastest), values hashed like poisson2d's pessimistic twin -----
+// What the 2-D stand-in of BASELINE configs[1] looks like one dimension up: grid lines of n cells, so that with n = 256 every
+// tile of 64 ... 73 rows holds the end of a line (round 5: masked stencil tiles, csr_stenciltile.hpp).
+csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long * total)
+{
+    if (n < 1 || n > 1290)
+        throw matrix::matrix_error("synthetic:poisson3d: grid edge must be in 1..1290");
+    long long const N = n * n * n;
+    if (total) *total = N;
+    if (re < 0) re = N;
+    auto len = [n](long long r) {
+        long long const x = r % n, y = (r / n) % n, z = r / (n * n);
+        return 1 + (x > 0) + (x < n - 1) + (y > 0) + (y < n - 1) + (z > 0) + (z < n - 1);
+    };
+    auto fill = [n](long long r, index_type * c, double * v) {
+        long long const x = r % n, y = (r / n) % n, z = r / (n * n);
+        index_type * const c0 = c;
+        double * const v0 = v;
+        if (z > 0) { *c++ = (index_type) (r - n * n); *v++ = -1.0; }
+        if (y > 0) { *c++ = (index_type) (r - n); *v++ = -1.0; }
+        if (x > 0) { *c++ = (index_type) (r - 1); *v++ = -1.0; }
+        *c++ = (index_type) r; *v++ = 6.0;
+        if (x < n - 1) { *c++ = (index_type) (r + 1); *v++ = -1.0; }
+        if (y < n - 1) { *c++ = (index_type) (r + n); *v++ = -1.0; }
+        if (z < n - 1) { *c++ = (index_type) (r + n * n); *v++ = -1.0; }
+        for (long long q = 0; q < v - v0; ++q)
+            v0[q] *= 1.0 + 0.25 * u11(h2(0x9015507ull + (std::uint64_t) r, (std::uint64_t) c0[q]));
+    };
+    return build(N, N, rb, re, len, fill);
+}
+
 // ---- queen: 3 unknowns per node of a jittered mesh, symmetric structure, dense 3x3 blocks ------------
 // The less tidy twins (round 5; what real finite-element files do): `broken` per mille of the off-diagonal 3 x 3 blocks have one
 // or two of their nine entries missing (explicit zeros the assembly dropped), and with `odd_every` = K > 0 every K-th node has
@@ -631,6 +662,13 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
             throw matrix::matrix_error("synthetic:poisson2d: grid edge must be in 1..46340");
         check_range(v[0] * v[0]);
         A = poisson2d(v[0], rb, re, &tot, v.size() > 1 ? v[1] : 0);
+    } else if (family == "poisson3d") {
+        if (v.size() != 1)
+            throw matrix::matrix_error("synthetic:poisson3d:<n> takes one number");
+        if (v[0] < 1 || v[0] > 1290)
+            throw matrix::matrix_error("synthetic:poisson3d: grid edge must be in 1..1290");
+        check_range(v[0] * v[0] * v[0]);
+        A = poisson3d(v[0], rb, re, &tot);
     } else if (family == "kkt") {
         if (v.size() > 2)
             throw matrix::matrix_error("synthetic:kkt[:<n>[,<jitter %>]] takes at most two numbers");
@@ -668,7 +706,7 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
             : family == "scrambled" ? scrambled(v[0], v[1], seed, rb, re, &tot) : random_columns(v[0], v[1], seed, rb, re, &tot);
     } else {
         throw matrix::matrix_error("unknown synthetic matrix family '" + family +
-                                   "' (poisson2d, queen, kkt, webbase, powerlaw, banded, scrambled, random)");
+                                   "' (poisson2d, poisson3d, queen, kkt, webbase, powerlaw, banded, scrambled, random)");
     }
     if (total)
         *total = tot;

@@ -217,3 +217,28 @@ def test_out_of_range_specs_are_refused_before_any_arithmetic_on_them(spec):
     """products of numbers parsed from the command line are formed only after each factor has been bounded."""
     with pytest.raises(hostapi.HostError):
         hostapi.load(spec)
+
+
+def test_poisson3d_family():
+    """synthetic:poisson3d:<n>: the 7-point Laplacian on an n^3 grid, x fastest; rows on the faces lack the neighbours outside."""
+    n = 7
+    A = hostapi.load("synthetic:poisson3d:%d" % n, "csr")
+    p, c, v = np.asarray(A.row_ptr), np.asarray(A.column_index), np.asarray(A.value)
+    assert A.rows == A.cols == n ** 3 and p[-1] == 7 * n ** 3 - 6 * n * n
+    lens = np.diff(p)
+    r = (3 * n + 3) * n + 3  # an interior cell
+    assert lens[r] == 7 and np.array_equal(c[p[r]:p[r + 1]], [r - n * n, r - n, r - 1, r, r + 1, r + n, r + n * n])
+    assert lens[0] == 4 and np.array_equal(c[p[0]:p[1]], [0, 1, n, n * n])
+    assert all(np.all(np.diff(c[p[i]:p[i + 1]]) > 0) for i in range(A.rows))
+    # symmetric structure, positive diagonal
+    import scipy.sparse as sp
+    M = sp.csr_matrix((v, c, p), shape=(A.rows, A.cols))
+    assert (abs(M) > 0).astype(int).T.tocsr().nnz == M.nnz and ((abs(M) > 0) != (abs(M.T) > 0)).nnz == 0
+    assert np.all(M.diagonal() > 4.0)
+    part = hostapi.load("synthetic:poisson3d:%d" % n, "csr", row_begin=100, row_end=200) if "row_begin" in hostapi.load.__code__.co_varnames else None
+    if part is not None:
+        assert np.array_equal(np.asarray(part.column_index), c[p[100]:p[200]])
+        part.close()
+    A.close()
+    with pytest.raises(hostapi.HostError):
+        hostapi.load("synthetic:poisson3d:5000")

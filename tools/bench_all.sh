@@ -41,6 +41,10 @@ run kkt_csr_noshift --workload kkt --flags 0x400
 run kkt_csr_jitter50 --matrix synthetic:kkt:200,50
 run queen_csr_jitter6 --matrix synthetic:queen:110,71,177,6
 run queen_csr_noblocks --workload queen --flags 0x2000000
+# round 5: the less tidy twins of the queen-like stand-in (masked block tiles) and the 7-point Laplacian on a 256^3 grid (masked stencil tiles)
+run queen_csr_broken2pct --matrix synthetic:queen:110,71,177,3,20
+run queen_csr_oddnodes --matrix synthetic:queen:110,71,177,3,20,1000
+run poisson3d_csr --matrix synthetic:poisson3d:256
 # the launches of tests/test_gpu_perf_floor.py measured on this box -- measured and logged only: updating the committed table
 # (tests/golden/perf_floor.json) is an explicit, reviewed step (python3 tools/perf_floor.py --write), never a side effect of a
 # sweep, or a regressed build run through this script would loosen the very floor that exists to catch it

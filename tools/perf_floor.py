@@ -51,6 +51,7 @@ WORKLOADS = {
     "banded4001_ell": ("synthetic:banded:50000,2000", "ell", 0),          # ELLPACK rows of more than 2048 entries: a wave per row, in registers (round 5)
     "banded2001_csr": ("synthetic:banded:100000,1000", "csr", 0),         # CSR rows of more than 1024 entries: the same path
     "queen_small_broken_csr": ("synthetic:queen:80,60,60,3,20,500", "csr", 0),  # masked block tiles (round 5): dropped entries, odd nodes
+    "poisson3d_256_csr": ("synthetic:poisson3d:256", "csr", 0x100000),   # grid lines of 256 cells: masked stencil tiles (round 5), values read
 }
 
 
