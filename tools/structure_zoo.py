@@ -34,6 +34,24 @@ def stencil3d(n, offsets, seed=1):
     return n ** 3, n ** 3, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
 
 
+def stencil3d_2d(n, seed=1):
+    """5-point stencil on an n x n grid (lines of n cells)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    y, x = y.ravel(), x.ravel()
+    cols, ok = [], []
+    for dy, dx in [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)]:
+        yy, xx = y + dy, x + dx
+        good = (yy >= 0) & (yy < n) & (xx >= 0) & (xx < n)
+        cols.append(np.where(good, yy * n + xx, 0))
+        ok.append(good)
+    cols, ok = np.stack(cols, axis=1), np.stack(ok, axis=1)
+    p = np.zeros(n * n + 1, dtype=np.int64)
+    np.cumsum(ok.sum(axis=1), out=p[1:])
+    c = cols[ok].astype(np.int32)
+    return n * n, n * n, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
+
+
 def zoo():
     from spmv_amd import synth
     seven = [(0, 0, 0), (0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)]
@@ -42,6 +60,9 @@ def zoo():
         "stencil7_256^3": lambda: stencil3d(256, seven),
         "stencil19_160^3": lambda: stencil3d(160, nineteen),
         "stencil27_160^3": lambda: synth.stencil27_like(160, 160, 160),
+        "stencil27_128^3_real": lambda: stencil3d(128, [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]),  # HPCG's matrix
+        "stencil7_100^3": lambda: stencil3d(100, seven),
+        "stencil5_2d_1500^2": lambda: stencil3d_2d(1500),
         "band9": lambda: synth.banded(8000000, list(range(-4, 5)), seed=2),
         "band17": lambda: synth.banded(6000000, list(range(-8, 9)), seed=2),
         "band18": lambda: synth.banded(6000000, list(range(-8, 10)), seed=2),
