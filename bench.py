@@ -1386,7 +1386,10 @@ def main():
                            "block_window_tiles": info["blockwin_tiles"], "column_panel_tiles": info["panel_tiles"],
                            "balanced_tiles": bool(info["balanced"]), "value_dictionary_size": info["indexed_values"],
                            "tiles_reading_no_value_stream": info.get("value_row_tiles", 0),
-                           "tiles_of_the_dictionary_launch": info.get("dictionary_launch_tiles", 0)})
+                           "tiles_of_the_dictionary_launch": info.get("dictionary_launch_tiles", 0),
+                           "block_tiles": info.get("block_tiles", 0), "masked_block_tiles": info.get("masked_block_tiles", 0),
+                           "masked_stencil_tiles": info.get("stencil_mask_tiles", 0), "multi_window_tiles": info.get("multi_window_tiles", 0),
+                           "long_row_tiles": info.get("long_blocks", 0)})
         else:
             config.update({"ell_row_length": getattr(keep, "row_length", None), "coo_remainder_entries": getattr(keep, "num_coo_entries", None),
                            "tiles": info["row_blocks"], "shifted_tiles": info["shifted_tiles"],

@@ -1371,7 +1371,64 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
         if (rc != SPMV_HIP_OK)
             return rc;
     }
-    // masked stencil tiles (csr_stenciltile.hpp): the boundary rows of a structured grid
+    // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
+    if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
+        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
+        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES))) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        unsigned long long * d_count = nullptr;
+        unsigned long long count[6] = {0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
+                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),
+                               reinterpret_cast<uint32_t *>(pl->d_col16 + spmv::mask_stream_offset(pl->nnz)), pl->nnz, pl->cols,
+                               (pl->flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS) ? 0 : 1, d_count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = read_striped(d_count, count, 6, s);
+        pl->masked_block_tiles = (int) count[4];
+        pl->masked_block_entries = (long long) count[5];
+        (void) hipFree(d_count);
+        if (e != hipSuccess)
+            return fail_hip(e, "block tiles");
+        pl->block_tiles = (int) count[2];
+        pl->block_entries = (long long) count[3];
+        // Block tiles and block windows (x staged through LDS per 16 tiles, 10 bytes per entry) want the same narrow tiles: where
+        // most of the matrix consists of blocks the windows are given up -- 8.2 bytes per entry and no second launch
+        if (pl->d_blocks && 2 * (long long) count[0] > pl->ntiles) {
+            hipLaunchKernelGGL(spmv::csr_clear_blockwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            (void) hipFree(pl->d_blocks);
+            pl->d_blocks = nullptr;
+            pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nblocks16 * sizeof(int2));
+            pl->nblocks16 = 0;
+            pl->blockwin_tiles = 0;
+            if (pl->d_rest_tiles) {
+                (void) hipFree(pl->d_rest_tiles);
+                pl->d_rest_tiles = nullptr;
+                pl->nrest_tiles = 0;
+            }
+            pl->block_tiles = (int) count[0];
+            pl->block_entries = (long long) count[1];
+        }
+        if (pl->block_cuts > 0 && 2 * (long long) count[0] < pl->ntiles) {
+            // The hint was wrong (rows in equal triples, but no 3 x 3 blocks: a scalar mesh, a band) AND it made tiles shorter
+            // than they would have been: the tiles are built once more without it, from row_ptr fetched back from the device,
+            // and classified again -- plan time only, and only for such matrices.
+            int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, nullptr, reindex);
+            if (rc != SPMV_HIP_OK)
+                return rc;
+        } else if (pl->block_tiles > 0) {
+            int rc = plan_account(pl, true);
+            if (rc != SPMV_HIP_OK)
+                return rc;
+        }
+    }
+    // masked stencil tiles (csr_stenciltile.hpp): the boundary rows of a structured grid (after the block stage: should that one
+    // cut the tiles anew -- a wrong hint -- the marks made here would go with the old tiles)
     if (pl->stencil_mask_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr && pl->rows >= 64
         && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0 && pl->shifted_tiles < pl->ntiles
         && !(pl->flags & (SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_READ_ROW_PTR))) {
@@ -1510,62 +1567,6 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
                 if (rc != SPMV_HIP_OK)
                     return rc;
             }
-        }
-    }
-    // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
-    if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
-        && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
-        && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES))) {
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        unsigned long long * d_count = nullptr;
-        unsigned long long count[6] = {0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
-                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),
-                               reinterpret_cast<uint32_t *>(pl->d_col16 + spmv::mask_stream_offset(pl->nnz)), pl->nnz, pl->cols,
-                               (pl->flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS) ? 0 : 1, d_count);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = read_striped(d_count, count, 6, s);
-        pl->masked_block_tiles = (int) count[4];
-        pl->masked_block_entries = (long long) count[5];
-        (void) hipFree(d_count);
-        if (e != hipSuccess)
-            return fail_hip(e, "block tiles");
-        pl->block_tiles = (int) count[2];
-        pl->block_entries = (long long) count[3];
-        // Block tiles and block windows (x staged through LDS per 16 tiles, 10 bytes per entry) want the same narrow tiles: where
-        // most of the matrix consists of blocks the windows are given up -- 8.2 bytes per entry and no second launch
-        if (pl->d_blocks && 2 * (long long) count[0] > pl->ntiles) {
-            hipLaunchKernelGGL(spmv::csr_clear_blockwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(s));
-            (void) hipFree(pl->d_blocks);
-            pl->d_blocks = nullptr;
-            pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nblocks16 * sizeof(int2));
-            pl->nblocks16 = 0;
-            pl->blockwin_tiles = 0;
-            if (pl->d_rest_tiles) {
-                (void) hipFree(pl->d_rest_tiles);
-                pl->d_rest_tiles = nullptr;
-                pl->nrest_tiles = 0;
-            }
-            pl->block_tiles = (int) count[0];
-            pl->block_entries = (long long) count[1];
-        }
-        if (pl->block_cuts > 0 && 2 * (long long) count[0] < pl->ntiles) {
-            // The hint was wrong (rows in equal triples, but no 3 x 3 blocks: a scalar mesh, a band) AND it made tiles shorter
-            // than they would have been: the tiles are built once more without it, from row_ptr fetched back from the device,
-            // and classified again -- plan time only, and only for such matrices.
-            int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, nullptr, reindex);
-            if (rc != SPMV_HIP_OK)
-                return rc;
-        } else if (pl->block_tiles > 0) {
-            int rc = plan_account(pl, true);
-            if (rc != SPMV_HIP_OK)
-                return rc;
         }
     }
     // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
