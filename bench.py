@@ -693,6 +693,7 @@ def build_plan_timed(torch, capi, rows, cols, p, tp, tc, tv, algo, lanes, flags,
         return out
     plan = stage("tiles_from_host_row_ptr", lambda: capi.CsrPlan(rows, cols, p, algo, lanes, flags))
     if not (flags & capi.FLAG_NO_INDEX_COMPRESSION):
+        stage("confirm_blocks (row groups of a block-tile candidate, tiles cut on them)", lambda: plan.confirm_blocks(tp.data_ptr(), tc.data_ptr(), p, stream))
         stage("compress (tile classes, 16-bit columns, patterns, windows)", lambda: plan.compress(tc.data_ptr(), stream))
         stage("repack (column panels, where the matrix is scattered)", lambda: plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream))
         stage("index_values (dictionary, constant-row marks, re-cut tiles)", lambda: plan.index_values(tv.data_ptr(), stream))

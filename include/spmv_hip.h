@@ -305,6 +305,15 @@ int spmv_hip_plan_csr(spmv_hip_plan **plan, int32_t rows, int32_t cols,
  * latency-sensitive first call.  The check is skipped (left pending) while `stream` is being captured into a
  * graph.  Two host threads may share a plan: the pending check is claimed atomically by one of them. */
 int spmv_hip_plan_csr_compress(spmv_hip_plan *plan, const int32_t *d_column_index, void *stream);
+/* Optional, BEFORE spmv_hip_plan_csr_compress (spmv_hip_upload_csr does it): a plan whose rows are mostly longer than 16 entries and about
+ * as long as their successors is a CANDIDATE for (masked) block tiles -- three unknowns per mesh node, with or without entries
+ * missing.  This call looks at the columns (which rows have the same columns as the row in front of them?) and, if half of the
+ * rows stand in groups of three, cuts the plan's tiles once more on those groups, so that they are classified ONCE; without it
+ * spmv_hip_plan_csr_repack does the same after the classification and classifies again (queen-like with broken blocks: 51 instead
+ * of ~35 ms of plan time).  host_row_ptr: the array given to spmv_hip_plan_csr, or NULL (row_ptr is then fetched back from the
+ * device).  A no-op for every other plan, and after spmv_hip_plan_csr_compress.  Synchronises `stream`. */
+int spmv_hip_plan_csr_confirm_blocks(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
+                                     const int32_t *host_row_ptr, void *stream);
 /* Content guard on demand: SPMV_HIP_OK if d_column_index is not the array the plan was compressed from
  * (nothing derived will be used) or still has the same contents; SPMV_HIP_ERR_STATE if the contents
  * changed.  One pass over the array; synchronises `stream`. */

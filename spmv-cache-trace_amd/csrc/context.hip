@@ -270,7 +270,7 @@ int spmv_hip_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nn
     }
     if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
         // a candidate for (masked) block tiles is confirmed -- and its tiles cut on the row groups -- before they are classified
-        if ((rc = spmv_hip_internal_plan_confirm_blocks(c->plan, c->d_ptr, c->d_col, row_ptr, c->stream)) != 0) return rc;
+        if ((rc = spmv_hip_plan_csr_confirm_blocks(c->plan, c->d_ptr, c->d_col, row_ptr, c->stream)) != 0) return rc;
         if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
         // scattered columns and an x that does not fit one XCD's L2: column panels (the context owns
         // the arrays, so the snapshot of the values cannot go stale)
@@ -359,7 +359,7 @@ static int ctx_plan_device_csr(spmv_hip_ctx * c, const std::vector<int32_t> & ho
     if (rc != 0)
         return rc;
     if (!(c->flags & SPMV_HIP_FLAG_NO_INDEX_COMPRESSION)) {
-        if ((rc = spmv_hip_internal_plan_confirm_blocks(c->plan, c->d_ptr, c->d_col, host_ptr.data(), c->stream)) != 0) return rc;
+        if ((rc = spmv_hip_plan_csr_confirm_blocks(c->plan, c->d_ptr, c->d_col, host_ptr.data(), c->stream)) != 0) return rc;
         if ((rc = spmv_hip_plan_csr_compress(c->plan, c->d_col, c->stream)) != 0) return rc;
         if ((rc = spmv_hip_plan_csr_repack(c->plan, c->d_ptr, c->d_col, c->d_val, c->stream)) != 0) return rc;
         if ((rc = spmv_hip_plan_csr_index_values(c->plan, c->d_val, c->stream)) != 0) return rc;

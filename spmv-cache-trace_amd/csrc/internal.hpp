@@ -245,9 +245,6 @@ int multi_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns);
 
 } // namespace spmvi
 
-// plan_csr.hip: a block-tile candidate confirmed (and its tiles cut on the row groups) BEFORE the plan is compressed
-extern "C" int spmv_hip_internal_plan_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
-                                                     const int32_t * host_row_ptr, void * stream);
 // coo_sort.hip
 extern "C" int spmv_hip_internal_exclusive_scan_i32(const int32_t * d_in, int32_t * d_out, long long n, hipStream_t s);
 extern "C" int spmv_hip_internal_coo_panels(int32_t cols, int32_t nnz, const int32_t * d_row, const int32_t * d_col, const double * d_val,

@@ -1228,7 +1228,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     return rc;
 }
 
-int spmv_hip_internal_plan_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+int spmv_hip_plan_csr_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
                                           const int32_t * host_row_ptr, void * stream);
 
 int spmv_hip_plan_verify(spmv_hip_plan * pl, const int32_t * d_column_index, void * stream)
@@ -1353,8 +1353,7 @@ static int confirm_block_candidate(spmv_hip_plan * pl, const int32_t * d_row_ptr
     return SPMV_HIP_OK;
 }
 
-// (not part of the public header: spmv_hip_upload_csr calls it between spmv_hip_plan_csr and spmv_hip_plan_csr_compress)
-int spmv_hip_internal_plan_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
+int spmv_hip_plan_csr_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index,
                                           const int32_t * host_row_ptr, void * stream)
 {
     if (!pl || pl->d_col16)

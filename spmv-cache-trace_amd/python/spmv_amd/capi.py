@@ -78,6 +78,7 @@ SIGNATURES = {
     "spmv_hip_plan_csr_index_values": (C.c_int, [_vp, _vp, _vp]),
     "spmv_hip_plan_destroy": (None, [_vp]),
     "spmv_hip_plan_info": (C.c_int, [_vp, _i64p, C.c_int]),
+    "spmv_hip_plan_csr_confirm_blocks": (C.c_int, [_vp, _vp, _vp, C.c_void_p, _vp]),
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_csr_spmv_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_csr_spmv_out_peers": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _vp]),
@@ -320,6 +321,11 @@ class CsrPlan:
                 "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles",
                 "masked_block_tiles", "masked_block_entries", "stencil_mask_tiles", "stencil_mask_entries"]
         return dict(zip(keys, out.tolist()))
+
+    def confirm_blocks(self, d_row_ptr, d_col, host_row_ptr=None, stream=0):
+        """Before compress: a candidate for (masked) block tiles gets its tiles cut on the row groups found in the columns."""
+        hp = None if host_row_ptr is None else np.ascontiguousarray(host_row_ptr, dtype=np.int32)
+        check(self.lib.spmv_hip_plan_csr_confirm_blocks(self.h, d_row_ptr, d_col, None if hp is None else hp.ctypes.data, stream))
 
     def compress(self, d_col, stream=0):
         """16-bit column offsets for the tiles that allow it (wave-tile algorithm only)."""

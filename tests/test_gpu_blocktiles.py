@@ -506,3 +506,46 @@ def test_queen_twins_through_the_context(oracle, spec):
         ctx.set_x(x)
         ctx.run()
         assert_close(ctx.get_y(), want, scale, what=spec + " coo upload", nterms=110)
+
+
+def test_confirm_blocks_before_compress_gives_the_same_plan(oracle):
+    """spmv_hip_plan_csr_confirm_blocks between plan and compress (what spmv_hip_upload_csr does): the candidate's tiles are cut on
+    the row groups BEFORE they are classified, so that the classification runs once; the plan ends up with the same tiles and the
+    same bits as when spmv_hip_plan_csr_repack finds the groups after the classification.  A no-op on a matrix without blocks."""
+    import torch
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    rows, cols, p, c, v = fem_ragged(5000, 20, 30, seed=21, drop=0.08, odd_every=61)
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
+    got, infos = {}, {}
+    for how in ("repack finds the groups", "confirm_blocks first", "confirm_blocks, row_ptr fetched back"):
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_NO_VALUE_INDEX)
+        if how != "repack finds the groups":
+            before = plan.info()["row_blocks"]
+            plan.confirm_blocks(tp.data_ptr(), tc.data_ptr(), p if how == "confirm_blocks first" else None, stream)
+            assert plan.info()["row_blocks"] != before  # the tiles were cut anew
+        plan.compress(tc.data_ptr(), stream)
+        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+        infos[how] = plan.info()
+        ty = torch.from_numpy(y0.copy()).to(dev)
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got[how] = ty.cpu().numpy()
+        plan.close()
+    ref = infos["repack finds the groups"]
+    assert ref["masked_block_tiles"] > 0
+    for how in got:
+        assert (infos[how]["row_blocks"], infos[how]["block_tiles"], infos[how]["masked_block_tiles"]) == (ref["row_blocks"], ref["block_tiles"], ref["masked_block_tiles"]), how
+        assert_bitexact(got[how], got["repack finds the groups"], how)
+    assert_close(got["confirm_blocks first"], want, abs_products(rows, p, c, v, x) + np.abs(y0), what="confirm_blocks", nterms=93)
+    # no candidate, nothing to do
+    r2, c2n, p2, cc2, v2 = synth.poisson2d(80)
+    plan = capi.CsrPlan(r2, c2n, p2, capi.CSR_AUTO, 0, 0)
+    tp2, tc2 = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p2, cc2))
+    before = plan.info()["row_blocks"]
+    plan.confirm_blocks(tp2.data_ptr(), tc2.data_ptr(), p2, stream)
+    assert plan.info()["row_blocks"] == before
+    plan.close()
