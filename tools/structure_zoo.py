@@ -83,6 +83,33 @@ def zoo():
         order = np.lexsort((c, base))
         c = c[order].astype(np.int32)
         return rows, rows, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
+    def queen_dof_major():
+        # the queen-like mesh (3 unknowns per node) numbered dof by dof -- all x unknowns, then all y, then all z -- instead of node by
+        # node: the same matrix, no 3 x 3 blocks in consecutive rows, three clusters of columns a third of the matrix apart
+        from spmv_amd import hostapi
+        import scipy.sparse as sp
+        Q = hostapi.load("synthetic:queen:100,80,70", "csr")
+        A = sp.csr_matrix((np.array(Q.value), np.array(Q.column_index), np.array(Q.row_ptr)), shape=(Q.rows, Q.cols))
+        Q.close()
+        n = A.shape[0] // 3
+        perm = np.concatenate([np.arange(n) * 3 + d for d in range(3)])
+        B = A[perm][:, perm].tocsr()
+        B.sort_indices()
+        return B.shape[0], B.shape[1], B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data
+    out["queen_dof_major"] = queen_dof_major
+
+    def queen_dof_major_rcm():
+        # ... and what reverse Cuthill-McKee makes of it (scipy's here; the product's is the "__RCM" path suffix): the three unknowns of
+        # a node have the same neighbours, so they come out next to each other again -- groups of three rows with the same columns
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        rows, cols, p, c, v = queen_dof_major()
+        A = sp.csr_matrix((v, c, p), shape=(rows, cols))
+        order = reverse_cuthill_mckee(A, symmetric_mode=True)
+        B = A[order][:, order].tocsr()
+        B.sort_indices()
+        return rows, cols, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data
+    out["queen_dof_major_rcm"] = queen_dof_major_rcm
     out["ragged_1-8_near"] = lambda: ragged(8000000, 1, 8, 2000, 3)
     out["ragged_4-40_near"] = lambda: ragged(3000000, 4, 40, 5000, 4)
     out["ragged_20-100_near"] = lambda: ragged(1200000, 20, 100, 20000, 5)
@@ -108,7 +135,7 @@ def main():
         tp, tc, tv = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v))
         tx = torch.from_numpy(synth.x_vector(cols, seed=3)).to(dev)
         ty = torch.zeros(rows, dtype=torch.float64, device=dev)
-        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_NO_VALUE_INDEX)
+        plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, capi.FLAG_NO_VALUE_INDEX | int(os.environ.get("ZOO_FLAGS", "0"), 0))
         plan.compress(tc.data_ptr(), stream)
         plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
         info = plan.info()
