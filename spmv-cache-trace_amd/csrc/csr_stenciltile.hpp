@@ -12,7 +12,8 @@
 // ONE LANE PER ROW like tile_rows_uniform_values: the tile's values are loaded coalesced and parked in the wave's LDS slice, where
 // a row's values start follows from a prefix sum of the rows' mask counts (one DPP scan), x is read 512 contiguous bytes per
 // position (clamped into x where the neighbour does not exist), and every row is added left to right by one lane in column order:
-// the reference's bits (src/matrix/csr-matrix-spmv.cpp:29-32).  No column index, no row_ptr: 8 bytes per entry + 2 per row.
+// the reference's bits (src/matrix/csr-matrix-spmv.cpp:29-32).  No column index, no row_ptr: 8 bytes per entry + 2 per row (under a
+// value dictionary: 1 byte per entry + 2 per row).
 #pragma once
 
 #include "tile_common.hpp"
@@ -27,13 +28,27 @@ __device__ __host__ __forceinline__ bool is_masked_stencil_tile(int meta)
 }
 constexpr int kStencilMaskMaxLen = 16; // positions of the pattern = bits of a row's mask
 
-template <int QUADS, bool X32>
+// VI: the plan holds a value dictionary (a constant-coefficient Laplacian: two values): the tile's values are one index BYTE per entry
+// (vit, 512 bytes per tile parked as two dwords per lane) and the doubles come out of the dictionary, like tile_rows_uniform_indexed.
+template <int QUADS, bool X32, bool VI>
 __device__ __forceinline__ void tile_rows_masked_stencil(
     double * prod, const int32_t * __restrict__ rel /* the pattern's relative columns */, int len, const uint16_t * __restrict__ rowmask /* j16 + k0 */,
-    const double * __restrict__ at, const double * __restrict__ x, int cols, int r0, int last, int lane, int lead, int nrows, double & zA, double & zB)
+    const double * __restrict__ at, const uint8_t * __restrict__ vit, ValueLookup vtab, const double * __restrict__ x, int cols, int r0, int last,
+    int lane, int lead, int nrows, double & zA, double & zB)
 {
+    static_assert(!VI || QUADS == 2, "the index bytes of a 512-entry tile are two dwords per lane");
     TileValues<QUADS, false> vals;
-    vals.load(at, nullptr, last, lane);
+    unsigned vi[2] = {0u, 0u};
+    if (VI) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int o = 256 * q + 4 * lane;
+            o = o < last ? o : last; // lanes past the tile's end re-read its last dword (and park it where nobody looks)
+            vi[q] = *reinterpret_cast<const unsigned *>(vit + o);
+        }
+    } else {
+        vals.load(at, nullptr, last, lane);
+    }
     const bool second = nrows > kWave; // wave-uniform
     const int rowA = lane < nrows ? lane : nrows - 1;
     const int rowB = lane + kWave < nrows ? lane + kWave : nrows - 1;
@@ -45,18 +60,25 @@ __device__ __forceinline__ void tile_rows_masked_stencil(
     const int total_a = __builtin_amdgcn_readlane(incl, kWave - 1) & 0xFFFF;
     int kA = lead + (incl & 0xFFFF) - __builtin_popcount(mA);
     int kB = lead + total_a + (incl >> 16) - __builtin_popcount(mB);
+    if (VI) {
+        unsigned * vw = reinterpret_cast<unsigned *>(prod);
+        vw[lane] = vi[0];
+        vw[kWave + lane] = vi[1];
+    } else {
 #pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int o = 256 * q + 4 * lane;
-        if (o <= last) {
-            v2d * dst = reinterpret_cast<v2d *>(prod + o);
-            dst[0] = vals.va[q];
-            dst[1] = vals.vb[q];
+        for (int q = 0; q < QUADS; ++q) {
+            const int o = 256 * q + 4 * lane;
+            if (o <= last) {
+                v2d * dst = reinterpret_cast<v2d *>(prod + o);
+                dst[0] = vals.va[q];
+                dst[1] = vals.vb[q];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t * vbytes = reinterpret_cast<const uint8_t *>(prod);
     zA = 0.0;
     zB = 0.0;
     constexpr int CH = 4;
@@ -78,11 +100,11 @@ __device__ __forceinline__ void tile_rows_masked_stencil(
         for (int i = 0; i < CH; ++i) {
             if (p0 + i < len) {
                 if ((mA >> (p0 + i)) & 1u) {
-                    zA += prod[kA] * xa[i];
+                    zA += (VI ? vtab[vbytes[kA] & 0x7Fu] : prod[kA]) * xa[i];
                     ++kA;
                 }
                 if (second && ((mB >> (p0 + i)) & 1u)) {
-                    zB += prod[kB] * xb[i];
+                    zB += (VI ? vtab[vbytes[kB] & 0x7Fu] : prod[kB]) * xb[i];
                     ++kB;
                 }
             }

@@ -707,14 +707,14 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
         }
         if (C16 && TILE == 512 && !PANELS && is_masked_stencil_tile(meta)) {
             // rows that follow the stencil's pattern with some positions missing (the boundary of a structured grid): a lane per row,
-            // the rows' masks in the tile's 16-bit column slots (csr_stenciltile.hpp); values from the value array, dictionary or not
+            // the rows' masks in the tile's 16-bit column slots (csr_stenciltile.hpp); under a value dictionary an index byte per entry
             const double * yin_t = y_in + r0;
             const double yA = yin_t[lane < nrows ? lane : nrows - 1];
             const double yB = yin_t[lane + kWave < nrows ? lane + kWave : nrows - 1];
             const int32_t * pat = patterns + (size_t) cbase * kPatStride;
             double zA, zB;
-            tile_rows_masked_stencil<QUADS, X32>(prod, pat + kPatRel, __builtin_amdgcn_readfirstlane(pat[0]), j16 + k0, a + kb, x, cols, r0,
-                                                 (k1 - 1 - kb) & ~3, lane, k0 - kb, nrows, zA, zB);
+            tile_rows_masked_stencil<QUADS, X32, VI && !kViAblate>(prod, pat + kPatRel, __builtin_amdgcn_readfirstlane(pat[0]), j16 + k0, a + kb, vidx + kb,
+                                                                   vtab, x, cols, r0, (k1 - 1 - kb) & ~3, lane, k0 - kb, nrows, zA, zB);
             if (lane < nrows)
                 y_store<PEER, false>(y, peers, r0 + lane, yA + zA, nt_y);
             if (lane + kWave < nrows)

@@ -164,7 +164,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             && !(pl->flags & SPMV_HIP_FLAG_EXACT_ORDER);
         if (compressed && stream_tile && spmv::is_masked_stencil_tile(meta)) { // no columns, no row_ptr: a 16-bit mask per row
             pl->shifted_entries += entries;
-            bytes += 8 * entries + 2 * rows + 16 + 16 * rows;
+            bytes += (pl->nvalues > 0 ? 1 : 8) * entries + 2 * rows + 16 + 16 * rows; // (a dictionary launch reads an index byte per entry)
             continue;
         }
         if (block3) { // one 16-bit number per 3 x 3 block (masked block tiles: a 32-bit word per block, about one per 8 entries), no row_ptr

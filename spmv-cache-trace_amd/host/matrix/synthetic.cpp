@@ -224,7 +224,7 @@ csr_matrix::Matrix kkt(long long n, long long rb, long long re, long long * tota
 // ---- poisson3d: the 7-point Laplacian on an n^3 grid (x fastest), values hashed like poisson2d's pessimistic twin -----
 // What the 2-D stand-in of BASELINE configs[1] looks like one dimension up: grid lines of n cells, so that with n = 256 every
 // tile of 64 ... 73 rows holds the end of a line (round 5: masked stencil tiles, csr_stenciltile.hpp).
-csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long * total)
+csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long * total, long long constant = 0)
 {
     if (n < 1 || n > 1290)
         throw matrix::matrix_error("synthetic:poisson3d: grid edge must be in 1..1290");
@@ -235,7 +235,7 @@ csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long 
         long long const x = r % n, y = (r / n) % n, z = r / (n * n);
         return 1 + (x > 0) + (x < n - 1) + (y > 0) + (y < n - 1) + (z > 0) + (z < n - 1);
     };
-    auto fill = [n](long long r, index_type * c, double * v) {
+    auto fill = [n, constant](long long r, index_type * c, double * v) {
         long long const x = r % n, y = (r / n) % n, z = r / (n * n);
         index_type * const c0 = c;
         double * const v0 = v;
@@ -246,8 +246,9 @@ csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long 
         if (x < n - 1) { *c++ = (index_type) (r + 1); *v++ = -1.0; }
         if (y < n - 1) { *c++ = (index_type) (r + n); *v++ = -1.0; }
         if (z < n - 1) { *c++ = (index_type) (r + n * n); *v++ = -1.0; }
-        for (long long q = 0; q < v - v0; ++q)
-            v0[q] *= 1.0 + 0.25 * u11(h2(0x9015507ull + (std::uint64_t) r, (std::uint64_t) c0[q]));
+        if (!constant) // (constant = 1: the constant-coefficient operator, two distinct values: the plan's value dictionary applies)
+            for (long long q = 0; q < v - v0; ++q)
+                v0[q] *= 1.0 + 0.25 * u11(h2(0x9015507ull + (std::uint64_t) r, (std::uint64_t) c0[q]));
     };
     return build(N, N, rb, re, len, fill);
 }
@@ -663,12 +664,12 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
         check_range(v[0] * v[0]);
         A = poisson2d(v[0], rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "poisson3d") {
-        if (v.size() != 1)
-            throw matrix::matrix_error("synthetic:poisson3d:<n> takes one number");
+        if (v.size() < 1 || v.size() > 2)
+            throw matrix::matrix_error("synthetic:poisson3d:<n>[,<constant coefficients 0|1>] takes one or two numbers");
         if (v[0] < 1 || v[0] > 1290)
             throw matrix::matrix_error("synthetic:poisson3d: grid edge must be in 1..1290");
         check_range(v[0] * v[0] * v[0]);
-        A = poisson3d(v[0], rb, re, &tot);
+        A = poisson3d(v[0], rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "kkt") {
         if (v.size() > 2)
             throw matrix::matrix_error("synthetic:kkt[:<n>[,<jitter %>]] takes at most two numbers");
