@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, spec, fused, balanced):
+def _worker(rank, world, port, out_dir, spec, fused, balanced, need=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -63,6 +63,8 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced):
         expect_fused = (fused and world > 1 and not info["balanced"] and not ring_window and info["panel_tiles"] == 0
                         and info["long_blocks"] == 0)
         ok = ok and (op.fused == expect_fused)
+        if need is not None:  # the tile class this case is here for is in this rank's plan
+            ok = ok and info[need] > 0 and op.fused
         op.zero()
         ok = ok and float(op.y().abs().max().item()) == 0.0
         op.finish()  # a vector may be read until ANY rank multiplies again: this rank is done reading
@@ -71,7 +73,7 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced):
         want1 = O.csr_spmv(rows, p, c, v, x, num_threads=2)
         ok = ok and bool(np.all(np.abs(got1 - want1) <= 1e-10 * np.maximum(scale, np.abs(want1)) + 1e-300))
         op.close()
-        verdict = "ok" if ok else "mismatch (fused %s, expected %s)" % (op.fused, expect_fused)
+        verdict = "ok" if ok else "mismatch (fused %s, expected %s, %s %s)" % (op.fused, expect_fused, need, info.get(need))
     except Exception as ex:  # the parent reads the verdict; a silent hang would cost the whole GPU call
         verdict = "exception: %r" % (ex,)
     open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write(verdict)
@@ -86,18 +88,24 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced):
         pass
 
 
-@pytest.mark.parametrize("world,spec,fused,balanced", [
-    (2, "synthetic:poisson2d:300", True, False),       # value dictionary + lane-per-row tiles, row sums forwarded by the kernel
-    (3, "synthetic:poisson2d:300,1", True, False),     # the same without a dictionary, three ranks, a short last block
-    (2, "synthetic:queen:20,15,10", True, False),      # narrow tiles, several lanes per row
-    (2, "synthetic:banded:60000,13", True, False),     # shifted tiles with x windows (the XW kernel variant)
-    (2, "synthetic:kkt:44,50", True, False),           # segment windows + the launch over the leftover tiles, both forwarding
-    (2, "synthetic:poisson2d:300", False, False),      # pushed by a second launch
-    (3, "synthetic:webbase:30000,100000,300,75", True, True),  # skewed rows: balanced tiles (no forwarding variant) + uneven blocks
+@pytest.mark.parametrize("world,spec,fused,balanced,need", [
+    (2, "synthetic:poisson2d:300", True, False, None),       # value dictionary + lane-per-row tiles, row sums forwarded by the kernel
+    (3, "synthetic:poisson2d:300,1", True, False, None),     # the same without a dictionary, three ranks, a short last block
+    (2, "synthetic:queen:20,15,10", True, False, None),      # narrow tiles, several lanes per row
+    (2, "synthetic:banded:60000,13", True, False, None),     # shifted tiles with x windows (the XW kernel variant)
+    (2, "synthetic:kkt:44,50", True, False, None),           # segment windows + the launch over the leftover tiles, both forwarding
+    (2, "synthetic:poisson2d:300", False, False, None),      # pushed by a second launch
+    (3, "synthetic:webbase:30000,100000,300,75", True, True, None),  # skewed rows: balanced tiles (no forwarding variant) + uneven blocks
+    # round 5's tile classes, each storing through the same forwarding y_store
+    (2, "synthetic:queen:20,15,10,3,20,97", True, False, "masked_block_tiles"),  # 3 x 3 blocks with entries missing, odd nodes
+    (2, "synthetic:poisson3d:40", True, False, "stencil_mask_tiles"),            # masked stencil tiles, values read
+    (2, "synthetic:poisson3d:40,1", True, False, "stencil_mask_tiles"),          # ... and with the value dictionary
+    (2, "synthetic:random:3000,600", True, False, "multi_window_tiles"),         # rows of 600 entries sharing a tile through LDS
+    (2, "synthetic:random:40000,600", True, False, "multi_window_tiles"),        # ... and, the matrix large enough, in registers
 ])
-def test_peer_stores_between_processes_on_one_device(tmp_path, world, spec, fused, balanced):
+def test_peer_stores_between_processes_on_one_device(tmp_path, world, spec, fused, balanced, need):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), spec, fused, balanced), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), spec, fused, balanced, need), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
