@@ -33,7 +33,7 @@
 namespace spmv {
 
 constexpr int kSegWinWaves = 8;
-constexpr int kSegWinMaxSegs = 8;
+constexpr int kSegWinMaxSegs = 12;
 constexpr int kSegWinMaxRuns = 64;
 constexpr int kSegWinBitmapWords = 2048; // 65536 bits
 
