@@ -1104,7 +1104,7 @@ def test_block_window_kernel(oracle, case):
 
 
 @pytest.mark.parametrize("spec", ["synthetic:kkt:40,50", "synthetic:kkt:44,100", "synthetic:kkt:40", "synthetic:queen:200,180,3",
-                                  "synthetic:queen:200,180,3,6", "kkt+scatter"])
+                                  "synthetic:queen:200,180,3,6", "kkt+scatter", "queen dof by dof"])
 def test_segment_window_kernel(oracle, spec):
     """Rows whose columns sit in a few clusters MORE than 65536 columns apart (a KKT row's diagonal plus three planes
     of its grid millions of columns away; a mesh whose planes hold 36 000 nodes) cannot have 16-bit column offsets;
@@ -1123,6 +1123,18 @@ def test_segment_window_kernel(oracle, spec):
         c = np.concatenate([c1, c2, c1])
         v = np.concatenate([v1, v2, v1])
         A.close()
+    elif spec == "queen dof by dof":
+        # the mesh of 3 unknowns per node numbered dof by dof (all first unknowns, then all second, ...): the same matrix, a row's columns
+        # in three clusters a third of the matrix apart, each over three mesh planes -- NINE segments per block (round 5: up to 12)
+        import scipy.sparse as sp
+        A = hostapi.load("synthetic:queen:48,40,36", "csr")
+        M = sp.csr_matrix((np.array(A.value), np.array(A.column_index), np.array(A.row_ptr)), shape=(A.rows, A.cols))
+        A.close()
+        n = M.shape[0] // 3
+        perm = np.concatenate([np.arange(n) * 3 + d for d in range(3)])
+        M = M[perm][:, perm].tocsr()
+        M.sort_indices()
+        rows, cols, p, c, v = M.shape[0], M.shape[1], M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data
     else:
         A = hostapi.load(spec, "csr")
         rows, cols, p, c, v = A.rows, A.cols, np.array(A.row_ptr), np.array(A.column_index), np.array(A.value)
