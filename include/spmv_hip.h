@@ -123,7 +123,7 @@ extern "C" {
                                              G copies of y itself as each tile finishes -- the gather overlaps the SAME multiply
                                              and needs no launch of its own; other kernels are followed by the push kernel */
 #define SPMV_HIP_FLAG_NO_SEGMENT_WINDOW 0x800000u /* plan_csr_compress: no segment windows (x staged through LDS per block of 32
-                                             tiles in up to 8 far-apart column segments: rows of a 3-D mesh in natural
+                                             tiles in up to 12 far-apart column segments: rows of a 3-D mesh in natural
                                              ordering, KKT systems; the tiles' 16-bit column stream then holds window
                                              slots).  Unstructured bands fall back to the one-ring block window. */
 #define SPMV_HIP_FLAG_NO_BLOCK_TILES 0x2000000u /* plan_csr / plan_csr_repack: no block tiles.  By default a matrix whose rows come in
@@ -375,7 +375,7 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *        [19] 1 if the tiles are balanced ones (filled by entries; see SPMV_HIP_FLAG_NO_BALANCED_TILES)
  *        [20] size of the value dictionary (0 = none; see spmv_hip_plan_csr_index_values)
  *        [21] tiles multiplied by the segment-window kernel (a subset of [12]; x staged through LDS per block of 32 tiles
- *             in up to 8 column segments)  [22] the largest window among its blocks, in doubles
+ *             in up to 12 column segments)  [22] the largest window among its blocks, in doubles
  *        [23] with a value dictionary: tiles whose rows all repeat the first row's values (constant-coefficient stencils) --
  *             they read no index stream at all, only the first row's bytes
  *        [24] tiles of the dictionary launch when runs of such tiles were re-cut into tiles of 128 rows (0: it uses [3])

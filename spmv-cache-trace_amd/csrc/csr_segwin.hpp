@@ -33,6 +33,9 @@
 namespace spmv {
 
 constexpr int kSegWinWaves = 8;
+// (8 until round 5; 12: a mesh of 3 unknowns per node numbered dof by dof has NINE clusters per block of rows -- three unknowns x
+// three mesh planes -- and fell back to column panels: 321 -> 304 us, profiles/r05_segwin_dof.log; kkt-like and queen-like plans
+// unchanged, profiles/r05_ab_segs12.log)
 constexpr int kSegWinMaxSegs = 12;
 constexpr int kSegWinMaxRuns = 64;
 constexpr int kSegWinBitmapWords = 2048; // 65536 bits

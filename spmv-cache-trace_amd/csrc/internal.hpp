@@ -113,7 +113,7 @@ struct spmv_hip_plan {
     // row-group plans (csr_rowgroup.hpp): the tiles csr_rowgroup_kernel multiplies, and the others (csr_wavetile_kernel<LIST>)
     int32_t * d_group_tiles = nullptr, * d_group_rest = nullptr;
     int ngroup_tiles = 0, ngroup_rest = 0;
-    // segment windows (csr_segwin.hpp): x staged through LDS per block of seg_tiles_per_block tiles, in up to 8 column segments
+    // segment windows (csr_segwin.hpp): x staged through LDS per block of seg_tiles_per_block tiles, in up to 12 column segments
     spmv::SegWinBlock * d_segblocks = nullptr;
     int nsegblocks = 0, seg_tiles_per_block = 0, segwin_tiles = 0, segwin_slots = 0;
     int32_t * d_patterns = nullptr; // shared window-of-runs layouts (kernels: kPatStride words each)

@@ -1112,7 +1112,7 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     pl->shifted_tiles = counts[1];
     pl->xwin_tiles = counts[2];
     pl->spread_tiles = counts[4];
-    // segment windows (x staged through LDS per block of 32 tiles, in up to 8 far-apart column segments: meshes in
+    // segment windows (x staged through LDS per block of 32 tiles, in up to 12 far-apart column segments: meshes in
     // natural ordering, KKT systems) for what has no cheaper path: first count the tiles that would qualify, and
     // only if they are the majority mark them and rewrite their 16-bit column stream to window slots
     if (e == hipSuccess && pl->tile == 512 && !pl->balanced && pl->ntiles >= 4 * 32
