@@ -387,7 +387,12 @@ void spmv_hip_plan_destroy(spmv_hip_plan *plan);
  *             per block, SPMV_HIP_FLAG_NO_MASKED_BLOCKS)  [32] their entries
  *        [33] masked stencil tiles (the boundary rows of a structured grid: rows that follow a stencil pattern of at most 16
  *             positions with some of them missing -- a 16-bit mask per row instead of column indices and row_ptr; marked by
- *             spmv_hip_plan_csr_repack; never with SPMV_HIP_FLAG_NO_SHIFTED_TILES)  [34] their entries */
+ *             spmv_hip_plan_csr_repack; never with SPMV_HIP_FLAG_NO_SHIFTED_TILES)  [34] their entries
+ *        [35] group tiles (rows in groups of 2 or 4 equally long rows with the same columns -- a mesh with 2 or 4 unknowns per node:
+ *             one 16-bit column list and one gather of x per group instead of per row, the values in place, the row sums of the
+ *             plain tile bit for bit; a hint from row_ptr in spmv_hip_plan_csr, checked against the columns and marked by
+ *             spmv_hip_plan_csr_repack; never with SPMV_HIP_FLAG_NO_BLOCK_TILES or a value dictionary)  [36] their entries
+ *        [37] the rows per group of those tiles (0 = none) */
 int spmv_hip_plan_info(const spmv_hip_plan *plan, int64_t *out, int n);
 
 /* y += A*x, CSR.  Replaces csr_spmv / csr_spmv_inner_loop

@@ -61,6 +61,20 @@ __host__ __device__ __forceinline__ size_t mask_stream_words(long long nnz_total
 // a tile's words start at k0 / 4: every tile in front of it holds at most (its entries / kMaskedMinFill) < (its entries / 4) blocks
 __host__ __device__ __forceinline__ int mask_stream_index(int k0) { return k0 >> 2; }
 
+// GROUP tiles (late in round 5): a mesh with 2 or 4 unknowns per node has no 3 x 3 blocks, but its rows still come in groups of
+// D = 2 or 4 with IDENTICAL column lists.  Such a tile keeps its values in place and its usual row sums; what changes is where the
+// products' columns come from: ONE 16-bit column list per group (the first row's, copied to a plan-owned stream -- 2 / D bytes
+// per entry instead of 2) and ONE gather of x per column of a group, multiplied with the D values that share it
+// (tile_products_grouped in csr_wavetile.hpp).  The products land where tile_products_narrow would have put them, so the row sums
+// -- lanes per row, order, bits -- are those of the plain tile.  D is the plan's (the strict hint of spmv_hip_plan_csr: all rows in
+// groups of D equally long rows); the mark: kTileMetaBlock3 together with kTileMetaGroupRows.
+// (structure sweep, profiles/r05_zoo_mesh_dofs.log: meshes with 2 / 4 unknowns per node 0.79 / 0.80 of the roofline against 1.05 / 1.10
+// with 3 / 6)
+constexpr int kTileMetaGroupRows = 1 << 30; // only together with kTileMetaBlock3 (a block tile has no x window: the window bits are free)
+// the group stream shares the block stream's place behind the 16-bit columns (a plan has 3 x 3 blocks or row groups, not both);
+// a tile's group entries start at k0 / D: every tile in front of it holds at most (its entries / D)
+__host__ __device__ __forceinline__ int group_stream_index(int k0, int d) { return k0 / d; }
+
 // inclusive prefix sum over the 64 lanes (every lane active): DPP row shifts inside the rows of 16, then the two row broadcasts
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
@@ -417,6 +431,130 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
         if (!dense) {
             striped_add(count, 4, 1ull);
             striped_add(count, 5, (unsigned long long) n);
+        }
+    }
+}
+
+// Products of a group tile.  A "group entry" e = one column of one group: the tile's groups hold E = entries / D of them, numbered
+// through the tile (group g starts at G_g = (its first row's start - the tile's start) / D).  Row lengths are even (the mark kernel
+// checks), so a PAIR of group entries 2 t, 2 t + 1 never straddles two groups: lane l takes the pairs t = l, l + 64 (4 / D steps at
+// most).  Which group a pair belongs to follows from the row starts the lanes already hold (`ps_rel`: the start of the lane's row
+// relative to the tile's 4-aligned base kb; row h sits in lane h << lanes_log2): a wave-uniform walk over the groups with
+// readlanes, no memory access.  Then: two 16-bit columns from the group stream, two x, D pairs of values (16-byte loads,
+// consecutive across the lanes of a group row -- the load mix of tile_products_narrow with 1 / D of its gathers) and D pairs of
+// products into the wave's LDS slice at the entries' own places.
+template <int D>
+__device__ __forceinline__ void tile_products_grouped(
+    double * prod, const uint16_t * __restrict__ gt /* the tile's group stream */, const double * __restrict__ at /* a + kb */,
+    const double * __restrict__ xt /* x + tile base */, unsigned limit, int ps_rel, int row_len, int lanes_log2, int nrows, int first_rel /* k0 - kb */,
+    int entries, int lane)
+{
+    static_assert(D == 2 || D == 4, "row groups of 2 or 4");
+    constexpr int STEPS = 4 / D; // a tile holds at most 512 / D group entries = 256 / D pairs: D = 2: 2 x 64, D = 4: 1 x 64
+    const int pairs = entries / (2 * D);
+    int off[STEPS], len[STEPS]; // 2 t + off = the pair's place (relative to kb) in the group's FIRST row; len = the group's row length
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        off[i] = first_rel;
+        len[i] = 0;
+    }
+    const int ngroups = nrows / D;
+    for (int h = 0; h < ngroups; ++h) { // wave-uniform
+        const int src = (h * D) << lanes_log2;
+        const int s_h = __builtin_amdgcn_readlane(ps_rel, src), m_h = __builtin_amdgcn_readlane(row_len, src);
+        const int G_h = (s_h - first_rel) / D;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const bool here = 2 * (lane + 64 * i) >= G_h;
+            off[i] = here ? s_h - G_h : off[i];
+            len[i] = here ? m_h : len[i];
+        }
+    }
+    unsigned c0[STEPS], c1[STEPS];
+    v2d_u8 v[STEPS][D];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        int t = lane + 64 * i;
+        t = t < pairs ? t : pairs - 1; // idle lanes repeat the last pair's loads and store nothing
+        c0[i] = gt[2 * t];
+        c1[i] = gt[2 * t + 1];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+            v[i][a] = *reinterpret_cast<const v2d_u8 *>(at + 2 * t + off[i] + a * len[i]);
+    }
+    const char * xb = reinterpret_cast<const char *>(xt);
+    double x0[STEPS], x1[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        x0[i] = *reinterpret_cast<const double *>(xb + (min(c0[i], limit) << 3));
+        x1[i] = *reinterpret_cast<const double *>(xb + (min(c1[i], limit) << 3));
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int t = lane + 64 * i;
+        if (t < pairs) {
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+                *reinterpret_cast<v2d_u8 *>(prod + 2 * t + off[i] + a * len[i]) = v2d_u8{v[i][a].x * x0[i], v[i][a].y * x1[i]};
+        }
+    }
+}
+
+// Plan time, one wave per tile: a stream tile with 16-bit columns and rows of more than 16 entries is a GROUP tile if its rows come in
+// groups of D equally long rows with the same columns, entry by entry; the first row's columns (offsets from the tile's smallest
+// column) are then copied to the group stream and the tile marked.  Counts as csr_block3_mark_kernel's: count[0], [1] tiles and
+// entries, count[2], [3] those no block window has claimed.
+static __global__ __launch_bounds__(256) void csr_group_mark_kernel(
+    int ntiles, int tile, int d, int4 * __restrict__ desc, const int32_t * __restrict__ p, const int32_t * __restrict__ j,
+    uint16_t * __restrict__ gstream, unsigned long long * __restrict__ count)
+{
+    const int wave = (int) threadIdx.x >> 6;
+    const int lane = (int) __lane_id();
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= ntiles)
+        return;
+    const int4 d0 = desc[w];
+    const int4 d1 = desc[w + 1];
+    const int r0 = d0.x & ~kTileFlagPartial, r1 = d1.x & ~kTileFlagPartial;
+    const int k0 = d0.y, k1 = d1.y;
+    const int meta = d0.z;
+    const int nrows = r1 - r0, n = k1 - k0;
+    const int other = kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | (1 << 21) /* balanced tiles */;
+    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || !(meta & kTileMetaNarrow) || (meta & other)
+        || nrows < d || nrows > kBlockTileMaxRows || nrows % d != 0 || k1 - (k0 & ~3) > tile || tile > 512 || (d != 2 && d != 4))
+        return;
+    const int cmin = d0.w;
+    const int ps = p[r0 + (lane <= nrows ? lane : nrows)]; // row starts in lanes 0 .. nrows (nrows <= 30)
+    const int len = __shfl_down(ps, 1) - ps;                // lanes < nrows
+    const int len0 = __shfl(len, lane - lane % d);
+    if (!__all(lane >= nrows || (len > 16 && len == len0 && len % 2 == 0)))
+        return; // (rows of up to 16 entries keep their one-lane-per-row, bit-exact path; even lengths: the multiply takes the columns in pairs)
+    int ok = 1;
+    for (int r = 0; r < nrows; ++r) {
+        const int a = r % d;
+        if (a == 0)
+            continue;
+        const int start = __shfl(ps, r), rl = __shfl(len, r);
+        for (int k = start + lane; k < start + rl; k += kWave)
+            ok &= j[k] == j[k - a * rl];
+    }
+    if (!__all(ok))
+        return;
+    // the group stream: the first rows' columns, group after group
+    const int base = group_stream_index(k0, d);
+    for (int r = 0; r < nrows; r += d) {
+        const int start = __shfl(ps, r), rl = __shfl(len, r);
+        const int g0 = (start - k0) / d; // what the groups in front of this one hold
+        for (int q = lane; q < rl; q += kWave)
+            gstream[base + g0 + q] = (uint16_t) (j[start + q] - cmin);
+    }
+    if (lane == 0) {
+        desc[w].z = meta | kTileMetaBlock3 | kTileMetaGroupRows;
+        striped_add(count, 0, 1ull);
+        striped_add(count, 1, (unsigned long long) n);
+        if (!(meta & kTileMetaBlockWin)) {
+            striped_add(count, 2, 1ull);
+            striped_add(count, 3, (unsigned long long) n);
         }
     }
 }

@@ -631,6 +631,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
     // exact_order_and_nt: bit 0 = SPMV_HIP_FLAG_EXACT_ORDER, bit 1 = write y non-temporally (the matrix streams from HBM)
     const int exact_order = exact_order_and_nt & 1;
     const bool nt_y = (exact_order_and_nt & 2) != 0;
+    const int group_rows = (exact_order_and_nt >> 8) & 15; // bits 8-11: rows per group of the plan's group tiles (csr_blocktile.hpp), 0 = none
     __shared__ __attribute__((aligned(16))) double prod_all[4][TILE + 4];
     __shared__ __attribute__((aligned(16))) uint32_t first_row_all[C16 ? 4 : 1][C16 ? kShiftedMaxLen : 1]; // shifted tiles: the first row's columns
     __shared__ double vtab_lds[VI ? kMaxIndexedValues : 1];             // VI variant: the value dictionary
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                                                               [&](int idx, double v) { y_store<PEER, false>(y, peers, idx, v, nt_y); });
             return;
         }
-        if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !exact_order) {
+        if (C16 && !VI && !PANELS && TILE == 512 && (meta & kTileMetaBlock3) && !(meta & kTileMetaGroupRows) && !exact_order) {
             // dense 3 x 3 blocks (csr_blocktile.hpp): one 16-bit number per block instead of a column per entry, no row_ptr
             if (meta & kTileMetaBlock3Masked) // blocks with entries missing, off the grid of column triples: a 32-bit word per block
                 tile_rows_block3<true>(prod, reinterpret_cast<const uint32_t *>(j16 + mask_stream_offset(nnz_total)) + mask_stream_index(k0), a,
@@ -840,6 +841,16 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             tile_products_shifted<QUADS, X32, VI>(prod, first_row_all[C16 ? wave : 0],
                                               pattern ? patterns + (size_t) cbase * kPatStride + kPatRel : j + k0, pattern ? r0 : 0,
                                               a + kb, x, (unsigned) (cols - 1), last, lane, maxlen, k0 - kb, vidx + kb, vtab);
+        }
+        else if (C16 && !VI && !PANELS && TILE == 512 && ABL == 0 && (meta & kTileMetaBlock3) && (meta & kTileMetaGroupRows) && !exact_order
+                 && (group_rows == 2 || group_rows == 4)) {
+            // rows in groups of 2 or 4 with the same columns (csr_blocktile.hpp): one column list and one x per group; the row
+            // sums below are the plain tile's
+            const uint16_t * gt = j16 + block_stream_offset(nnz_total) + group_stream_index(k0, group_rows);
+            if (group_rows == 2)
+                tile_products_grouped<2>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane);
+            else
+                tile_products_grouped<4>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane);
         }
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);

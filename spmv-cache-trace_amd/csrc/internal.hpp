@@ -132,8 +132,10 @@ struct spmv_hip_plan {
     // block tiles (csr_blocktile.hpp): rows in triples of equal length (a hint from row_ptr at plan time), checked against
     // the columns and marked by spmv_hip_plan_csr_repack; their block stream lives behind the 16-bit columns in d_col16
     int multi_window_tiles = 0; // tiles of several long rows walked in windows of 512 entries
-    int block_hint = 0;
-    int block_offset = 0; // the row (0, 1 or 2) at which the grid of triples starts
+    int block_hint = 0;   // 3: rows in triples (3 x 3 blocks); 2 or 4: rows in groups of that many equally long rows (group tiles)
+    int block_offset = 0; // the row (0 ... block_hint - 1) at which the grid of triples / groups starts
+    int colshare_tiles = 0; // group tiles (csr_blocktile.hpp): tiles whose rows share one column list per group of block_hint rows
+    long long colshare_entries = 0;
     int block_candidate = 0; // rows in triples of merely similar length: repack samples the columns before it believes in blocks
     const uint32_t * group_bits = nullptr; // ... and has confirmed them: bit r = row r begins a group of rows with the same columns
                                            // (host memory, alive only while repack cuts the tiles once more)

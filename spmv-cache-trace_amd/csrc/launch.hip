@@ -190,7 +190,9 @@ static int csr_spmv_launch(const spmv_hip_plan * pl, const int32_t * p, const in
             const int exact_order = (pl->flags & SPMV_HIP_FLAG_EXACT_ORDER) ? 1 : 0;
             // what the kernels get: bit 0 = exact order, bit 1 = y written non-temporally -- when the matrix streams from HBM (twice
             // the Infinity Cache: the same threshold as for the 128-row tiles); a cache-resident matrix keeps its y in the caches
-            const int exact = exact_order | ((12.0 * (double) pl->nnz + 20.0 * (double) pl->rows >= 512e6) ? 2 : 0);
+            // (bits 8-11: the rows per group of the plan's group tiles, csr_blocktile.hpp)
+            const int exact = exact_order | ((12.0 * (double) pl->nnz + 20.0 * (double) pl->rows >= 512e6) ? 2 : 0)
+                | ((pl->colshare_tiles > 0 ? pl->block_hint : 0) << 8);
             // the 16-bit index stream is only valid for the column array it was derived from
             const bool c16 = pl->d_col16 != nullptr && pl->compressed_from == j;
             // x below 4 GiB: 32-bit gather offsets from a scalar base

@@ -167,6 +167,13 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
             bytes += (pl->nvalues > 0 ? 1 : 8) * entries + 2 * rows + 16 + 16 * rows; // (a dictionary launch reads an index byte per entry)
             continue;
         }
+        if (block3 && (meta & spmv::kTileMetaGroupRows)) { // group tile: one 16-bit column per column of a group of block_hint rows; row_ptr read
+            pl->narrow_entries += entries;
+            bytes += 8 * entries + 2 * (entries / std::max(1, pl->block_hint)) + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+            if (uniform)
+                pl->uniform_rows += rows;
+            continue;
+        }
         if (block3) { // one 16-bit number per 3 x 3 block (masked block tiles: a 32-bit word per block, about one per 8 entries), no row_ptr
             pl->narrow_entries += entries;
             bytes += 8 * entries + ((meta & spmv::kTileMetaBlock3Masked) ? 4 * ((entries + 7) / 8) : 2 * (entries / 9)) + 16 + 16 * rows;
@@ -369,6 +376,40 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     pl->block_offset = o;
                 }
             }
+            // Rows in groups of 4 or of 2 equally long rows (a mesh with 4 or 2 unknowns per node; 8 or 10: groups of 4 / 2 as well):
+            // no 3 x 3 blocks, but the rows of a group may share their column list -- group tiles, csr_blocktile.hpp.  The same
+            // strict rule as for triples (four fifths of the groups: rows longer than 16 entries, all equally long, the length a
+            // multiple of the group size, a whole group no longer than a tile), tried for 4 before 2; tiles are then cut on multiples of
+            // that many rows.
+            for (int d = 4; d >= 2 && !pl->block_hint; d -= 2)
+                for (int o = 0; o < d && !pl->block_hint; ++o) {
+                    const long long groups = (rows - o) / d, allowed_bad = groups / 5;
+                    long long good = 0, bad = 0;
+                    // (a glance first -- 512 groups spread over the matrix -- so that a matrix without groups costs next to nothing)
+                    int glance = 0;
+                    for (int t = 0; t < 512; ++t) {
+                        const int32_t q = o + (int32_t) ((groups - 1) * t / 511) * d;
+                        const int l0 = p[q + 1] - p[q];
+                        bool ok = l0 > 16 && l0 % d == 0 && (long long) l0 * d <= tile; // (a group must fit a tile)
+                        for (int a = 1; a < d && ok; ++a)
+                            ok = p[q + a + 1] - p[q + a] == l0;
+                        glance += ok;
+                    }
+                    if (glance < 384)
+                        continue;
+                    for (int32_t q = o; q + d <= rows && bad <= allowed_bad; q += d) {
+                        const int l0 = p[q + 1] - p[q];
+                        bool ok = l0 > 16 && l0 % d == 0 && (long long) l0 * d <= tile;
+                        for (int a = 1; a < d && ok; ++a)
+                            ok = p[q + a + 1] - p[q + a] == l0;
+                        good += ok;
+                        bad += !ok;
+                    }
+                    if (bad <= allowed_bad && good * 5 >= groups * 4) {
+                        pl->block_hint = d;
+                        pl->block_offset = o;
+                    }
+                }
             if (!pl->block_hint && !(flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS)) {
                 // (given up as soon as two fifths of the rows have failed)
                 const long long allowed_bad = 2LL * rows / 5;
@@ -413,7 +454,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     ++q;
                 row_limit = q;
             }
-        } else if (pl->block_hint && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !similar_triple(r)) {
+        } else if (pl->block_hint == 3 && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !similar_triple(r)) {
             for (int d = 1; d <= 2; ++d)
                 if (similar_triple(r + d) && similar_triple(r + d + 3)) {
                     phase = (r + d) % 3;
@@ -501,9 +542,10 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         }
         // block hint: a tile of long rows ends on a triple boundary and holds at most kBlockTileMaxRows rows
         if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
-            int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows);
+            const int d = pl->block_hint; // 3, or the rows per group of a group-tile plan
+            int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows - spmv::kBlockTileMaxRows % d);
             if (cut < ce)
-                cut -= ((cut - phase) % 3 + 3) % 3;
+                cut -= ((cut - phase) % d + d) % d;
             if (cut > r && cut < r1) {
                 o.block_cuts++;
                 r1 = cut;
@@ -645,7 +687,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     for (int c = 0; c <= nchunks; ++c) {
         long long bnd = (long long) rows * c / nchunks;
         if (pl->block_hint && c > 0 && c < nchunks)
-            bnd -= ((bnd - pl->block_offset) % 3 + 3) % 3;
+            bnd -= ((bnd - pl->block_offset) % pl->block_hint + pl->block_hint) % pl->block_hint;
         bound[(size_t) c] = (int32_t) bnd;
     }
     std::vector<int4> desc;
@@ -1293,7 +1335,8 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
     pl->nblocks16 = pl->blockwin_tiles = pl->nrest_tiles = pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = pl->npatterns = 0;
     pl->uniform_tiles = pl->split_rows = pl->long_blocks = pl->multi_window_tiles = 0;
     pl->balanced = false;
-    pl->block_hint = pl->block_cuts = pl->block_tiles = pl->masked_block_tiles = pl->block_candidate = pl->stencil_mask_tiles = 0;
+    pl->block_hint = pl->block_cuts = pl->block_tiles = pl->masked_block_tiles = pl->block_candidate = pl->stencil_mask_tiles = pl->colshare_tiles = 0;
+    pl->colshare_entries = 0;
     pl->stencil_mask_entries = 0;
     pl->block_entries = pl->masked_block_entries = 0;
     pl->meta_bytes = 0;
@@ -1371,7 +1414,7 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             return rc;
     }
     // block tiles (csr_blocktile.hpp): the one structural pass that needs row_ptr next to the columns
-    if (pl->block_hint && pl->block_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
+    if (pl->block_hint && pl->block_tiles == 0 && pl->colshare_tiles == 0 && pl->d_col16 && pl->compressed_from == d_column_index && d_row_ptr
         && pl->algorithm == SPMV_HIP_CSR_WAVETILE && pl->tile == 512 && !pl->balanced && pl->ntiles > 0
         && !(pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_BLOCK_TILES))) {
         hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1379,11 +1422,16 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
         unsigned long long count[6] = {0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
         hipError_t e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
+        const bool groups = pl->block_hint != 3; // rows in groups of 2 or 4 with one column list each, not 3 x 3 blocks
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
-                               pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),
-                               reinterpret_cast<uint32_t *>(pl->d_col16 + spmv::mask_stream_offset(pl->nnz)), pl->nnz, pl->cols,
-                               (pl->flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS) ? 0 : 1, d_count);
+            if (groups)
+                hipLaunchKernelGGL(spmv::csr_group_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
+                                   pl->block_hint, pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count);
+            else
+                hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
+                                   pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),
+                                   reinterpret_cast<uint32_t *>(pl->d_col16 + spmv::mask_stream_offset(pl->nnz)), pl->nnz, pl->cols,
+                                   (pl->flags & SPMV_HIP_FLAG_NO_MASKED_BLOCKS) ? 0 : 1, d_count);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = read_striped(d_count, count, 6, s);
@@ -1413,6 +1461,12 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             pl->block_tiles = (int) count[0];
             pl->block_entries = (long long) count[1];
         }
+        if (groups) { // (the launch hands the group size to the kernel only if there are group tiles)
+            pl->colshare_tiles = pl->block_tiles;
+            pl->colshare_entries = pl->block_entries;
+            pl->block_tiles = 0;
+            pl->block_entries = 0;
+        }
         if (pl->block_cuts > 0 && 2 * (long long) count[0] < pl->ntiles) {
             // The hint was wrong (rows in equal triples, but no 3 x 3 blocks: a scalar mesh, a band) AND it made tiles shorter
             // than they would have been: the tiles are built once more without it, from row_ptr fetched back from the device,
@@ -1420,7 +1474,7 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, nullptr, reindex);
             if (rc != SPMV_HIP_OK)
                 return rc;
-        } else if (pl->block_tiles > 0) {
+        } else if (pl->block_tiles > 0 || pl->colshare_tiles > 0) {
             int rc = plan_account(pl, true);
             if (rc != SPMV_HIP_OK)
                 return rc;
@@ -1918,7 +1972,7 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
 {
     if (!pl || !out || n < 0)
         return fail(SPMV_HIP_ERR_INVALID, "plan/out null");
-    const int64_t v[35] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
+    const int64_t v[38] = {pl->algorithm, pl->lanes_per_row, pl->workgroups, pl->nblk,
                            pl->long_blocks, pl->rows, pl->nnz, (int64_t) pl->meta_bytes, pl->narrow_tiles,
                            pl->uniform_tiles, pl->shifted_tiles, pl->xwin_tiles, pl->blockwin_tiles,
                            pl->inner ? pl->inner->ntiles : 0, pl->streamed_bytes, pl->shifted_entries,
@@ -1927,8 +1981,10 @@ int spmv_hip_plan_info(const spmv_hip_plan * pl, int64_t * out, int n)
                            pl->nvalues > 0 && pl->d_tiles_vi ? pl->ntiles_vi : 0, pl->nvalues > 0 ? 0 : pl->block_tiles,
                            pl->nvalues > 0 ? 0 : pl->block_entries, pl->nhubs, pl->hub_entries, pl->multi_window_tiles,
                            pl->ngroup_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_tiles, pl->nvalues > 0 ? 0 : pl->masked_block_entries,
-                           pl->stencil_mask_tiles, pl->stencil_mask_entries};
-    for (int i = 0; i < n && i < 35; ++i)
+                           pl->stencil_mask_tiles, pl->stencil_mask_entries,
+                           pl->nvalues > 0 ? 0 : pl->colshare_tiles, pl->nvalues > 0 ? 0 : pl->colshare_entries,
+                           pl->colshare_tiles > 0 ? pl->block_hint : 0};
+    for (int i = 0; i < n && i < 38; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

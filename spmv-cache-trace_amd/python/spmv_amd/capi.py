@@ -313,13 +313,14 @@ class CsrPlan:
             pass
 
     def info(self):
-        out = np.zeros(35, dtype=np.int64)
-        check(self.lib.spmv_hip_plan_info(self.h, out, 35))
+        out = np.zeros(38, dtype=np.int64)
+        check(self.lib.spmv_hip_plan_info(self.h, out, 38))
         keys = ["algorithm", "lanes_per_row", "workgroups", "row_blocks", "long_blocks", "rows",
                 "nnz", "meta_bytes", "narrow_tiles", "uniform_tiles", "shifted_tiles", "xwin_tiles", "blockwin_tiles", "panel_tiles",
                 "streamed_bytes", "shifted_entries", "narrow_entries", "uniform_rows", "value_snapshot", "balanced", "indexed_values",
                 "segwin_tiles", "segwin_slots", "value_row_tiles", "dictionary_launch_tiles", "block_tiles", "block_entries", "hub_columns", "hub_entries", "multi_window_tiles", "row_group_tiles",
-                "masked_block_tiles", "masked_block_entries", "stencil_mask_tiles", "stencil_mask_entries"]
+                "masked_block_tiles", "masked_block_entries", "stencil_mask_tiles", "stencil_mask_entries",
+                "group_tiles", "group_entries", "group_rows"]
         return dict(zip(keys, out.tolist()))
 
     def confirm_blocks(self, d_row_ptr, d_col, host_row_ptr=None, stream=0):

@@ -52,43 +52,6 @@ def stencil3d_2d(n, seed=1):
     return n * n, n * n, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
 
 
-def mesh_dofs(grid, d, seed=1, jitter_share=0.3):
-    """An unstructured-looking mesh: nodes of a gx x gy x gz grid, each linked to its 27 grid neighbours, 30 % of the links ending up to
-    3 nodes beside their grid neighbour (no two rows are shifted copies of each other); d unknowns per node, numbered node by node:
-    dense d x d blocks, the d rows of a node with the same columns.  (d = 3: what synthetic:queen is; d = 2 / 4: no 3 x 3 blocks.)"""
-    rng = np.random.default_rng(seed)
-    gx, gy, gz = grid
-    n = gx * gy * gz
-    z, y, x = np.meshgrid(np.arange(gz), np.arange(gy), np.arange(gx), indexing="ij")
-    z, y, x = z.ravel(), y.ravel(), x.ravel()
-    rows, cols = [], []
-    for dz in (-1, 0, 1):
-        for dy in (-1, 0, 1):
-            for dx in (-1, 0, 1):
-                zz, yy, xx = z + dz, y + dy, x + dx
-                good = (zz >= 0) & (zz < gz) & (yy >= 0) & (yy < gy) & (xx >= 0) & (xx < gx)
-                c = (zz * gy + yy) * gx + xx
-                if (dz, dy, dx) != (0, 0, 0):
-                    moved = rng.random(n) < jitter_share
-                    c = np.where(moved, c + rng.integers(-3, 4, size=n), c)
-                    good &= (c >= 0) & (c < n)
-                rows.append(np.arange(n)[good])
-                cols.append(c[good])
-    key = np.unique(np.concatenate(rows).astype(np.int64) * n + np.concatenate(cols))
-    rn, cn = key // n, key % n
-    lens_n = np.bincount(rn, minlength=n)
-    pn = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(lens_n, out=pn[1:])
-    seg = ((cn * d)[:, None] + np.arange(d)).ravel()          # node i: its row's columns, pn[i] * d ... pn[i + 1] * d
-    node = np.repeat(np.arange(n), d)                          # expanded row -> node
-    starts, lens = pn[node] * d, lens_n[node] * d
-    p = np.zeros(n * d + 1, dtype=np.int64)
-    np.cumsum(lens, out=p[1:])
-    idx = np.repeat(starts - p[:-1], lens) + np.arange(int(p[-1]))
-    c = seg[idx].astype(np.int32)
-    return n * d, n * d, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
-
-
 def zoo():
     from spmv_amd import synth
     seven = [(0, 0, 0), (0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)]
@@ -147,12 +110,12 @@ def zoo():
         B.sort_indices()
         return rows, cols, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data
     out["queen_dof_major_rcm"] = queen_dof_major_rcm
-    out["mesh_1dof_160x120x100"] = lambda: mesh_dofs((160, 120, 100), 1)
-    out["mesh_2dof_100x80x70"] = lambda: mesh_dofs((100, 80, 70), 2)
-    out["mesh_3dof_100x80x70"] = lambda: mesh_dofs((100, 80, 70), 3)
-    out["mesh_4dof_100x80x60"] = lambda: mesh_dofs((100, 80, 60), 4)
-    out["mesh_5dof_80x60x60"] = lambda: mesh_dofs((80, 60, 60), 5)
-    out["mesh_6dof_80x60x50"] = lambda: mesh_dofs((80, 60, 50), 6)
+    out["mesh_1dof_160x120x100"] = lambda: synth.mesh_dofs((160, 120, 100), 1)
+    out["mesh_2dof_100x80x70"] = lambda: synth.mesh_dofs((100, 80, 70), 2)
+    out["mesh_3dof_100x80x70"] = lambda: synth.mesh_dofs((100, 80, 70), 3)
+    out["mesh_4dof_100x80x60"] = lambda: synth.mesh_dofs((100, 80, 60), 4)
+    out["mesh_5dof_80x60x60"] = lambda: synth.mesh_dofs((80, 60, 60), 5)
+    out["mesh_6dof_80x60x50"] = lambda: synth.mesh_dofs((80, 60, 50), 6)
     out["ragged_1-8_near"] = lambda: ragged(8000000, 1, 8, 2000, 3)
     out["ragged_4-40_near"] = lambda: ragged(3000000, 4, 40, 5000, 4)
     out["ragged_20-100_near"] = lambda: ragged(1200000, 20, 100, 20000, 5)
