@@ -353,6 +353,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     auto group_start = [gb, rows](int32_t q) { return q >= rows || ((gb[q >> 5] >> (q & 31)) & 1u) != 0; };
     auto triple_at = [&](int32_t q) { return q + 3 <= rows && group_start(q) && !group_start(q + 1) && !group_start(q + 2) && group_start(q + 3); };
     pl->block_candidate = 0;
+    pl->hint_from_bits = gb != nullptr;
     if (gb) {
         pl->block_hint = 3;
         pl->block_offset = 0;
@@ -360,7 +361,8 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
         pl->block_hint = 0;
         pl->block_offset = 0;
         if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
-            for (int o = 0; o < 3 && !pl->block_hint; ++o) {
+            // (pl->hints_tried: a hint that repack found wrong is not taken again when the tiles are cut anew -- the next one gets its turn)
+            for (int o = 0; o < 3 && !pl->block_hint && !(pl->hints_tried & 1); ++o) {
                 // (an offset is given up as soon as a fifth of all triples have failed: a matrix without blocks -- most -- pays for a
                 // fifth of one pass per offset, not for three passes over row_ptr)
                 const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
@@ -381,7 +383,7 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             // strict rule as for triples (four fifths of the groups: rows longer than 16 entries, all equally long, the length a
             // multiple of the group size, a whole group no longer than a tile), tried for 4 before 2; tiles are then cut on multiples of
             // that many rows.
-            for (int d = 4; d >= 2 && !pl->block_hint; d -= 2)
+            for (int d = 4; d >= 2 && !pl->block_hint && !(pl->hints_tried & 2); d -= 2)
                 for (int o = 0; o < d && !pl->block_hint; ++o) {
                     const long long groups = (rows - o) / d, allowed_bad = groups / 5;
                     long long good = 0, bad = 0;
@@ -1311,6 +1313,8 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
                          const int32_t * host_row_ptr = nullptr /* the caller still has it: no copy back */)
 {
     const bool with_blocks = group_bits != nullptr;
+    const int wrong_hint = pl->block_hint;
+    const bool wrong_from_bits = pl->hint_from_bits;
     const bool was_compressed = pl->d_col16 != nullptr; // (a plan that has not been classified yet is not classified here either)
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<int32_t> hp;
@@ -1341,8 +1345,14 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
     pl->block_entries = pl->masked_block_entries = 0;
     pl->meta_bytes = 0;
     pl->compressed_from = nullptr;
-    if (!with_blocks)
-        pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
+    if (!with_blocks) {
+        // a hint read from row_ptr alone was wrong: it is not taken again, the others (triples / groups of 2 or 4 / the candidate
+        // whose columns are looked at) still get their turn; groups found in the columns themselves that made no block tiles end it
+        if (wrong_from_bits || wrong_hint == 0)
+            pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
+        else
+            pl->hints_tried |= wrong_hint == 3 ? 1 : 2;
+    }
     pl->group_bits = group_bits;
     int rc = build_wave_tiles(pl, host_row_ptr, pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
     pl->group_bits = nullptr;
@@ -1408,6 +1418,9 @@ int spmv_hip_plan_csr_confirm_blocks(spmv_hip_plan * pl, const int32_t * d_row_p
 static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const int32_t * d_column_index, const double * d_value,
                          void * stream, const double ** reindex)
 {
+    // (a hint that turns out wrong makes the tiles anew, and the next hint -- or the candidate -- gets its turn: at most four rounds)
+    for (int attempt = 0; attempt < 4; ++attempt) {
+    bool hint_was_wrong = false;
     if (pl->d_col16 && pl->compressed_from == d_column_index) {
         int rc = confirm_block_candidate(pl, d_row_ptr, d_column_index, stream, reindex, nullptr);
         if (rc != SPMV_HIP_OK)
@@ -1474,11 +1487,15 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             int rc = rebuild_tiles(pl, d_row_ptr, d_column_index, stream, nullptr, reindex);
             if (rc != SPMV_HIP_OK)
                 return rc;
+            hint_was_wrong = true;
         } else if (pl->block_tiles > 0 || pl->colshare_tiles > 0) {
             int rc = plan_account(pl, true);
             if (rc != SPMV_HIP_OK)
                 return rc;
         }
+    }
+    if (!hint_was_wrong)
+        break;
     }
     // masked stencil tiles (csr_stenciltile.hpp): the boundary rows of a structured grid (after the block stage: should that one
     // cut the tiles anew -- a wrong hint -- the marks made here would go with the old tiles)

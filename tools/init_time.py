@@ -23,7 +23,7 @@ def main():
         for rep in range(2):
             fresh = (p.copy(), c.copy(), v.copy())
             t0 = time.perf_counter()
-            ctx = capi.Context(0, capi.FLAG_NO_RUN_EVENTS)
+            ctx = capi.Context(0, capi.FLAG_NO_RUN_EVENTS | int(os.environ.get("INIT_FLAGS", "0"), 0))  # INIT_FLAGS: extra SPMV_HIP_FLAG_* bits
             t1 = time.perf_counter()
             ctx.upload_csr(rows, cols, *fresh)
             t2 = time.perf_counter()

@@ -158,10 +158,10 @@ def main():
             if rnd > 0:
                 best = us if best is None else min(best, us)
         alg = synth.csr_bytes(rows, cols, nnz)
-        print("%-22s %9d rows %6.1f/row  %8.1f us  frac(8d) %.3f  streamed/triad %.3f  tiles %d: narrow %d shifted %d xwin %d blockwin %d segwin %d panels %d block %d multi %d long %d balanced %d stencil-masked %d  (setup %.0f s)"
+        print("%-22s %9d rows %6.1f/row  %8.1f us  frac(8d) %.3f  streamed/triad %.3f  tiles %d: narrow %d shifted %d xwin %d blockwin %d segwin %d panels %d block %d group %d multi %d long %d balanced %d stencil-masked %d  (setup %.0f s)"
               % (name, rows, nnz / rows, best, alg / (best * 1e-6) / 8e12, info["streamed_bytes"] / (best * 1e-6) / 1e9 / triad, info["row_blocks"],
                  info["narrow_tiles"], info["shifted_tiles"], info["xwin_tiles"], info["blockwin_tiles"], info["segwin_tiles"], info["panel_tiles"],
-                 info["block_tiles"], info["multi_window_tiles"], info["long_blocks"], info["balanced"], info["stencil_mask_tiles"], time.perf_counter() - t0), flush=True)
+                 info["block_tiles"], info["group_tiles"], info["multi_window_tiles"], info["long_blocks"], info["balanced"], info["stencil_mask_tiles"], time.perf_counter() - t0), flush=True)
         plan.close()
         del tp, tc, tv, tx, ty
         torch.cuda.empty_cache()
