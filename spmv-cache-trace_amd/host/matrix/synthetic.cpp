@@ -257,8 +257,10 @@ csr_matrix::Matrix poisson3d(long long n, long long rb, long long re, long long 
 // The less tidy twins (round 5; what real finite-element files do): `broken` per mille of the off-diagonal 3 x 3 blocks have one
 // or two of their nine entries missing (explicit zeros the assembly dropped), and with `odd_every` = K > 0 every K-th node has
 // only one or two unknowns (a constraint node, a pressure node), which moves the grid of row and column triples behind it.
+// `dof` (7th number of the spec; default 3): unknowns per node -- 2 or 4 give a mesh without 3 x 3 blocks whose rows still come in groups
+// with the same columns (the group tiles of csrc/csr_blocktile.hpp); broken blocks and odd nodes are defined for 3 only.
 csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb, long long re, long long * total, long long jitter_nodes = 3,
-                         long long broken = 0, long long odd_every = 0)
+                         long long broken = 0, long long odd_every = 0, long long dof = 3)
 {
     if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
         throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
@@ -266,12 +268,15 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
         throw matrix::matrix_error("synthetic:queen:gx,gy,gz,<J>: a jittered link ends J nodes away, 3 <= J <= 4096");
     if (broken < 0 || broken > 1000 || odd_every < 0 || odd_every == 1)
         throw matrix::matrix_error("synthetic:queen:gx,gy,gz,J,<broken per mille>,<odd node every K>: 0 <= broken <= 1000, K = 0 or K >= 2");
+    if (dof < 1 || dof > 8 || (dof != 3 && (broken != 0 || odd_every != 0)) || gx * gy > 2000000000LL / gz / dof)
+        throw matrix::matrix_error("synthetic:queen:gx,gy,gz,J,broken,odd,<unknowns per node>: 1 .. 8, and broken blocks / odd nodes only with 3");
     long long const nodes = gx * gy * gz;
+    int const D = (int) dof;
     std::uint64_t const seedJ = 0x51DE, seedQ = 0x0EE2, seedB = 0xB20CE, seedO = 0x0DD;
     // unknowns per node and the first row (= column) of every node
     auto dofs = [=](long long n) -> int {
         if (odd_every == 0 || n % odd_every != odd_every / 2)
-            return 3;
+            return D;
         return 1 + (int) (h2(seedO, (std::uint64_t) n) & 1);
     };
     std::vector<long long> first_row;
@@ -281,13 +286,13 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
         for (long long n = 0; n < nodes; ++n)
             first_row[(std::size_t) n + 1] = first_row[(std::size_t) n] + dofs(n);
     }
-    auto row0 = [&](long long n) { return odd_every > 0 ? first_row[(std::size_t) n] : 3 * n; };
+    auto row0 = [&](long long n) { return odd_every > 0 ? first_row[(std::size_t) n] : D * n; };
     long long const N = row0(nodes);
     if (total) *total = N;
     if (re < 0) re = N;
     auto node_of = [&](long long r) {
         if (odd_every == 0)
-            return r / 3;
+            return r / D;
         return (long long) (std::upper_bound(first_row.begin(), first_row.end(), r) - first_row.begin()) - 1;
     };
     long long const J = jitter_nodes; // a jittered link's far end is moved by J nodes (3 by default; more = the pessimistic twin)
@@ -369,7 +374,7 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
     auto len = [&](long long r) -> long long {
         long long const n = node_of(r);
         if (plain)
-            return 3 * (node_ptr[(std::size_t) n + 1] - node_ptr[(std::size_t) n]);
+            return D * (node_ptr[(std::size_t) n + 1] - node_ptr[(std::size_t) n]);
         int const a = (int) (r - row0(n));
         long long c = 0;
         for (long long q = node_ptr[(std::size_t) n]; q < node_ptr[(std::size_t) n + 1]; ++q) {
@@ -387,7 +392,7 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
             long long const m = nbr[(std::size_t) q];
             std::uint64_t const edge = h2(h2(seedQ, (std::uint64_t) std::min(n, m)), (std::uint64_t) std::max(n, m));
             unsigned const gone = plain ? 0u : dropped(n, m) >> (3 * a);
-            int const mb = plain ? 3 : dofs(m);
+            int const mb = plain ? D : dofs(m);
             for (int b = 0; b < mb; ++b) {
                 if ((gone >> b) & 1u)
                     continue;
@@ -395,11 +400,11 @@ csr_matrix::Matrix queen(long long gx, long long gy, long long gz, long long rb,
                 int const ia = n < m ? a : b, ib = n < m ? b : a;
                 double v;
                 if (n == m) {
-                    v = u11(h2(edge, (std::uint64_t) (std::min(a, b) * 3 + std::max(a, b))));
+                    v = u11(h2(edge, (std::uint64_t) (std::min(a, b) * (D > 3 ? D : 3) + std::max(a, b))));
                     if (a == b)
                         v += 30.0;
                 } else {
-                    v = u11(h2(edge, (std::uint64_t) (ia * 3 + ib)));
+                    v = u11(h2(edge, (std::uint64_t) (ia * (D > 3 ? D : 3) + ib)));
                 }
                 *col++ = (index_type) (row0(m) + b);
                 *val++ = v;
@@ -679,13 +684,13 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
         check_range(2 * n * n * n + 6 * n * n);
         A = kkt(n, rb, re, &tot, v.size() > 1 ? v[1] : 0);
     } else if (family == "queen") {
-        if (!v.empty() && (v.size() < 3 || v.size() > 6))
-            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz[,J[,broken per mille[,odd node every K]]]] takes three to six numbers");
+        if (!v.empty() && (v.size() < 3 || v.size() > 7))
+            throw matrix::matrix_error("synthetic:queen[:gx,gy,gz[,J[,broken per mille[,odd node every K[,unknowns per node]]]]] takes three to seven numbers");
         long long const gx = v.empty() ? 110 : v[0], gy = v.empty() ? 71 : v[1], gz = v.empty() ? 177 : v[2];
         if (gx < 1 || gy < 1 || gz < 1 || gx > 100000 || gy > 100000 || gz > 100000 || gx * gy > 700000000LL / gz)
             throw matrix::matrix_error("synthetic:queen: bad mesh dimensions");
-        check_range(3 * gx * gy * gz);
-        A = queen(gx, gy, gz, rb, re, &tot, v.size() > 3 ? v[3] : 3, v.size() > 4 ? v[4] : 0, v.size() > 5 ? v[5] : 0);
+        check_range((v.size() > 6 ? std::max(1LL, std::min(8LL, v[6])) : 3) * gx * gy * gz);
+        A = queen(gx, gy, gz, rb, re, &tot, v.size() > 3 ? v[3] : 3, v.size() > 4 ? v[4] : 0, v.size() > 5 ? v[5] : 0, v.size() > 6 ? v[6] : 3);
     } else if (family == "webbase" || family == "powerlaw") {
         bool const web = family == "webbase";
         if (v.size() > (web ? 4u : 3u))

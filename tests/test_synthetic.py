@@ -41,7 +41,8 @@ def _check_sorted_unique(A):
     assert A.column_index.min() >= 0 and A.column_index.max() < A.cols
 
 
-@pytest.mark.parametrize("spec,rows", [("synthetic:kkt:7", 2 * 343 + 6 * 49), ("synthetic:queen:6,5,7", 3 * 210)])
+@pytest.mark.parametrize("spec,rows", [("synthetic:kkt:7", 2 * 343 + 6 * 49), ("synthetic:queen:6,5,7", 3 * 210),
+                                       ("synthetic:queen:6,5,7,3,0,0,2", 2 * 210), ("synthetic:queen:6,5,7,3,0,0,4", 4 * 210)])
 def test_kkt_and_queen_are_symmetric_with_ascending_columns(spec, rows):
     import scipy.sparse as sp
     A = hostapi.load(spec)
@@ -49,6 +50,16 @@ def test_kkt_and_queen_are_symmetric_with_ascending_columns(spec, rows):
     _check_sorted_unique(A)
     M = sp.csr_matrix((A.value, A.column_index, A.row_ptr), shape=(A.rows, A.cols))
     assert abs(M - M.T).max() == 0.0  # structure AND values
+    if spec.count(",") == 6:  # d unknowns per node: the d rows of a node have the same columns, in runs of d
+        d = int(spec.rsplit(",", 1)[1])
+        lens = np.diff(A.row_ptr)
+        assert (lens % d == 0).all()
+        for node in (0, 17, 209):
+            rows_of = [A.column_index[A.row_ptr[node * d + a]:A.row_ptr[node * d + a + 1]] for a in range(d)]
+            assert all(np.array_equal(rows_of[0], r) for r in rows_of[1:])
+            assert np.array_equal(rows_of[0][:d], rows_of[0][0] + np.arange(d))
+        with pytest.raises(Exception):
+            hostapi.load("synthetic:queen:6,5,7,3,20,0,2")  # broken blocks are defined for 3 unknowns per node only
     if "kkt" in spec:
         n = 7
         lens = np.diff(A.row_ptr)

@@ -44,6 +44,8 @@ run queen_csr_noblocks --workload queen --flags 0x2000000
 # round 5: the less tidy twins of the queen-like stand-in (masked block tiles) and the 7-point Laplacian on a 256^3 grid (masked stencil tiles)
 run queen_csr_broken2pct --matrix synthetic:queen:110,71,177,3,20
 run queen_csr_oddnodes --matrix synthetic:queen:110,71,177,3,20,1000
+run mesh_2dof_csr --matrix synthetic:queen:100,80,70,3,0,0,2
+run mesh_4dof_csr --matrix synthetic:queen:100,80,60,3,0,0,4
 run poisson3d_csr --matrix synthetic:poisson3d:256
 # the launches of tests/test_gpu_perf_floor.py measured on this box -- measured and logged only: updating the committed table
 # (tests/golden/perf_floor.json) is an explicit, reviewed step (python3 tools/perf_floor.py --write), never a side effect of a

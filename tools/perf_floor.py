@@ -52,6 +52,8 @@ WORKLOADS = {
     "banded2001_csr": ("synthetic:banded:100000,1000", "csr", 0),         # CSR rows of more than 1024 entries: the same path
     "queen_small_broken_csr": ("synthetic:queen:80,60,60,3,20,500", "csr", 0),  # masked block tiles (round 5): dropped entries, odd nodes
     "poisson3d_256_csr": ("synthetic:poisson3d:256", "csr", 0x100000),   # grid lines of 256 cells: masked stencil tiles (round 5), values read
+    "mesh_2dof_csr": ("synthetic:queen:100,80,70,3,0,0,2", "csr", 0),     # 2 / 4 unknowns per node: group tiles (end of round 5)
+    "mesh_4dof_csr": ("synthetic:queen:100,80,60,3,0,0,4", "csr", 0),
 }
 
 
@@ -61,7 +63,8 @@ TOLERANCE = {"bandwidth": 1.10, "latency": 1.15}  # (1.07 failed twice on the po
 # a wave per long row spreads more between boxes than the triad does (bands of 2001 per row: 0.76 ... 0.86 of the roofline on
 # five boxes of one afternoon, profiles/r05_results.md): these rows carry their own gate
 # ... and so do the queen-like and kkt-like launches (full size: 462 ... 510 us and 743 ... 803 us on boxes with the same triad)
-ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12}
+ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12,
+                 "mesh_2dof_csr": 1.15, "mesh_4dof_csr": 1.15}  # (the two mesh rows: one box measured so far, end of round 5)
 
 
 _TRIAD = {}
