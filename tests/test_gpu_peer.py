@@ -100,6 +100,8 @@ def _worker(rank, world, port, out_dir, spec, fused, balanced, need=None):
     (2, "synthetic:queen:20,15,10,3,20,97", True, False, "masked_block_tiles"),  # 3 x 3 blocks with entries missing, odd nodes
     (2, "synthetic:poisson3d:40", True, False, "stencil_mask_tiles"),            # masked stencil tiles, values read
     (2, "synthetic:poisson3d:40,1", True, False, "stencil_mask_tiles"),          # ... and with the value dictionary
+    (2, "synthetic:queen:20,15,10,3,0,0,2", True, False, "group_tiles"),         # 2 unknowns per node: group tiles (one column list per pair of rows)
+    (3, "synthetic:queen:20,15,10,3,0,0,4", True, False, "group_tiles"),         # 4 per node, three ranks
     (2, "synthetic:random:3000,600", True, False, "multi_window_tiles"),         # rows of 600 entries sharing a tile through LDS
     (2, "synthetic:random:40000,600", True, False, "multi_window_tiles"),        # ... and, the matrix large enough, in registers
 ])
