@@ -71,6 +71,10 @@ __host__ __device__ __forceinline__ int mask_stream_index(int k0) { return k0 >>
 // (structure sweep, profiles/r05_zoo_mesh_dofs.log: meshes with 2 / 4 unknowns per node 0.79 / 0.80 of the roofline against 1.05 / 1.10
 // with 3 / 6)
 constexpr int kTileMetaGroupRows = 1 << 30; // only together with kTileMetaBlock3 (a block tile has no x window: the window bits are free)
+// ... and, with kTileMetaGroupRows: every PAIR of group columns the multiply takes is (c, c + 1) -- the dense 2 x 2 / 4 x 4 blocks of a mesh
+// with 2 / 4 unknowns per node -- so x is read 16 bytes at a time, one gather per pair, and the group stream holds one column per pair:
+// 1 / D bytes per entry (the bit that marks masked 3 x 3 blocks otherwise)
+constexpr int kTileMetaGroupPairs = 1 << 29;
 // the group stream shares the block stream's place behind the 16-bit columns (a plan has 3 x 3 blocks or row groups, not both);
 // a tile's group entries start at k0 / D: every tile in front of it holds at most (its entries / D)
 __host__ __device__ __forceinline__ int group_stream_index(int k0, int d) { return k0 / d; }
@@ -447,7 +451,7 @@ template <int D>
 __device__ __forceinline__ void tile_products_grouped(
     double * prod, const uint16_t * __restrict__ gt /* the tile's group stream */, const double * __restrict__ at /* a + kb */,
     const double * __restrict__ xt /* x + tile base */, unsigned limit, int ps_rel, int row_len, int lanes_log2, int nrows, int first_rel /* k0 - kb */,
-    int entries, int lane)
+    int entries, int lane, bool adjacent /* every pair is (c, c + 1): kTileMetaGroupPairs */)
 {
     static_assert(D == 2 || D == 4, "row groups of 2 or 4");
     constexpr int STEPS = 4 / D; // a tile holds at most 512 / D group entries = 256 / D pairs: D = 2: 2 x 64, D = 4: 1 x 64
@@ -476,18 +480,27 @@ __device__ __forceinline__ void tile_products_grouped(
     for (int i = 0; i < STEPS; ++i) {
         int t = lane + 64 * i;
         t = t < pairs ? t : pairs - 1; // idle lanes repeat the last pair's loads and store nothing
-        c0[i] = gt[2 * t];
-        c1[i] = gt[2 * t + 1];
+        c0[i] = adjacent ? gt[t] : gt[2 * t]; // (adjacent pairs: the stream holds the first column of every pair only)
+        c1[i] = adjacent ? 0u : gt[2 * t + 1];
 #pragma unroll
         for (int a = 0; a < D; ++a)
             v[i][a] = *reinterpret_cast<const v2d_u8 *>(at + 2 * t + off[i] + a * len[i]);
     }
     const char * xb = reinterpret_cast<const char *>(xt);
     double x0[STEPS], x1[STEPS];
+    if (adjacent) { // wave-uniform: one 16-byte gather per pair of columns
 #pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        x0[i] = *reinterpret_cast<const double *>(xb + (min(c0[i], limit) << 3));
-        x1[i] = *reinterpret_cast<const double *>(xb + (min(c1[i], limit) << 3));
+        for (int i = 0; i < STEPS; ++i) {
+            const v2d_u8 xx = *reinterpret_cast<const v2d_u8 *>(xb + (min(c0[i], limit - 1u) << 3));
+            x0[i] = xx.x;
+            x1[i] = xx.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            x0[i] = *reinterpret_cast<const double *>(xb + (min(c0[i], limit) << 3));
+            x1[i] = *reinterpret_cast<const double *>(xb + (min(c1[i], limit) << 3));
+        }
     }
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
@@ -540,16 +553,29 @@ static __global__ __launch_bounds__(256) void csr_group_mark_kernel(
     }
     if (!__all(ok))
         return;
-    // the group stream: the first rows' columns, group after group
+    // is every pair of the first rows' columns (c, c + 1)?
+    int adjacent = 1;
+    for (int r = 0; r < nrows; r += d) {
+        const int start = __shfl(ps, r), rl = __shfl(len, r);
+        for (int q = 2 * lane + 1; q < rl; q += 2 * kWave)
+            adjacent &= j[start + q] == j[start + q - 1] + 1;
+    }
+    adjacent = __all(adjacent);
+    // the group stream: the first rows' columns, group after group -- every column, or (adjacent pairs) the first of each pair
     const int base = group_stream_index(k0, d);
     for (int r = 0; r < nrows; r += d) {
         const int start = __shfl(ps, r), rl = __shfl(len, r);
-        const int g0 = (start - k0) / d; // what the groups in front of this one hold
-        for (int q = lane; q < rl; q += kWave)
-            gstream[base + g0 + q] = (uint16_t) (j[start + q] - cmin);
+        const int g0 = (start - k0) / d; // what the groups in front of this one hold (even: row lengths are)
+        if (adjacent) {
+            for (int q = 2 * lane; q < rl; q += 2 * kWave)
+                gstream[base + (g0 + q) / 2] = (uint16_t) (j[start + q] - cmin);
+        } else {
+            for (int q = lane; q < rl; q += kWave)
+                gstream[base + g0 + q] = (uint16_t) (j[start + q] - cmin);
+        }
     }
     if (lane == 0) {
-        desc[w].z = meta | kTileMetaBlock3 | kTileMetaGroupRows;
+        desc[w].z = meta | kTileMetaBlock3 | kTileMetaGroupRows | (adjacent ? kTileMetaGroupPairs : 0);
         striped_add(count, 0, 1ull);
         striped_add(count, 1, (unsigned long long) n);
         if (!(meta & kTileMetaBlockWin)) {

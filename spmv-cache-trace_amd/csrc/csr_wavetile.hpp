@@ -848,9 +848,9 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
             // sums below are the plain tile's
             const uint16_t * gt = j16 + block_stream_offset(nnz_total) + group_stream_index(k0, group_rows);
             if (group_rows == 2)
-                tile_products_grouped<2>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane);
+                tile_products_grouped<2>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0);
             else
-                tile_products_grouped<4>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane);
+                tile_products_grouped<4>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0);
         }
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);

@@ -169,7 +169,7 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         }
         if (block3 && (meta & spmv::kTileMetaGroupRows)) { // group tile: one 16-bit column per column of a group of block_hint rows; row_ptr read
             pl->narrow_entries += entries;
-            bytes += 8 * entries + 2 * (entries / std::max(1, pl->block_hint)) + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+            bytes += 8 * entries + ((meta & spmv::kTileMetaGroupPairs) ? 1 : 2) * (entries / std::max(1, pl->block_hint)) + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
             if (uniform)
                 pl->uniform_rows += rows;
             continue;
