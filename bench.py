@@ -1389,6 +1389,7 @@ def main():
                            "tiles_reading_no_value_stream": info.get("value_row_tiles", 0),
                            "tiles_of_the_dictionary_launch": info.get("dictionary_launch_tiles", 0),
                            "block_tiles": info.get("block_tiles", 0), "masked_block_tiles": info.get("masked_block_tiles", 0),
+                           "group_tiles": info.get("group_tiles", 0), "rows_per_group": info.get("group_rows", 0),
                            "masked_stencil_tiles": info.get("stencil_mask_tiles", 0), "multi_window_tiles": info.get("multi_window_tiles", 0),
                            "long_row_tiles": info.get("long_blocks", 0)})
         else:

@@ -132,7 +132,10 @@ extern "C" {
                                              of dense 3 x 3 blocks (checked entry by entry): such a tile reads one 16-bit number per
                                              BLOCK instead of a column index per entry and no row_ptr (8.2 instead of 10 bytes per
                                              entry).  Only rows of more than 16 entries (1e-10 class either way); never under
-                                             SPMV_HIP_FLAG_EXACT_ORDER */
+                                             SPMV_HIP_FLAG_EXACT_ORDER.  The flag also switches off the GROUP TILES of meshes with 2 or 4
+                                             unknowns per node (rows in groups of 2 or 4 equally long rows with the same columns: one
+                                             16-bit column list per group, one 16-byte gather of x per pair of adjacent columns;
+                                             plan_info[35..37]) and every hint read from row_ptr for either */
 /* 0x4000000u and 0x10000000u are not flags of this library: two kernel families that were measured SLOWER than the paths they
  * were meant to replace (hub columns for web graphs, 26.6 vs 23.9 us; a lane group per row for stencil rows of 17 ... 64
  * entries, 797 vs 740 us: DESIGN.md sections 3.3, 3.1b) were retired from the product library in round 5 and are
@@ -333,6 +336,11 @@ int spmv_hip_plan_verify(spmv_hip_plan *plan, const int32_t *d_column_index, voi
  * boundaries) every tile of rows longer than 16 entries is checked entry by entry for dense 3 x 3 blocks; a tile that
  * has them reads one 16-bit number per block from a plan-owned side stream instead of a column index per entry, and no
  * row_ptr.  The CSR arrays are read in place; y stays within 1e-10 (such rows are summed by several lanes either way).
+ * Likewise GROUP TILES (plan_info[35]): where the rows come in groups of 2 or 4 equally long rows (2 or 4 unknowns per mesh node)
+ * every tile is checked entry by entry for identical column lists within its groups; a tile that has them reads the first
+ * row's 16-bit columns of each group from the side stream (one per PAIR where the pairs are adjacent columns) and sums its rows
+ * exactly as before.  A hint from row_ptr that the columns do not bear out costs a second cut of the tiles (plan time only) and
+ * hands over to the next one: triples, groups of 4 / 2, then the rows of merely similar length whose columns are looked at.
  * SPMV_HIP_FLAG_NO_BLOCK_TILES / SPMV_HIP_FLAG_EXACT_ORDER switch it off. */
 int spmv_hip_plan_csr_repack(spmv_hip_plan *plan, const int32_t *d_row_ptr, const int32_t *d_column_index,
                              const double *d_value, void *stream);
