@@ -119,9 +119,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="poisson2d",
-                    choices=["poisson2d", "queen", "kkt", "webbase", "powerlaw", "banded", "random24", "stencil27", "random"],
+                    choices=["poisson2d", "queen", "kkt", "queen_stored", "kkt_stored", "webbase", "powerlaw", "banded", "random24", "stencil27", "random"],
                     help="poisson2d = BASELINE configs[1]; queen / kkt / webbase = generated stand-ins of configs[2..4] "
-                         "at full size; powerlaw = webbase with uniformly scattered columns; banded / random24 = north_star's synthetic banded / "
+                         "at full size (symmetric structure EXPANDED, the entry counts BASELINE.json quotes); queen_stored / kkt_stored = the stored "
+                         "lower triangle of the same matrices: what a `symmetric` Matrix Market file holds and the reference multiplies "
+                         "(it mirrors nothing); powerlaw = webbase with uniformly scattered columns; banded / random24 = north_star's synthetic banded / "
                          "random CSR of ~100 M entries (SURVEY 8d S-banded, S-random); stencil27 / random: round-1 numpy stand-ins")
     ap.add_argument("--matrix", default=None, help="Matrix Market file (.mtx, .gz, .tgz, .tar.gz) or synthetic:<spec>; overrides --workload")
     ap.add_argument("--expand-symmetric", action="store_true",
@@ -185,6 +187,10 @@ def parse_args():
     return ap.parse_args()
 
 
+QUEEN_STORED_NAME = "queen-like 110x71x177 mesh x 3 dof, stored lower triangle (Queen_4147.mtx as the reference multiplies it)"
+KKT_STORED_NAME = "kkt-27pt-%d^3, stored lower triangle (nlpkkt%d.mtx as the reference multiplies it)"
+
+
 def workload_spec(args):
     """(spec for the host library or None, short name)."""
     if args.matrix:
@@ -195,6 +201,10 @@ def workload_spec(args):
         return "synthetic:kkt:%d" % args.kkt_grid, "kkt-27pt-%d^3 (nlpkkt%d-like)" % (args.kkt_grid, args.kkt_grid)
     if args.workload == "queen":
         return "synthetic:queen", "queen-like 110x71x177 mesh x 3 dof (Queen_4147-like)"
+    if args.workload == "queen_stored":
+        return "synthetic:queen:tril", QUEEN_STORED_NAME
+    if args.workload == "kkt_stored":
+        return "synthetic:kkt:%d:tril" % args.kkt_grid, KKT_STORED_NAME % (args.kkt_grid, args.kkt_grid)
     if args.workload == "webbase":
         return "synthetic:webbase", "webbase-like power law, 75% host-local links (webbase-1M-like)"
     if args.workload == "powerlaw":
@@ -726,7 +736,11 @@ def companion(torch, capi, hostapi, synth, args, device, stream, spec, fmt, name
         alg_bytes = synth.csr_bytes(rows, cols, nnz)
         host_arrays = {"p": p, "c": c, "v": v}
         extra = {"tiles": info["row_blocks"], "tiles_with_16bit_columns": info["narrow_tiles"], "shifted_tiles": info["shifted_tiles"],
-                 "segment_window_tiles": info["segwin_tiles"], "block_row_tiles": info.get("block_tiles", 0), "balanced_tiles": bool(info["balanced"]),
+                 "segment_window_tiles": info["segwin_tiles"], "block_row_tiles": info.get("block_tiles", 0),
+                 "masked_block_tiles": info.get("masked_block_tiles", 0), "stencil_mask_tiles": info.get("stencil_mask_tiles", 0),
+                 "group_tiles": info.get("group_tiles", 0), "multi_window_tiles": info.get("multi_window_tiles", 0),
+                 "entries_in_block_tiles": info.get("block_entries", 0) + info.get("masked_block_entries", 0), "entries_in_shifted_tiles": info.get("shifted_entries", 0),
+                 "balanced_tiles": bool(info["balanced"]),
                  "value_dictionary_size": info["indexed_values"], "plan_ms": plan_ms}
     else:
         op = ContextOperator(fmt, M, x, device.index or 0, flags | capi.FLAG_NO_RUN_EVENTS, stream)
@@ -1354,6 +1368,12 @@ def main():
             and not args.no_companions):
         companions["config2_queen"] = companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:queen", "csr",
                                                 "queen-like 110x71x177 mesh x 3 dof (Queen_4147-like), csr", flags, algo)
+        # round 6: the reference's DEFAULT semantics for the two SuiteSparse files -- a `symmetric` file's stored
+        # triangle, nothing mirrored (src/matrix/matrix-market.cpp:396-414, :530-555): section-8(d) bytes of the STORED matrix
+        companions["config2_queen_stored"] = companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:queen:tril", "csr",
+                                                       QUEEN_STORED_NAME + ", csr", flags, algo)
+        companions["config3_kkt_stored"] = companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:kkt:200:tril", "csr",
+                                                     KKT_STORED_NAME % (200, 200) + ", csr", flags, algo)
         companions["config4_webbase"] = {
             f: companion(torch, capi, hostapi, synth, args, device, stream, "synthetic:webbase", f,
                          "webbase-like power law, 75%% host-local links (webbase-1M-like), %s" % f, flags, algo, steps=50, warmup=10)

@@ -111,7 +111,8 @@ int spmv_host_load(const char * path, int format, unsigned flags, spmv_host_matr
     m->format = format;
     int const rc = guarded([&] {
         std::string const p = path;
-        if (format == SPMV_HOST_FORMAT_CSR && plain_spec(p)) {
+        // (a stored triangle that is to be expanded takes the loader's way: generate -> mirror -> convert)
+        if (format == SPMV_HOST_FORMAT_CSR && plain_spec(p) && !((flags & SPMV_HOST_EXPAND_SYMMETRIC) && synthetic::is_stored_triangle(p))) {
             m->csr = synthetic::generate_csr(p);
             m->rows_total = m->csr.rows;
             return;
@@ -150,7 +151,7 @@ int spmv_host_load_csr_rows(const char * path, unsigned flags, int64_t row_begin
     m->format = SPMV_HOST_FORMAT_CSR;
     int const rc = guarded([&] {
         std::string const p = path;
-        if (plain_spec(p)) {
+        if (plain_spec(p) && !((flags & SPMV_HOST_EXPAND_SYMMETRIC) && synthetic::is_stored_triangle(p))) {
             m->csr = synthetic::generate_csr(p, row_begin, row_end, &m->rows_total);
             return;
         }

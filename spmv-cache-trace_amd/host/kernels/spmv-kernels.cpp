@@ -48,7 +48,8 @@ matrix_market::Matrix load(std::string const & path, SpmvOptions const & opt, st
 // entries); files and reordered specs go through the loader and the converter like in the reference
 csr_matrix::Matrix load_csr(std::string const & path, SpmvOptions const & opt, std::ostream & o, bool verbose)
 {
-    if (synthetic::is_spec(path) && path.find("__RCM") == std::string::npos && path.find("__GP") == std::string::npos) {
+    if (synthetic::is_spec(path) && path.find("__RCM") == std::string::npos && path.find("__GP") == std::string::npos &&
+        !(opt.expand_symmetric && synthetic::is_stored_triangle(path))) {
         if (verbose)
             o << "Generating matrix " << path << '\n';
         return synthetic::generate_csr(path);

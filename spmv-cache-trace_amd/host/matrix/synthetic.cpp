@@ -637,15 +637,54 @@ csr_matrix::Matrix random_columns(long long N, long long k, std::uint64_t seed, 
     return build(N, N, rb, re, len, fill);
 }
 
+// ---- ":tril": what a Matrix Market file with a `symmetric` header holds of a structurally symmetric matrix ----------------
+// The reference stores exactly the entries of the file and mirrors nothing (src/matrix/matrix-market.cpp:396-414 parses the
+// token, :530-555 keeps the entries as read; README.md:106: 1138_bus has "nonzeros": 2596, its stored triangle), so what it
+// multiplies when handed Queen_4147.tar.gz / nlpkkt200.tar.gz is the LOWER TRIANGLE, diagonal included: rows whose length
+// grows with the number of neighbours numbered before them, triangular diagonal blocks, half stencils.  Keeps the entries with
+// column <= row of the rows [rb, rb + A.rows) of a generated matrix; two passes, every row on its own.
+csr_matrix::Matrix lower_triangle(csr_matrix::Matrix const & A, long long rb)
+{
+    long long const nr = A.rows;
+    csr_matrix::size_array_type row_ptr((std::size_t) nr + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < nr; ++r) {
+        index_type const * const c = A.column_index.data();
+        size_type const k0 = A.row_ptr[(std::size_t) r], k1 = A.row_ptr[(std::size_t) r + 1];
+        // columns ascend inside a row: the stored part is a prefix
+        row_ptr[(std::size_t) r + 1] = (size_type) (std::upper_bound(c + k0, c + k1, (index_type) (rb + r)) - (c + k0));
+    }
+    for (long long r = 0; r < nr; ++r)
+        row_ptr[(std::size_t) r + 1] += row_ptr[(std::size_t) r];
+    std::size_t const Z = (std::size_t) row_ptr[(std::size_t) nr];
+    csr_matrix::index_array_type col(Z);
+    csr_matrix::value_array_type val(Z);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (long long r = 0; r < nr; ++r) {
+        size_type const k0 = A.row_ptr[(std::size_t) r], d0 = row_ptr[(std::size_t) r], n = row_ptr[(std::size_t) r + 1] - d0;
+        std::copy_n(A.column_index.data() + k0, n, col.data() + d0);
+        std::copy_n(A.value.data() + k0, n, val.data() + d0);
+    }
+    return csr_matrix::Matrix((index_type) nr, A.columns, (size_type) Z, 1, std::move(row_ptr), std::move(col), std::move(val));
+}
+
 } // namespace
 
 bool is_spec(std::string const & path) { return path.compare(0, 10, "synthetic:") == 0; }
+
+bool is_stored_triangle(std::string const & spec)
+{
+    return is_spec(spec) && spec.size() >= 15 && spec.compare(spec.size() - 5, 5, ":tril") == 0;
+}
 
 csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long long re, long long * total)
 {
     if (!is_spec(spec))
         throw matrix::matrix_error("not a synthetic matrix specification: " + spec);
     std::string rest = spec.substr(10);
+    bool const tril = is_stored_triangle(spec);
+    if (tril)
+        rest.resize(rest.size() - 5);
     std::string family = rest, params;
     std::size_t const colon = rest.find(':');
     if (colon != std::string::npos) {
@@ -716,6 +755,8 @@ csr_matrix::Matrix generate_csr(std::string const & spec, long long rb, long lon
     }
     if (total)
         *total = tot;
+    if (tril)
+        return lower_triangle(A, rb);
     return A;
 }
 
@@ -733,6 +774,8 @@ matrix_market::Matrix generate(std::string const & spec)
             a[(std::size_t) k] = A.value[(std::size_t) k];
         }
     matrix_market::Header h;
+    if (is_stored_triangle(spec)) // the header such a file carries (parsed and otherwise ignored, as in the reference)
+        h.symmetry = matrix_market::Symmetry::symmetric;
     matrix_market::Size s;
     s.rows = A.rows;
     s.columns = A.columns;

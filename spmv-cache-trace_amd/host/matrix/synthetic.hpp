@@ -30,6 +30,13 @@
 //   synthetic:scrambled:N,b[,seed]   the same band matrix with rows and columns renumbered by a pseudo-random permutation (P B P^T): what
 //                                    the reordering suffixes __RCM / __GP<n> are for
 //   synthetic:random:N,k[,seed]      SURVEY 8d S-random: k distinct uniform columns per row, ascending, values U(-1,1)
+//   synthetic:<any of the above>:tril
+//                                    the STORED TRIANGLE of that matrix (entries with column <= row): what a Matrix Market file
+//                                    with a `symmetric` header holds and what the reference multiplies when it is handed such a
+//                                    file (it mirrors nothing: src/matrix/matrix-market.cpp:530-555, README.md:106).  As
+//                                    coordinate entries the matrix carries the `symmetric` header word, so that
+//                                    --expand-symmetric gives the whole matrix back.  queen:tril = 168.8 M entries
+//                                    (Queen_4147's file: 166.8 M), kkt:200:tril = 222 M (nlpkkt200's file: 232.2 M)
 //
 // What these are NOT: the SuiteSparse matrices themselves.  They reproduce size, row-length
 // populations, symmetry of structure and the kind of column locality of their namesakes
@@ -45,6 +52,9 @@ namespace synthetic {
 
 // true for paths that start with "synthetic:"
 bool is_spec(std::string const & path);
+
+// true for a spec that ends in ":tril" (the stored triangle of a symmetric matrix)
+bool is_stored_triangle(std::string const & spec);
 
 // The matrix of `spec`, rows [row_begin, row_end) (row_end < 0: all rows) as its own CSR matrix:
 // row_ptr rebased to 0, column indices global, columns ascending inside every row.

@@ -100,6 +100,10 @@ def test_poisson4096_alt_formats_context_api(oracle, fmt):
     ("synthetic:kkt:200", 16240000, 430000000),   # configs[3]: nlpkkt200-like, N = 16.24 M, ~436 M entries
     ("synthetic:webbase", 1000005, 3105536),      # configs[4]: webbase-1M-like
     ("synthetic:powerlaw", 1000005, 3105536),     # the same row lengths, uniformly scattered columns
+    # round 6: what the reference multiplies when it is handed the SuiteSparse FILES -- the stored lower triangle of a `symmetric`
+    # Matrix Market file, nothing mirrored (src/matrix/matrix-market.cpp:396-414, :530-555; README.md:106)
+    ("synthetic:queen:tril", 4147110, 166000000),   # configs[2] as stored: 166.8 M entries, triangular diagonal blocks, rows of 1 ... 84
+    ("synthetic:kkt:200:tril", 16240000, 222000000),  # configs[3] as stored: 8.24 M rows that hold their diagonal only, 8 M rows of <= 27
 ])
 def test_baseline_configs_full_size_whole_vector(oracle, spec, min_rows, min_nnz):
     A = hostapi.load(spec, "csr")

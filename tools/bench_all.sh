@@ -24,6 +24,9 @@ run poisson_csr
 run poisson_csr_product --headline product
 run queen_csr --workload queen
 run kkt_csr --workload kkt
+# round 6: the stored lower triangles -- what the reference multiplies when it is handed the symmetric SuiteSparse files
+run queen_stored_csr --workload queen_stored
+run kkt_stored_csr --workload kkt_stored
 run webbase_csr --workload webbase
 run powerlaw_csr --workload powerlaw
 run webbase_coo --workload webbase --format coo
