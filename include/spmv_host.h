@@ -11,7 +11,7 @@
  * callers that are not C++ (bench.py --matrix, the tests), so that a file goes through the
  * same loader and converter whichever front end multiplies it.
  *
- * `path` is a Matrix Market file (.mtx, .gz, .tgz, .tar.gz, optional __RCM / __GP<n> suffix),
+ * `path` is a Matrix Market file (.mtx, .gz, .tgz, .tar.gz, optional __RCM / __GP<n> suffix as in the reference -- without METIS __GP<n> reorders nothing -- or __GPX<n>, this build's own partitioner),
  * or "synthetic:<family>[:<parameters>]" (host/matrix/synthetic.hpp) for a generated matrix.
  * Symmetric files are NOT expanded (the reference multiplies the stored triangle only) unless
  * SPMV_HOST_EXPAND_SYMMETRIC is passed -- an extension, off by default.

@@ -13,7 +13,7 @@ Edits (anchored on short unique strings, so a moved line does not silently mis-a
   src/main.cpp:142-150       --spmv-format hip-csr | hip-coo | hip-ell
   src/main.cpp:187           the option's help text names them
   src/main.cpp:209-232       the factory makes hip_{csr,coo,ell}_spmv_kernel
-  src/util/perf-events.cpp:35-45  a libpfm_context can be constructed in a NO_LIBPFM build; asking it for an event group
+  src/util/perf-events.cpp:35-45  ONLY under USE_SPMV_HIP: a libpfm_context can be constructed in a NO_LIBPFM build; asking it for an event group
                              or the event list still fails with "Please re-build with libpfm enabled" -- so that
                              main.cpp:247 no longer makes --profile unreachable without libpfm
   Makefile                   SPMV_HIP_ROOT=<engine checkout>: -DUSE_SPMV_HIP, -I.../include, -lspmv_hip + rpath, hip-spmv.cpp
@@ -72,8 +72,9 @@ def apply_edits(root):
          '    default:\n'
          '        break;\n')])
     edit(os.path.join(root, "src/util/perf-events.cpp"), [
+        # (only in a build that binds the engine: without SPMV_HIP_ROOT the reference behaves as before, throw included)
         ('#else\n    throw perf_error("Please re-build with libpfm enabled");\n#endif\n}\n\nlibpfm_context::~libpfm_context()',
-         '#endif\n}\n\nlibpfm_context::~libpfm_context()')])
+         '#elif !defined(USE_SPMV_HIP)\n    throw perf_error("Please re-build with libpfm enabled");\n#endif\n}\n\nlibpfm_context::~libpfm_context()')])
     edit(os.path.join(root, "Makefile"), [
         ('# Default\n',
          '# MI355X kernels: make SPMV_HIP_ROOT=<checkout of the engine> (its include/spmv_hip.h and built libspmv_hip.so)\n'

@@ -1588,7 +1588,12 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             unsigned long long * d_count = nullptr;
             unsigned long long count[2] = {0, 0};
             HIP_TRY(hipMalloc((void **) &d_count, kStripedInts * sizeof(unsigned long long)));
-            for (int dry = (pl->d_blocks || pl->d_segblocks) ? 1 : 0; dry >= 0; --dry) {
+            // A value dictionary built BEFORE this stage (compress, index_values, repack: an order the header allows) lists the
+            // boundary tiles in d_tiles_vi as plain narrow tiles, while the marks below turn their 16-bit column slots into row
+            // masks: its launch would multiply with masks for columns.  Such a plan gets a dry run first;
+            // if any tile would be marked, the dictionary is dropped and built again on the marked tiles (as rebuild_tiles does).
+            const bool had_dictionary = pl->values_from != nullptr || pl->d_tiles_vi != nullptr;
+            for (int dry = (pl->d_blocks || pl->d_segblocks || had_dictionary) ? 1 : 0; dry >= 0; --dry) {
                 e = hipMemsetAsync(d_count, 0, kStripedInts * sizeof(unsigned long long), s);
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL(spmv::csr_stencil_mask_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
@@ -1598,7 +1603,12 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
                 if (e == hipSuccess) e = read_striped(d_count, count, 2, s);
                 if (e != hipSuccess)
                     break;
-                if (dry && 10 * ((long long) count[0] + pl->shifted_tiles) >= 9LL * pl->ntiles) {
+                if (dry && had_dictionary && count[0] > 0) {
+                    if (pl->values_from)
+                        *reindex = pl->values_from;
+                    drop_value_dictionary(pl);
+                }
+                if (dry && (pl->d_blocks || pl->d_segblocks) && 10 * ((long long) count[0] + pl->shifted_tiles) >= 9LL * pl->ntiles) {
                     if (pl->d_blocks)
                         hipLaunchKernelGGL(spmv::csr_clear_blockwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
                     else // (segment windows rewrote their tiles' 16-bit stream to window slots: those tiles go back to 32-bit columns)

@@ -2,6 +2,7 @@
 
 #include "../matrix/matrix-error.hpp"
 #include "../matrix/matrix-market.hpp"
+#include "../matrix/matrix-reorder.hpp"
 #include "../matrix/synthetic.hpp"
 
 #include "spmv_hip.h"
@@ -61,10 +62,15 @@ std::ostream & print_common(std::ostream & o, std::string const & name, std::str
                             char const * format, long long rows, long long columns, long long nonzeros,
                             std::size_t matrix_size)
 {
-    return o << "{\n"
-             << "\"name\": \"" << name << "\",\n"
-             << "\"matrix_path\": \"" << path << "\",\n"
-             << "\"matrix_format\": \"" << format << "\",\n"
+    // (additive, only for a path with a reordering suffix: which order the rows got -- "__GP<n>" without METIS changes nothing,
+    // "__GPX<n>" names this build's own partitioner, so that neither is taken for a METIS ordering)
+    std::string const reordering = matrix_market::reordering_of(path);
+    o << "{\n"
+      << "\"name\": \"" << name << "\",\n"
+      << "\"matrix_path\": \"" << path << "\",\n";
+    if (!reordering.empty())
+        o << "\"reordering\": \"" << reordering << "\",\n";
+    return o << "\"matrix_format\": \"" << format << "\",\n"
              << "\"rows\": " << rows << ",\n"
              << "\"columns\": " << columns << ",\n"
              << "\"nonzeros\": " << nonzeros << ",\n"

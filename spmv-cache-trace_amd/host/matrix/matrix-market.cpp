@@ -531,25 +531,54 @@ Matrix load_file(std::string const & path, std::ostream & o, bool verbose)
 
 } // namespace
 
+// The reference's suffix parser (src/matrix/matrix-market.cpp:786-802): the last "__RCM" and everything behind it goes,
+// then the last "__GP" with the number behind it.  "__GPX<n>" (extension) is the same position with an X in front of the number
+// -- the reference would strip it just the same and read no number.
+ReorderSuffixes parse_reorder_suffixes(std::string const & path)
+{
+    ReorderSuffixes r;
+    r.file = path;
+    auto pos = r.file.rfind("__RCM");
+    if (pos != std::string::npos) {
+        r.rcm = true;
+        r.file.erase(pos);
+    }
+    pos = r.file.rfind("__GP");
+    if (pos != std::string::npos) {
+        std::size_t at = pos + 4;
+        if (at < r.file.size() && r.file[at] == 'X') {
+            r.gpx = true;
+            ++at;
+        } else {
+            r.gp = true;
+        }
+        if (at < r.file.size())
+            r.nparts = std::atoi(r.file.c_str() + at);
+        r.file.erase(pos);
+    }
+    return r;
+}
+
+std::string reordering_of(std::string const & path)
+{
+    ReorderSuffixes const s = parse_reorder_suffixes(path);
+    std::string out;
+    if (s.rcm)
+        out = "rcm";
+    if (s.gp)
+        out += std::string(out.empty() ? "" : "+") + "gp (no METIS in this build: order unchanged, as in a reference build without USE_METIS)";
+    if (s.gpx)
+        out += std::string(out.empty() ? "" : "+") + "gpx:" + kPartitionerName + ":" + std::to_string(s.nparts <= 1 ? 16 : s.nparts);
+    return out;
+}
+
 Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
 {
     // "<file>__RCM" / "<file>__GP<n>": load <file>, then reorder it
-    // (src/matrix/matrix-market.cpp:782-802)
-    std::string file = path;
-    bool rcm = false, gp = false;
-    int nparts = 0;
-    auto pos = file.rfind("__RCM");
-    if (pos != std::string::npos) {
-        rcm = true;
-        file.erase(pos);
-    }
-    pos = file.rfind("__GP");
-    if (pos != std::string::npos) {
-        gp = true;
-        if (pos + 4 < file.size())
-            nparts = std::atoi(file.c_str() + pos + 4);
-        file.erase(pos);
-    }
+    // (src/matrix/matrix-market.cpp:782-802); "__GPX<n>" is this build's extension (matrix-reorder.hpp)
+    ReorderSuffixes const sfx = parse_reorder_suffixes(path);
+    std::string const & file = sfx.file;
+    bool const rcm = sfx.rcm, gp = sfx.gp || sfx.gpx;
     if (verbose) {
         o << "Loading matrix from " << file << '\n';
         if (rcm)
@@ -573,8 +602,10 @@ Matrix load_matrix(std::string const & path, std::ostream & o, bool verbose)
     }
     if (rcm)
         m = permute(m, find_new_order_RCM(m, o, verbose));
-    if (gp)
-        m = permute(m, find_new_order_GP(m, nparts, o, verbose));
+    if (sfx.gpx)
+        m = permute(m, find_new_order_GPX(m, sfx.nparts, o, verbose));
+    else if (sfx.gp) // (the identity: the reference's Matrix::permute would change nothing, or -- for a matrix that is not square
+        (void) find_new_order_GP(m, sfx.nparts, o, verbose); //  and real -- say so on stderr and change nothing either, :309-334)
     return m;
 }
 

@@ -132,17 +132,31 @@ std::vector<int> find_new_order_RCM(Matrix const & m, std::ostream & log, bool v
     return new_order;
 }
 
-// "__GP<n>": rows clustered by a k-way partition of the matrix's graph, parts one after the other, the original order kept inside
-// a part -- what the reference does with the partition vector METIS_PartGraphKway returns (matrix-market-reorder.cpp:183-279:
-// `permutation[offset[part[i]]++] = i; new_order[permutation[i]] = i`).  METIS is a third-party library that is neither vendored
-// in the reference nor installed here; a reference build without it leaves the order unchanged (:172-181).  This build has its
-// own partitioner instead -- greedy graph growing: the graph is made undirected; a part starts at the unassigned node of
+// "__GP<n>" as the reference does it WITHOUT METIS (src/matrix/matrix-market-reorder.cpp:172-181): METIS is a third-party
+// library that is neither vendored in the reference nor installed here, and a reference build without USE_METIS prints one
+// warning and returns the identity order -- no check of shape or field, nothing reordered.  So does this build: the same
+// warning text, the same order (pinned by tests/golden/reorder_vectors.json: what oracle/_ref/libref_spmv.so returned for
+// <file>__GP<n>).  (The reference writes the warning to std::cout, where it lands in front of the JSON document; here it goes
+// to the loader's log stream -- stderr in the CLI -- so that the document stays parseable.)
+std::vector<int> find_new_order_GP(Matrix const & m, int /* nparts */, std::ostream & log, bool /* verbose */)
+{
+    log << "Warning: No reordering is done. You should compile with 'USE_METIS' defined\n";
+    std::vector<int> same_order((std::size_t) std::max<index_type>(m.rows(), 0));
+    std::iota(same_order.begin(), same_order.end(), 0);
+    return same_order;
+}
+
+// "__GPX<n>" -- EXTENSION, named so that its result cannot be mistaken for a METIS ordering (the
+// reference's own parser strips "__GPX<n>" like "__GP" and, without METIS, reorders nothing): rows clustered by a k-way
+// partition of the matrix's graph, parts one after the other, the original order kept inside a part -- what the reference does
+// with the partition vector METIS_PartGraphKway returns (matrix-market-reorder.cpp:183-279:
+// `permutation[offset[part[i]]++] = i; new_order[permutation[i]] = i`) -- with the repo's own partitioner,
+// kPartitionerName = "greedy-bfs-kway": the graph is made undirected; a part starts at the unassigned node of
 // smallest degree (lowest index first) and grows breadth-first, neighbours in adjacency order, until it holds ceil(n / k)
 // nodes; the next part starts from the oldest node still waiting in the frontier (so parts are neighbours), or, when the
 // frontier is empty (a new component), again from the smallest degree.  Deterministic; balanced to within one node; NOT the
-// partition METIS would return (whose result depends on its version and seed anyway): a documented stand-in, compared with
-// the identity and with RCM in tests/test_host.py and profiles/r04_reordering.md.
-std::vector<int> find_new_order_GP(Matrix const & m, int nparts, std::ostream & log, bool verbose)
+// partition METIS would return: compared with the identity and with RCM in tests/test_host.py and profiles/r04_reordering.md.
+std::vector<int> find_new_order_GPX(Matrix const & m, int nparts, std::ostream & log, bool verbose)
 {
     require_square_real(m);
     int const n = m.rows();
@@ -172,13 +186,12 @@ std::vector<int> find_new_order_GP(Matrix const & m, int nparts, std::ostream & 
                 adjacency[fill[(std::size_t) ci[k] - 1]++] = ri[k] - 1;
             }
     }
-    // (always on the log, not only when verbose -- ADVICE r04: a "__GP<n>" order from this build must not be mistaken for a METIS
-    // ordering; a reference build without METIS prints its own warning here and leaves the order unchanged)
-    log << "Warning: METIS is not part of this build: '__GP" << nparts << "' orders the rows with the partitioner 'greedy-bfs-kway' "
-           "(parts grown breadth-first), not with METIS_PartGraphKway\n";
+    // (always on the log, not only when verbose: the order comes from this build's own partitioner)
+    log << "Note: '__GPX" << nparts << "' orders the rows with the partitioner '" << kPartitionerName << "' (parts grown breadth-first); "
+           "this is an extension -- '__GP<n>' without METIS reorders nothing, as in the reference\n";
     if (verbose)
         log << "Number of rows=" << n << " columns=" << m.columns() << " entries=" << ri.size() << '\n'
-            << "Growing " << nparts << " parts breadth-first (this build's stand-in for METIS_PartGraphKway)\n";
+            << "Growing " << nparts << " parts breadth-first\n";
     std::vector<int> by_degree((std::size_t) n);
     std::iota(by_degree.begin(), by_degree.end(), 0);
     std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) {

@@ -65,8 +65,25 @@ def main():
             R.mm_free(h)
             R.mm_free(o)
             print(name, len(oa), "entries; bandwidth", int(np.max(np.abs(oi - oj))), "->", int(np.max(np.abs(ri - rj))))
+        # "__GP<n>" as THIS reference build does it (no METIS: src/matrix/matrix-market-reorder.cpp:172-181 -- a warning on stdout and
+        # the identity order; after "__RCM" the RCM order stays), also for a rectangular pattern matrix (no shape / field check there)
+        gp_cases = []
+        rect = "%%MatrixMarket matrix coordinate pattern general\n3 5 4\n1 5\n3 1\n2 2\n1 1\n"
+        for name, text, suffix in [("components_isolated_duplicates", dict(inputs)["components_isolated_duplicates"], "__GP"),
+                                   ("components_isolated_duplicates", dict(inputs)["components_isolated_duplicates"], "__GP16"),
+                                   ("one_triangle_symmetric_header", dict(inputs)["one_triangle_symmetric_header"], "__GP4"),
+                                   ("one_triangle_symmetric_header", dict(inputs)["one_triangle_symmetric_header"], "__RCM__GP8"),
+                                   ("one_triangle_symmetric_header", dict(inputs)["one_triangle_symmetric_header"], "__GP8__RCM"),
+                                   ("rectangular_pattern", rect, "__GP2")]:
+            path = os.path.join(tmp, name + ".mtx")
+            open(path, "w").write(text)
+            h = R.mm_load(path + suffix)
+            gi, gj, _ = R.mm_entries(h)
+            gp_cases.append({"name": name, "suffix": suffix, "mtx": text, "i": [int(v) for v in gi], "j": [int(v) for v in gj]})
+            R.mm_free(h)
+            print(name + suffix, len(gi), "entries")
     json.dump({"_generated_by": "tests/golden/make_reorder_golden.py with oracle/_ref/libref_spmv.so (the reference's own "
-                                "load_matrix on <file>__RCM)", "cases": cases},
+                                "load_matrix on <file>__RCM)", "cases": cases, "gp_cases": gp_cases},
               open(os.path.join(HERE, "reorder_vectors.json"), "w"), indent=0)
 
 

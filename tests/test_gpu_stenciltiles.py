@@ -45,15 +45,18 @@ def grid_stencil(shape, offsets, seed=1, hole_share=0.0, values="random"):
     return n, n, p.astype(np.int32), c, v
 
 
-def run_plan(rows, cols, p, c, v, x, y0, flags=0, runs=1, other_columns=False, out_of_place=False, index_values=True):
+def run_plan(rows, cols, p, c, v, x, y0, flags=0, runs=1, other_columns=False, out_of_place=False, index_values=True,
+             index_values_first=False):
     import torch
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in (p, c, v, x))
     plan = capi.CsrPlan(rows, cols, p, capi.CSR_AUTO, 0, flags)
     plan.compress(tc.data_ptr(), stream)
+    if index_values and index_values_first:  # (compress, index_values, repack: an order the header allows)
+        plan.index_values(tv.data_ptr(), stream)
     plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
-    if index_values:
+    if index_values and not index_values_first:
         plan.index_values(tv.data_ptr(), stream)
     info = plan.info()
     cols_now = tc.clone() if other_columns else tc
@@ -110,6 +113,29 @@ def test_masked_stencil_tiles_bitexact(oracle, name, shape, offsets, holes, valu
     assert_bitexact(got_o, want, name + ", y_out")
     got_c, _ = run_plan(rows, cols, p, c, v, x, y0, other_columns=True)
     assert_bitexact(got_c, want, name + ", other column array")
+
+
+@pytest.mark.parametrize("name,shape,offsets,holes", [
+    ("7-point 64^3", (64, 64, 64), STAR7, 0.0),
+    ("7-point 33 x 47 x 29", (33, 47, 29), STAR7, 0.0),
+    ("5-point 200^2, 1 % removed", (200, 200), FIVE, 0.01),
+    ("5-point 300 x 210", (300, 210), FIVE, 0.0)])
+def test_dictionary_built_before_the_repack_that_marks_stencil_tiles(oracle, name, shape, offsets, holes):
+    """compress, index_values, THEN repack on a constant-coefficient grid.  The dictionary (with its
+    constant-row tile list) is built while the boundary tiles still hold 16-bit columns; repack then turns those slots into row
+    masks.  The dictionary must not survive that: repack drops it and builds it again on the marked tiles, and both orders end in
+    the same plan and the reference's bits."""
+    rows, cols, p, c, v = grid_stencil(shape, offsets, seed=len(name), hole_share=holes, values="constant")
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2)
+    got_d, info_d = run_plan(rows, cols, p, c, v, x, y0, runs=2)
+    got_f, info_f = run_plan(rows, cols, p, c, v, x, y0, runs=2, index_values_first=True)
+    assert info_d["stencil_mask_tiles"] > 0 and info_d["indexed_values"] == 2, info_d
+    for k in ("stencil_mask_tiles", "indexed_values", "row_blocks", "value_row_tiles", "dictionary_launch_tiles", "streamed_bytes"):
+        assert info_f[k] == info_d[k], (name, k, info_f[k], info_d[k])
+    assert_bitexact(got_d, want, name + ", default order")
+    assert_bitexact(got_f, want, name + ", index_values before repack")
 
 
 def test_a_foreign_column_keeps_its_tile_out(oracle):

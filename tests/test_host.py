@@ -183,8 +183,8 @@ def test_rcm_reordering_matches_the_golden_vectors(host, tmp_path):
 
 @pytest.mark.parametrize("nparts", [2, 8, 16, 37])
 def test_graph_partition_order(host, tmp_path, nparts):
-    """<file>__GP<n>: METIS is not vendored by the reference and not installed here; where a reference build without it
-    leaves the order unchanged (src/matrix/matrix-market-reorder.cpp:172-181) this build clusters the rows with its own k-way
+    """<file>__GPX<n> (EXTENSION; "__GP<n>" itself does what a reference build without METIS does: nothing, see
+    test_gp_suffix_without_metis_is_the_reference_identity): this build clusters the rows with its own k-way
     partitioner and orders them the way the reference orders METIS's parts (:253-268): parts one after the other, the file's
     order inside a part.  Checked: a symmetric permutation; parts balanced to one row; old indices ascending inside a part;
     far fewer entries between parts than for the scrambled numbering."""
@@ -197,7 +197,7 @@ def test_graph_partition_order(host, tmp_path, nparts):
     assert diag.sum() == n
     path = str(tmp_path / "band.mtx")
     synth.write_mtx(path, n, n, i, j, a)
-    g = host.mm_load(path + "__GP%d" % nparts)
+    g = host.mm_load(path + "__GPX%d" % nparts)
     gi, gj, ga = host.mm_entries(g)
     host.mm_free(g)
     assert sorted(ga.tolist()) == sorted(a.tolist())
@@ -218,10 +218,28 @@ def test_graph_partition_order(host, tmp_path, nparts):
     cut_identity = int(np.sum(part_of_new[i - 1] != part_of_new[j - 1]))
     assert cut < 0.4 * cut_identity, (cut, cut_identity)  # (37 parts of 24 rows of a band that reaches 7 rows: a quarter is cut by any split)
     # the default number of parts is the reference's 16 (:237-238)
-    g0, g16 = host.mm_load(path + "__GP"), host.mm_load(path + "__GP16")
+    g0, g16 = host.mm_load(path + "__GPX"), host.mm_load(path + "__GPX16")
     assert host.mm_entries(g0)[0].tolist() == host.mm_entries(g16)[0].tolist()
     host.mm_free(g0)
     host.mm_free(g16)
+
+
+def test_gp_suffix_without_metis_is_the_reference_identity(host, tmp_path):
+    """<file>__GP<n> in a build without METIS (the reference as compiled here, and this repo): one warning, the identity order
+    (src/matrix/matrix-market-reorder.cpp:172-181).  tests/golden/reorder_vectors.json holds what the reference library returned
+    for <file>__GP, __GP16, __RCM__GP8 when the fixtures were generated -- entries in file order, nothing moved (after RCM: the RCM
+    order) -- also for a matrix that is neither square nor real, which the reference's parser and identity accept."""
+    import json
+    G = json.load(open(os.path.join(GOLDEN, "reorder_vectors.json")))
+    assert len(G["gp_cases"]) >= 4
+    for case in G["gp_cases"]:
+        text = open(os.path.join(GOLDEN, case["mtx"][1:])).read() if case["mtx"].startswith("@") else case["mtx"]
+        path = str(tmp_path / (case["name"] + ".mtx"))
+        open(path, "w").write(text)
+        h = host.mm_load(path + case["suffix"])
+        hi, hj, _ = host.mm_entries(h)
+        assert hi.tolist() == case["i"] and hj.tolist() == case["j"], (case["name"], case["suffix"])
+        host.mm_free(h)
 
 
 def test_rcm_requires_square_real(host, tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the reordering suffixes buy on the GPU (VERDICT r03 task 4): launch time of `y += A x` for a matrix as
-it is, after `__RCM` (the reference's reverse Cuthill-McKee) and after `__GP<n>` (the repo's k-way partition order), with the
+it is, after `__RCM` (the reference's reverse Cuthill-McKee) and after `__GPX<n>` (EXTENSION: the repo's k-way partition order; `__GP<n>` without METIS reorders nothing, as in the reference), with the
 time the reordering itself took on the host.
 
     python tools/reorder_effect.py [SPEC ...]        (default: a scrambled band of 27 per row and uniformly random columns)
@@ -24,7 +24,7 @@ def main():
     print("| matrix | order | load + reorder s | bandwidth | mean abs(i-j) | launch us | GFLOP/s | frac algorithmic | 16-bit tiles / tiles | column panels |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for spec in specs:
-        for suffix in ("", "__RCM", "__GP64", "__GP4096"):
+        for suffix in ("", "__RCM", "__GPX64", "__GPX4096"):
             t0 = time.perf_counter()
             A = hostapi.load(spec + suffix, "csr")
             t_load = time.perf_counter() - t0
