@@ -7,7 +7,7 @@
 // file order), puts the same triplets into the layout the kernel is fast on: runs of equal rows that
 // a wave adds up before issuing one atomic per run.  rocPRIM's radix sort (through hipCUB) does the
 // sorting; this is library plumbing, not a hot-path kernel.
-#include "spmv_hip.h"
+#include "spmv_hip_plan.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>

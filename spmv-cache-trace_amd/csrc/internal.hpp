@@ -9,7 +9,7 @@
 //   coo_sort.hip     device sort of COO triplets, scans (hipCUB plumbing)
 #pragma once
 
-#include "spmv_hip.h"
+#include "spmv_hip_plan.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> // types and prototypes only: librccl.so is dlopen'ed by spmv_hip_create_multi when G > 1
@@ -38,8 +38,8 @@ void set_last_error_text(std::string const & text);
     } while (0)
 
 // Two kernel families were built, measured slower than the paths they were meant to replace, and retired from the product
-// library in round 5: hub columns for web graphs (csr_hub.hpp: 26.6 against 23.9 us) and a lane group per
-// row for stencil rows of 17 ... 64 entries (csr_rowgroup.hpp: 797 against 740 us).  They live on in
+// library in round 5: hub columns for web graphs (tools/experiments/csr_hub.hpp: 26.6 against 23.9 us) and a lane group per
+// row for stencil rows of 17 ... 64 entries (tools/experiments/csr_rowgroup.hpp: 797 against 740 us).  They live on in
 // libspmv_hip_experiments.so (-DSPMV_HIP_EXPERIMENTS), with their parity tests (tests/experiments/); the product library
 // refuses both bits like any unknown flag.
 #define SPMV_HIP_FLAG_HUB_COLUMNS 0x4000000u

@@ -17,7 +17,7 @@ HOST_SRCS := host/util/json-value.cpp host/util/cpu-budget.cpp host/trace-config
              host/kernels/spmv-kernels.cpp host/kernels/triad-kernel.cpp host/profile-kernel.cpp \
              host/host-api.cpp
 HOST_OBJS := $(HOST_SRCS:.cpp=.o)
-HOST_HDRS := $(wildcard host/*.hpp host/*/*.hpp) $(ROOT)/include/spmv_hip.h
+HOST_HDRS := $(wildcard host/*.hpp host/*/*.hpp) $(wildcard $(ROOT)/include/spmv_hip*.h)
 HOST_LIB  := libspmv_host.so
 CLI       := spmv-cache-trace-hip
 

@@ -5,7 +5,7 @@
 #include "../matrix/matrix-reorder.hpp"
 #include "../matrix/synthetic.hpp"
 
-#include "spmv_hip.h"
+#include "spmv_hip_tuning.h" // (spmv_hip.h + the CSR algorithm choice and ctx_info of the CLI)
 
 #include <chrono>
 #include <ostream>

@@ -2,7 +2,7 @@
 
 #include "../matrix/aligned-vector.hpp"
 
-#include "spmv_hip.h"
+#include "spmv_hip_plan.h"
 
 #include <hip/hip_runtime_api.h>
 

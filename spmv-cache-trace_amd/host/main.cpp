@@ -15,7 +15,7 @@
 #include "util/cpu-budget.hpp"
 #include "util/json-ostreambuf.hpp"
 
-#include "spmv_hip.h"
+#include "spmv_hip_tuning.h" // (spmv_hip.h + the CSR algorithm choice and ctx_info of the CLI)
 
 #include <argp.h>
 #include <locale.h>

@@ -2,7 +2,7 @@
 
 A rocprofv3 summary under profiles/ is only evidence for the binary it profiled.  Every bench line
 therefore carries `build` = {source_sha256, lib_sha256, git_head}: the hash of the sources
-libspmv_hip.so is compiled from (csrc/ + include/spmv_hip.h; reproducible wherever the library is
+libspmv_hip.so is compiled from (csrc/ + include/spmv_hip*.h; reproducible wherever the library is
 rebuilt), the hash of the .so the process really loaded, and the commit (from .git where the tree
 has one, else from the stamp file __graft_entry__.build() leaves next to the library: the GPU box
 gets a snapshot without .git).  bench.py reports PMC traffic from a committed summary only when its
@@ -32,7 +32,7 @@ def _sha_files(paths):
 def device_sources():
     """What libspmv_hip.so is compiled from (Makefile: CSRC + CHDR)."""
     src = sorted(glob.glob(os.path.join(PKG_ROOT, "csrc", "*.hip")) + glob.glob(os.path.join(PKG_ROOT, "csrc", "*.hpp")))
-    return src + [os.path.join(REPO_ROOT, "include", "spmv_hip.h")]
+    return src + sorted(glob.glob(os.path.join(REPO_ROOT, "include", "spmv_hip*.h")))  # spmv_hip.h, spmv_hip_plan.h, spmv_hip_tuning.h
 
 
 def source_sha256():

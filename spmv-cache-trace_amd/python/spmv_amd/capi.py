@@ -1,4 +1,4 @@
-"""ctypes binding of include/spmv_hip.h (the C ABI of libspmv_hip.so).
+"""ctypes binding of include/spmv_hip.h, spmv_hip_tuning.h and spmv_hip_plan.h (the C ABI of libspmv_hip.so).
 
 This is plumbing: it loads the in-tree shared library and turns negative return
 codes into ``SpmvHipError``.  There is deliberately no fallback of any kind: if
@@ -17,7 +17,9 @@ if os.environ.get("SPMV_HIP_EXPERIMENTS") == "1":
     LIB_PATH = EXPERIMENTS_LIB_PATH
 elif os.environ.get("SPMV_HIP_EXPERIMENTS", "").endswith(".so"):  # an ablation build of tools/ablate.sh
     LIB_PATH = os.path.abspath(os.environ["SPMV_HIP_EXPERIMENTS"])
+# the drop-in boundary (what an adapter of the reference binds) and the two headers that include it (tuning switches; Level 2)
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "spmv_hip.h")
+HEADER_PATHS = [HEADER_PATH] + [os.path.join(os.path.dirname(PKG_ROOT), "include", n) for n in ("spmv_hip_tuning.h", "spmv_hip_plan.h")]
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALIGN = -1, -2, -3, -4, -5, -6, -7
@@ -46,7 +48,7 @@ _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _vp = C.c_void_p
 
-# name -> (restype, argtypes); every symbol include/spmv_hip.h declares
+# name -> (restype, argtypes); every symbol include/spmv_hip*.h declare
 SIGNATURES = {
     "spmv_hip_version": (C.c_int, []),
     "spmv_hip_strerror": (C.c_char_p, [C.c_int]),

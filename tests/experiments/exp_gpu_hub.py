@@ -1,4 +1,4 @@
-"""Hub columns (csrc/csr_hub.hpp) -- a kernel family that was measured slower than the balanced tiles it extends (26.6 against
+"""Hub columns (tools/experiments/csr_hub.hpp) -- a kernel family that was measured slower than the balanced tiles it extends (26.6 against
 23.9 us on the web graph) and lives in libspmv_hip_experiments.so only since round 5.  Run in a process of its
 own with SPMV_HIP_EXPERIMENTS=1 (tests/test_gpu_experiments.py does that); the product library refuses the flag."""
 import numpy as np

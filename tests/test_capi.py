@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/spmv_hip.h declares; argument
+"""The C-ABI library loads and exports every symbol include/spmv_hip.h, spmv_hip_tuning.h and spmv_hip_plan.h declare; argument
 validation that needs no device works; and with no GPU the compute entry points FAIL
 (there is no CPU fallback).  No compute calls here."""
 import ctypes as C
@@ -10,10 +10,13 @@ import pytest
 from spmv_amd import capi
 
 
-def _declared_symbols():
-    text = open(capi.HEADER_PATH).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(spmv_hip_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(paths=None):
+    out = set()
+    for path in (paths or capi.HEADER_PATHS):
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(spmv_hip_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_symbols_all_exported():
@@ -24,6 +27,41 @@ def test_header_symbols_all_exported():
         assert hasattr(lib, s), "libspmv_hip.so does not export %s" % s
     # and the Python binding covers exactly the declared set
     assert sorted(capi.SIGNATURES.keys()) == syms
+
+
+def test_the_boundary_header_is_the_small_one():
+    """include/spmv_hip.h is the SURVEY 8(b) surface -- the context functions an adapter binds, the error
+    codes and six flags -- and nothing of the plan API or the tuning switches; the adapter of INTEGRATION.md compiles against
+    a directory that holds that header ALONE."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    small = _declared_symbols([capi.HEADER_PATH])
+    want = {"spmv_hip_create", "spmv_hip_create_multi", "spmv_hip_destroy", "spmv_hip_upload_csr", "spmv_hip_upload_coo", "spmv_hip_upload_ell",
+            "spmv_hip_upload_hybrid", "spmv_hip_set_x", "spmv_hip_set_y", "spmv_hip_get_y", "spmv_hip_run", "spmv_hip_sync", "spmv_hip_flush_caches",
+            "spmv_hip_last_run_ns", "spmv_hip_last_run_times", "spmv_hip_strerror", "spmv_hip_last_error", "spmv_hip_version", "spmv_hip_device_count"}
+    assert set(small) == want, sorted(set(small) ^ want)
+    text = open(capi.HEADER_PATH).read()
+    flags = sorted(set(re.findall(r"#define (SPMV_HIP_FLAG_[A-Z0-9_]+)", text)))
+    assert flags == ["SPMV_HIP_FLAG_BALANCE_ENTRIES", "SPMV_HIP_FLAG_COO_KEEP_ORDER", "SPMV_HIP_FLAG_EXACT_ORDER", "SPMV_HIP_FLAG_FUSED_PEER_STORE",
+                     "SPMV_HIP_FLAG_NO_RUN_EVENTS", "SPMV_HIP_FLAG_PEER_GATHER"], flags
+    assert "spmv_hip_plan" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    # every header is plain C99 on its own
+    root = os.path.dirname(os.path.dirname(capi.HEADER_PATH))
+    for h in capi.HEADER_PATHS:
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(h), "-fsyntax-only", "-x", "c", "-"],
+                           input='#include "%s"\n' % os.path.basename(h), text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout
+    # the reference-side adapter sees nothing but the small header
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("the reference tree is not here: the adapter's other includes cannot be resolved")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(capi.HEADER_PATH, tmp)
+        src = os.path.join(root, "integration", "src")
+        r = subprocess.run(["g++", "-std=c++14", "-fopenmp", "-DUSE_OPENMP", "-DUSE_POSIX_MEMALIGN", "-DUSE_SPMV_HIP", "-include", "cstdint", "-I", tmp, "-I", "/root/reference/src", "-I", "/root/reference/src/kernels", "-I", src,
+                            "-fsyntax-only", os.path.join(src, "kernels", "hip-spmv.cpp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-3000:]
 
 
 def test_version_and_strerror():

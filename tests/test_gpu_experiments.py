@@ -1,6 +1,6 @@
 """Two kernel families were measured slower than the paths they were meant to replace and were retired from the product
 library in round 5 (csrc/internal.hpp): a lane group per row for stencil rows of 17 ... 64 entries
-(csrc/csr_rowgroup.hpp) and hub columns for web graphs (csrc/csr_hub.hpp).  The product library refuses their flags; their parity
+(tools/experiments/csr_rowgroup.hpp) and hub columns for web graphs (tools/experiments/csr_hub.hpp).  The product library refuses their flags; their parity
 tests (against the oracle's CSR loop, src/matrix/csr-matrix-spmv.cpp:21-33) still run -- in a child process that loads
 libspmv_hip_experiments.so."""
 import os
@@ -23,7 +23,7 @@ def test_product_library_refuses_the_retired_flags():
         with pytest.raises(capi.SpmvHipError) as e:
             capi.CsrPlan(10, 10, p, capi.CSR_AUTO, 0, bit)
         assert e.value.code == capi.ERR_INVALID and "unknown flag" in str(e.value)
-    text = open(os.path.join(ROOT, "include", "spmv_hip.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("spmv_hip.h", "spmv_hip_tuning.h", "spmv_hip_plan.h"))
     assert "define SPMV_HIP_FLAG_ROW_GROUPS" not in text and "define SPMV_HIP_FLAG_HUB_COLUMNS" not in text
 
 
