@@ -182,6 +182,11 @@ def parse_args():
                     help="rehearsal: every rank uses device 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     ap.add_argument("--reject-scheme", default=None, choices=["peer-fused", "peer-push"],
                     help="rehearsal: treat this gather scheme as if its gathered y had failed the check against RCCL's")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="skip the `drop_in_multi_gpu` leg: the same workload through spmv_hip_create_multi in ONE fresh process over "
+                         "N devices -- the path the reference-side adapter binds (the reference is one process, src/profile-kernel.cpp:227)")
+    ap.add_argument("--drop-in-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: this process IS that child, over G devices
+    ap.add_argument("--drop-in-specs", default="", help=argparse.SUPPRESS)            # internal: name=spec;name=spec
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the all-gather even with one rank (rehearsal)")
     return ap.parse_args()
@@ -797,6 +802,180 @@ def companion(torch, capi, hostapi, synth, args, device, stream, spec, fmt, name
     return out
 
 
+DROP_IN_SCHEMES = (  # name, SPMV_HIP_FLAG_* bits (capi names), what it is
+    ("rccl", (), "one grouped in-place ncclAllGather per run on every device's stream"),
+    ("rccl-pipelined", ("FLAG_PIPELINE_GATHER",), "the same collective on a second stream per device beside the next run's multiply"),
+    ("peer-push", ("FLAG_PEER_GATHER",), "one push kernel per device and run: the slot stored into the other devices' y over xGMI"),
+    ("peer-push-pipelined", ("FLAG_PEER_GATHER", "FLAG_PIPELINE_GATHER"), "the push on a second stream beside the next run's multiply"),
+    ("peer-fused", ("FLAG_FUSED_PEER_STORE",), "the multiply kernel stores its row sums into every device's y itself"),
+)
+
+
+def drop_in_child(args):
+    """`bench.py --drop-in-child G`: ONE process, G devices, the drop-in's own multi-GPU path (csrc/multi_gpu.hip behind
+    include/spmv_hip.h): spmv_hip_create_multi -> ncclCommInitAll, rows cut by ceil(rows / G) (src/matrix/csr-matrix.cpp:77-95),
+    x replicated, a grouped in-place ncclAllGather per run -- and the same with the gather as peer stores, fused into the multiply,
+    or pipelined behind the next run.  Started fresh by rank 0 of the benchmark (no GPU call has been made in THIS process before
+    the library's own); imports neither torch nor anything under oracle/.  Prints one JSON document.
+
+    Two protocols per scheme: `t_total_us` = K runs enqueued back to back, one sync (bench.py's step); `sync_per_run` = the
+    reference's timed loop (run, sync, clock: src/profile-kernel.cpp:159-163) with the library's own event split --
+    t_local (the slowest device's multiply), t_allgather (the longest span from a device's multiply to the end of its gather)."""
+    from spmv_amd import capi, hostapi, synth
+    G = args.drop_in_child
+    out = {"devices_visible": capi.device_count(), "devices": G, "steps": args.steps, "warmup": args.warmup, "process": "one process, %d device%s" % (G, "" if G == 1 else "s"),
+           "workloads": {}}
+    share = os.environ.get("SPMV_HIP_SHARE_DEVICES") == "1"  # rehearsal on fewer devices than parts (peer schemes only; RCCL refuses)
+    out["rehearsal_shared_devices"] = share and out["devices_visible"] < G
+    if out["devices_visible"] < G and not share:
+        out["error"] = "%d devices asked for, %d visible" % (G, out["devices_visible"])
+        print(json.dumps(out), flush=True)
+        return 0
+    K, W = max(1, args.steps), max(0, args.warmup)
+    base = capi.FLAG_NO_VALUE_INDEX if args.headline == "general" else 0
+    for item in [q for q in args.drop_in_specs.split(";") if q]:
+        name, spec = item.split("=", 1)
+        t_load = time.perf_counter()
+        A = hostapi.load(spec, "csr")
+        rows, cols, nnz = A.rows, A.cols, int(A.row_ptr[-1])
+        x = synth.x_vector(cols, "uniform", seed=12345)
+        w = {"spec": spec, "rows": rows, "nnz": nnz, "algorithmic_bytes_per_launch": int(synth.csr_bytes(rows, cols, nnz)),
+             "segment_bytes_per_link": int(8 * -(-rows // G)) if G > 1 else 0, "load_s": round(time.perf_counter() - t_load, 2), "schemes": {}}
+        signatures = {}
+        one = (("one-device", (), "spmv_hip_create_multi with one device: no gather (t1 of the speed-ups below)"),)
+        for sname, bits, what in (one + DROP_IN_SCHEMES if G > 1 else one):
+            flags = base
+            for b in bits:
+                flags |= getattr(capi, b)
+            r = {"what": what}
+            Gs = 1 if sname == "one-device" else G
+            try:
+                # (a) K runs back to back, no per-run events (what bench.py's step is)
+                with capi.Context(num_gpus=Gs, flags=flags | capi.FLAG_NO_RUN_EVENTS) as ctx:
+                    t0 = time.perf_counter()
+                    ctx.upload_csr(rows, cols, A.row_ptr, A.column_index, A.value)
+                    ctx.set_x(x)
+                    r["init_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                    info = ctx.info()
+                    r["rccl_ranks"] = int(info["rccl_ranks"])
+                    r["pipelined"] = bool(info["pipelined"])
+                    ctx.run(1)
+                    y1 = ctx.get_y()
+                    signatures[sname] = (float(y1.sum()), float(np.abs(y1).sum()))
+                    ctx.run(W)
+                    t0 = time.perf_counter()
+                    ctx.run(K)  # K x spmv_hip_run, then one spmv_hip_sync
+                    t = (time.perf_counter() - t0) / K
+                    r["t_total_us"] = round(t * 1e6, 2)
+                    r["gflops"] = round(2.0 * nnz / t / 1e9, 1)
+                    r["frac_algorithmic_of_%dx8TBs" % Gs] = round(w["algorithmic_bytes_per_launch"] / t / 1e9 / (HBM_PEAK_GBS * Gs), 4)
+                # (b) the reference's protocol: every run waited for, with the library's event split
+                with capi.Context(num_gpus=Gs, flags=flags) as ctx:
+                    ctx.upload_csr(rows, cols, A.row_ptr, A.column_index, A.value)
+                    ctx.set_x(x)
+                    ctx.run(3)
+                    wall, loc, gat = [], [], []
+                    for _ in range(min(K, 20)):
+                        t0 = time.perf_counter()
+                        ctx.run(1)
+                        wall.append(time.perf_counter() - t0)
+                        k_ns, g_ns = ctx.last_run_times()
+                        loc.append(k_ns)
+                        gat.append(g_ns)
+                    r["sync_per_run"] = {"t_total_us_median": round(float(np.median(wall)) * 1e6, 2), "t_local_us_median": round(float(np.median(loc)) * 1e-3, 2),
+                                         "t_allgather_us_median": round(float(np.median(gat)) * 1e-3, 2), "runs": len(wall)}
+                    if Gs > 1 and np.median(gat) > 0 and sname != "peer-fused":
+                        r["sync_per_run"]["gather_gbs_per_link"] = round(w["segment_bytes_per_link"] / (float(np.median(gat)) * 1e-9) / 1e9, 2)
+            except capi.SpmvHipError as e:
+                r["error"] = str(e)[:300]
+            w["schemes"][sname] = r
+        ok = [k for k, v in w["schemes"].items() if "t_total_us" in v and k != "one-device"] or [k for k, v in w["schemes"].items() if "t_total_us" in v]
+        t1 = (w["schemes"].get("one-device") or {}).get("t_total_us")
+        if G > 1 and t1:
+            # SURVEY 8(e): speed-up vs one device on t_total; and what the links allow: every device must RECEIVE G - 1 segments, one
+            # per link (direct all-to-all), so a step cannot beat max(t1 / G, segment bytes / link rate) however the gather is done
+            links = [v["sync_per_run"]["gather_gbs_per_link"] for v in w["schemes"].values() if (v.get("sync_per_run") or {}).get("gather_gbs_per_link")]
+            for k in ok:
+                w["schemes"][k]["speedup_vs_one_device"] = round(t1 / w["schemes"][k]["t_total_us"], 3)
+            if links:
+                link = max(links)
+                bound_us = max(t1 / G, w["segment_bytes_per_link"] / (link * 1e9) * 1e6)
+                w["speedup_bound_at_measured_link"] = {"link_gbs": link, "step_us_at_best": round(bound_us, 2), "speedup": round(t1 / bound_us, 2),
+                                                       "is": "t1 / max(t1 / G, 8 * ceil(rows / G) bytes / the best per-link rate any scheme's gather reached)"}
+        if ok:
+            best = min(ok, key=lambda k: w["schemes"][k]["t_total_us"])
+            w["fastest"] = best
+            w["t_total_us"] = w["schemes"][best]["t_total_us"]
+            ref = signatures.get("one-device") or signatures.get(ok[0])
+            # (sum and absolute sum of y after one run; the row blocks cut their tiles by themselves, so a row of more than 16
+            # entries may be added in another lane order than on one device: 1e-12, not bits)
+            w["every_scheme_delivers_the_same_y"] = all(abs(signatures[k][0] - ref[0]) <= 1e-12 * ref[1] and abs(signatures[k][1] - ref[1]) <= 1e-12 * ref[1]
+                                                        for k in signatures)
+        out["workloads"][name] = w
+        A.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def drop_in_leg(args, torch, dist, rank, world, use_dist, specs, timeout_s=420):
+    """beside the one-process-per-GPU measurement (what the bench contract launches), the SAME workloads through
+    the drop-in's own multi-GPU path -- spmv_hip_create_multi in one fresh child process over `world` devices.  Rank 0 starts the
+    child (a child process, not an exec; its first GPU call is the library's) while the other ranks wait on the HOST (a key of the
+    process group's store: an RCCL barrier would keep a kernel spinning on their devices); every rank has synchronised its device and
+    released its caches before.  Never part of `value`; a failure or a timeout is reported in the line, never fatal."""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    store = None
+    if use_dist:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+        dist.barrier()
+        torch.cuda.synchronize()
+    result = None
+    if rank == 0:
+        cmd = [sys.executable, os.path.abspath(__file__), "--drop-in-child", str(world), "--drop-in-specs", ";".join("%s=%s" % kv for kv in specs),
+               "--steps", str(min(args.steps, 50)), "--warmup", str(min(args.warmup, 10)), "--headline", args.headline]
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                  "TORCHELASTIC_RUN_ID", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "OMP_NUM_THREADS"):
+            if k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+                continue  # what the launcher made visible stays visible
+            env.pop(k, None)
+        if args.share_gpu:  # rehearsal: the child's parts share the one device too (peer schemes only; RCCL refuses and says so)
+            env["SPMV_HIP_SHARE_DEVICES"] = "1"
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=timeout_s)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                result = json.loads(lines[-1])
+            else:
+                result = {"error": "child exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+        except subprocess.TimeoutExpired:
+            result = {"error": "child did not finish within %d s" % timeout_s}
+        except (OSError, ValueError) as e:
+            result = {"error": str(e)[:300]}
+        result["wall_s"] = round(time.perf_counter() - t0, 1)
+        result["command"] = " ".join(cmd[1:])
+        result["what"] = ("the drop-in's multi-GPU path: ONE process, spmv_hip_create_multi over %d device%s (csrc/multi_gpu.hip: ncclCommInitAll, "
+                          "grouped in-place ncclAllGather), started fresh by rank 0 while the other ranks idle; `value` above is the "
+                          "one-process-per-GPU path the bench contract launches" % (world, "" if world == 1 else "s"))
+        if use_dist and store is not None:
+            store.set("drop_in_done", "1")
+    if use_dist:
+        if store is not None:
+            try:
+                if rank != 0:
+                    store.wait(["drop_in_done"], __import__("datetime").timedelta(seconds=timeout_s + 60))
+            except Exception:
+                pass
+        dist.barrier()
+        torch.cuda.synchronize()
+    return result
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` typed plainly (no launcher): start the N ranks as FRESH child processes -- one
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` with this command line -- before this process has imported
@@ -817,6 +996,8 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.drop_in_child > 0:
+        sys.exit(drop_in_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -1380,6 +1561,15 @@ def main():
             for f in ("coo", "hybrid", "csr")}
         companions["config4_webbase"]["ell"] = "not representable: rows x longest row overflows int32, the converter throws like the reference's (ell-matrix.cpp:201-205)"
 
+    # ---- the drop-in's own multi-GPU path (one process over all devices) beside the one-process-per-GPU measurement ------------
+    drop_in = None
+    if fmt == "csr" and spec is not None and not args.no_drop_in and not args.force_collective:
+        dspecs = [("headline", spec)]
+        if world > 1 and config3 is not None and not args.share_gpu:  # (a rehearsal on one shared device keeps to the headline matrix)
+            dspecs.append(("config3_kkt", "synthetic:kkt:200"))
+        # (the child holds its own copy of every matrix: this rank's device arrays stay, there is room for both in 288 GB)
+        drop_in = drop_in_leg(args, torch, dist, rank, world, use_dist, dspecs)
+
     code, message = 0, None
     if rank == 0:
         from spmv_amd import buildinfo
@@ -1506,6 +1696,15 @@ def main():
             out["north_star_synthetic"] = north_star
             for sub in north_star.values():
                 attach_traffic(sub, build, triad_gbs)
+        if drop_in is not None:
+            h = (drop_in.get("workloads") or {}).get("headline") or {}
+            if h.get("t_total_us"):
+                # N = 1: the same launch through the context API in another process must reproduce the timed region within box spread
+                h["over_this_run_ms_per_step"] = round(h["t_total_us"] * 1e-3 / ms_per_step, 3)
+            k3 = (drop_in.get("workloads") or {}).get("config3_kkt") or {}
+            if k3.get("t_total_us") and config3 is not None and config3.get("ms_per_step"):
+                k3["over_the_per_process_path_ms_per_step"] = round(k3["t_total_us"] * 1e-3 / config3["ms_per_step"], 3)
+            out["drop_in_multi_gpu"] = drop_in
         if gather_check:
             out["gather_check"] = gather_check
             if not gather_check["pass"]:

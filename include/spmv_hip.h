@@ -78,6 +78,16 @@ extern "C" {
                                              where a device's multiply is the default CSR kernel it stores every row sum into all
                                              G copies of y itself as each tile finishes -- the gather overlaps the SAME multiply
                                              and needs no launch of its own; other kernels are followed by the push kernel */
+#define SPMV_HIP_FLAG_PIPELINE_GATHER 0x4u /* spmv_hip_create_multi, with the RCCL all-gather or SPMV_HIP_FLAG_PEER_GATHER: back-to-back runs
+                                             overlap -- the gather of run k travels on a second stream per device while run k + 1
+                                             multiplies (every device keeps TWO copies of y that alternate: a run reads its slot of one
+                                             and writes the other, so a slot is never written while it is still being sent).  A run
+                                             followed by spmv_hip_sync (the reference's timed loop, src/profile-kernel.cpp:159-161)
+                                             costs what it costs without the flag; K runs and one sync cost ~K x max(multiply, gather)
+                                             instead of K x (multiply + gather).  CSR-planned uploads only (CSR, and COO / ELLPACK /
+                                             hybrid uploads that run as row-major tiles); ignored -- the serial order is kept -- for
+                                             one device, for SPMV_HIP_FLAG_FUSED_PEER_STORE (whose multiply IS the transfer) and for
+                                             uploads that run another kernel.  Same y, bit for bit. */
 
 typedef struct spmv_hip_ctx spmv_hip_ctx;
 

@@ -123,7 +123,10 @@ int spmv_hip_set_csr_algorithm(spmv_hip_ctx *ctx, int algorithm, int lanes_per_r
  * use (see spmv_hip_plan_info [14]; formats without tiles: their algorithmic bytes)
  * [16] devices (1, or the num_gpus of spmv_hip_create_multi: [6..15] are then sums over the devices)
  * [17] ELLPACK path of the upload: 0 = not ELLPACK, 1 = the row-major arrays in place (wave tiles), 2 = column-major
- *      copy (one lane per row, the reference's order) */
+ *      copy (one lane per row, the reference's order)
+ * [18] ranks of the context's RCCL communicator as ncclCommCount reports them (0: the context holds none -- one device, or the
+ *      gather is done by peer stores)  [19] 1 if back-to-back runs are pipelined (SPMV_HIP_FLAG_PIPELINE_GATHER asked for AND
+ *      possible for the current upload) */
 int spmv_hip_ctx_info(spmv_hip_ctx *ctx, int64_t *out, int n);
 
 #ifdef __cplusplus

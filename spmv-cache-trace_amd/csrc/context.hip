@@ -180,6 +180,16 @@ void spmv_hip_destroy(spmv_hip_ctx * c)
         for (hipEvent_t ev : c->ev_gather)
             if (ev)
                 (void) hipEventDestroy(ev);
+        for (size_t g = 0; g < c->comm.size(); ++g) { // SPMV_HIP_FLAG_PIPELINE_GATHER: the gather streams and their events
+            if (g < c->parts.size())
+                (void) hipSetDevice(c->parts[g]->device);
+            for (hipEvent_t ev : {g < c->ev_mul.size() ? c->ev_mul[g] : nullptr, g < c->ev_sent[0].size() ? c->ev_sent[0][g] : nullptr,
+                                  g < c->ev_sent[1].size() ? c->ev_sent[1][g] : nullptr})
+                if (ev)
+                    (void) hipEventDestroy(ev);
+            if (c->comm[g])
+                (void) hipStreamDestroy(c->comm[g]);
+        }
         for (spmv_hip_ctx * part : c->parts)
             spmv_hip_destroy(part);
         // librccl.so stays loaded (dlclose of a library with live device state is not safe)
@@ -706,6 +716,8 @@ int spmv_hip_run(spmv_hip_ctx * c)
     // a part of a multi-GPU context with SPMV_HIP_FLAG_FUSED_PEER_STORE: the CSR multiply delivers its rows to the other
     // devices' copies of y itself (row sums forwarded by the kernel, or pushed behind it: spmv_hip_csr_spmv_out_peers)
     auto csr_run = [&]() {
+        if (c->y_in_override) // a part of a pipelined multi-GPU context: the old y comes from the other copy (multi_gpu.hip)
+            return spmv_hip_csr_spmv_out(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->y_in_override, c->d_y, c->stream);
         if (c->peer_y.empty())
             return spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
         delivered = true;
@@ -722,7 +734,7 @@ int spmv_hip_run(spmv_hip_ctx * c)
         break;
     case 4:
         if (c->as_csr) { // ELL part and remainder merged into one row-major matrix: one launch
-            rc = spmv_hip_csr_spmv(c->plan, c->d_ptr, c->d_col, c->d_val, c->d_x, c->d_y, c->stream);
+            rc = csr_run();
             break;
         }
         rc = c->ell_as_tiles
@@ -800,7 +812,12 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
         return fail(SPMV_HIP_ERR_INVALID, "ctx/out null");
     if (c->multi) {
         // the whole matrix: sizes from the front, tile counts / bytes summed over the devices, [16] = devices
-        int64_t v[18] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (int64_t) c->parts.size(), 0};
+        int64_t v[20] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (int64_t) c->parts.size(), 0, 0, c->pipeline ? 1 : 0};
+        if (!c->comms.empty() && c->comms[0] && c->p_comm_count) { // what RCCL itself says the communicator holds
+            int ranks = 0;
+            if (c->p_comm_count(c->comms[0], &ranks) == ncclSuccess)
+                v[18] = ranks;
+        }
         for (size_t g = 0; g < c->parts.size(); ++g) {
             int64_t w[18] = {0};
             if (c->parts[g]->format != 0)
@@ -811,14 +828,14 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
             for (int i : {6, 7, 8, 9, 10, 11, 12, 13, 14, 15})
                 v[i] += w[i];
             if (c->yfull[g])
-                v[9] += (int64_t) c->chunk * (int64_t) c->parts.size() * 8;
+                v[9] += (int64_t) c->chunk * (int64_t) c->parts.size() * 8 * (c->pipeline ? 2 : 1);
         }
-        for (int i = 0; i < n && i < 18; ++i)
+        for (int i = 0; i < n && i < 20; ++i)
             out[i] = v[i];
         return SPMV_HIP_OK;
     }
-    int64_t v[18] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0, 1,
-                     c->format == 3 ? (c->ell_as_tiles ? 1 : 2) : 0};
+    int64_t v[20] = {c->format, c->rows, c->cols, c->nnz, 0, 0, 0, 0, 0, (int64_t) c->bytes, 0, 0, 0, 0, 0, 0, 1,
+                     c->format == 3 ? (c->ell_as_tiles ? 1 : 2) : 0, 0, 0};
     // [15] bytes one run streams: the plan's count where tiles are used, else the format's algorithmic bytes
     switch (c->format) {
     case 2: v[15] = 16LL * c->nnz + 16LL * c->rows + 8LL * c->cols; break;
@@ -842,7 +859,7 @@ int spmv_hip_ctx_info(spmv_hip_ctx * c, int64_t * out, int n)
     }
     if (c->d_prow)
         v[14] += c->coo_panel_blocks; // COO (part) in column panels: workgroups per panel
-    for (int i = 0; i < n && i < 18; ++i)
+    for (int i = 0; i < n && i < 20; ++i)
         out[i] = v[i];
     return SPMV_HIP_OK;
 }

@@ -51,7 +51,7 @@ constexpr unsigned kKnownFlags = SPMV_HIP_FLAG_XCD_REMAP | SPMV_HIP_FLAG_EXACT_O
     SPMV_HIP_FLAG_ROWS128 | SPMV_HIP_FLAG_ELL_COLUMN_MAJOR | SPMV_HIP_FLAG_NO_SHIFTED_TILES | SPMV_HIP_FLAG_NO_X_WINDOW |
     SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_VERIFY_PLAN | SPMV_HIP_FLAG_NO_BALANCED_TILES | SPMV_HIP_FLAG_NO_RUN_EVENTS | SPMV_HIP_FLAG_NO_VALUE_INDEX |
     SPMV_HIP_FLAG_PEER_GATHER | SPMV_HIP_FLAG_BALANCE_ENTRIES | SPMV_HIP_FLAG_NO_SEGMENT_WINDOW | SPMV_HIP_FLAG_FUSED_PEER_STORE |
-    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MULTI_WINDOW | SPMV_HIP_FLAG_NO_MASKED_BLOCKS
+    SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MULTI_WINDOW | SPMV_HIP_FLAG_NO_MASKED_BLOCKS | SPMV_HIP_FLAG_PIPELINE_GATHER
 #ifdef SPMV_HIP_EXPERIMENTS
     | 0x2000u | 0x4000u | 0x30000u // timing experiments of tools/kernel_sweep.py (libspmv_hip_experiments.so only)
     | SPMV_HIP_FLAG_HUB_COLUMNS | SPMV_HIP_FLAG_ROW_GROUPS // kernel families that were measured SLOWER than the default path (below)
@@ -160,6 +160,8 @@ struct spmv_hip_plan {
     int4 * d_tiles_vi = nullptr; // the dictionary launch's own descriptors: runs of constant-row tiles re-cut into tiles of 128 rows
     int ntiles_vi = 0;           // (0 = it uses d_tiles)
     const double * values_from = nullptr; // the value array it was made from
+    const double * values_wanted = nullptr; // the array spmv_hip_plan_csr_index_values was last called with, dictionary built or not:
+                                            // a repack that frees the plan of its window kernels asks again (round 6)
     unsigned long long value_checksum = 0;
     mutable std::atomic<bool> verify_values_pending{false}; // claimed (exchange) by the one multiply that re-checks
     // content guard: checksum of the column array the 16-bit stream and the tile marks were derived from
@@ -198,6 +200,8 @@ struct spmv_hip_ctx {
     // SPMV_HIP_FLAG_FUSED_PEER_STORE: where this part's rows live in the OTHER devices' copies of y; a run then delivers
     // them itself (the multiply kernel's own stores, or a push behind it)
     std::vector<double *> peer_y;
+    // SPMV_HIP_FLAG_PIPELINE_GATHER: a part's CSR run reads the old y from here and writes the new one to d_y (null: in place)
+    const double * y_in_override = nullptr;
     // ---- multi-GPU front (spmv_hip_create_multi): parts[g] is an ordinary context on device g that holds
     // the rows [g * chunk, min(rows, (g + 1) * chunk)) of the matrix, a full x, and -- as its y -- slot g of
     // yfull[g], that device's copy of the whole y.  A run multiplies on every device and then gathers the
@@ -209,6 +213,17 @@ struct spmv_hip_ctx {
     int32_t chunk = 0;              // doubles per y slot: the longest row block
     std::vector<int32_t> row_begin; // G + 1 block boundaries; block g sits at yfull[.] + g * chunk
     bool packed = true;             // every block but the last fills its slot: yfull IS y (the static rule)
+    // SPMV_HIP_FLAG_PIPELINE_GATHER: a second copy of y per device, a second (gather) stream per device, and the events that
+    // order them.  Run k reads slot g of ybuf(cur) and writes slot g of ybuf(cur ^ 1) on the part's stream, then the gather
+    // of ybuf(cur ^ 1) is enqueued on comm[g] behind ev_mul[g]; run k + 1's multiply only waits for the gather that last
+    // SENT the copy it is about to write (ev_sent[b][g]: recorded on comm[g] after the gather out of copy b).
+    bool pipeline = false;          // asked for and possible for the current upload
+    std::vector<double *> yfull2;
+    int cur = 0;                    // which copy holds the current y (0: yfull, 1: yfull2)
+    std::vector<hipStream_t> comm;
+    std::vector<hipEvent_t> ev_mul;
+    std::vector<hipEvent_t> ev_sent[2];
+    bool sent_recorded[2] = {false, false};
     bool peer_gather = false; // SPMV_HIP_FLAG_PEER_GATHER: slots are pushed to the other devices by a kernel, no RCCL
     void * rccl_lib = nullptr;
     std::vector<ncclComm_t> comms;
@@ -217,6 +232,7 @@ struct spmv_hip_ctx {
     ncclResult_t (*p_group_end)() = nullptr;
     ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
     const char * (*p_error_string)(ncclResult_t) = nullptr;
+    ncclResult_t (*p_comm_count)(const ncclComm_t, int *) = nullptr;
 };
 
 namespace spmvi {

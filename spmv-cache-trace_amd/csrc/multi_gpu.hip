@@ -42,6 +42,7 @@ int multi_load_rccl(spmv_hip_ctx * c, int num_gpus)
     c->p_group_end = reinterpret_cast<decltype(c->p_group_end)>(dlsym(c->rccl_lib, "ncclGroupEnd"));
     c->p_comm_destroy = reinterpret_cast<decltype(c->p_comm_destroy)>(dlsym(c->rccl_lib, "ncclCommDestroy"));
     c->p_error_string = reinterpret_cast<decltype(c->p_error_string)>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+    c->p_comm_count = reinterpret_cast<decltype(c->p_comm_count)>(dlsym(c->rccl_lib, "ncclCommCount")); // (optional: ctx_info [18])
     if (!p_init_all || !c->p_all_gather || !c->p_group_start || !c->p_group_end || !c->p_comm_destroy)
         return fail(SPMV_HIP_ERR_STATE, "librccl.so lacks ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd");
     std::vector<int> devs((size_t) num_gpus);
@@ -56,19 +57,42 @@ int multi_load_rccl(spmv_hip_ctx * c, int num_gpus)
     return SPMV_HIP_OK;
 }
 
+// the copy of y that holds the current vector on device g (SPMV_HIP_FLAG_PIPELINE_GATHER alternates two)
+static inline double * ybuf(const spmv_hip_ctx * c, int which, size_t g) { return which ? c->yfull2[g] : c->yfull[g]; }
+
+// does a run of this part go through its CSR plan (the only launches with a y_in != y_out form)?
+static bool part_runs_csr_plan(const spmv_hip_ctx * part)
+{
+    return part->plan && (part->format == 1 || (part->format == 2 && part->as_csr) || (part->format == 3 && part->ell_as_tiles)
+                          || (part->format == 4 && part->as_csr));
+}
+
 void multi_free_matrix(spmv_hip_ctx * c)
 {
     for (size_t g = 0; g < c->parts.size(); ++g) {
         (void) hipSetDevice(c->parts[g]->device);
         (void) hipStreamSynchronize(c->parts[g]->stream);
+        if (g < c->comm.size() && c->comm[g])
+            (void) hipStreamSynchronize(c->comm[g]);
+    }
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        (void) hipSetDevice(c->parts[g]->device);
         free_ctx_matrix(c->parts[g]);
         c->parts[g]->borrowed_y = nullptr;
+        c->parts[g]->y_in_override = nullptr;
         c->parts[g]->peer_y.clear();
         if (g < c->yfull.size() && c->yfull[g]) {
             (void) hipFree(c->yfull[g]);
             c->yfull[g] = nullptr;
         }
+        if (g < c->yfull2.size() && c->yfull2[g]) {
+            (void) hipFree(c->yfull2[g]);
+            c->yfull2[g] = nullptr;
+        }
     }
+    c->pipeline = false;
+    c->cur = 0;
+    c->sent_recorded[0] = c->sent_recorded[1] = false;
     c->format = 0;
     c->rows = c->cols = c->nnz = 0;
     c->chunk = 0;
@@ -130,6 +154,32 @@ int multi_layout(spmv_hip_ctx * c, int32_t rows, const long long * entries_befor
     return SPMV_HIP_OK;
 }
 
+// After every upload: can back-to-back runs overlap (SPMV_HIP_FLAG_PIPELINE_GATHER)?  Needs more than one device, a gather that
+// is a step of its own (not the fused store), and parts whose runs have a y_in != y_out form.  Then every device gets its
+// second copy of y (zeroed like the first).
+static int multi_after_upload(spmv_hip_ctx * c)
+{
+    const size_t G = c->parts.size();
+    c->pipeline = false;
+    c->cur = 0;
+    c->sent_recorded[0] = c->sent_recorded[1] = false;
+    if (!(c->flags & SPMV_HIP_FLAG_PIPELINE_GATHER) || G < 2 || (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) || c->comm.size() != G)
+        return SPMV_HIP_OK;
+    for (size_t g = 0; g < G; ++g)
+        if (c->parts[g]->rows > 0 && !part_runs_csr_plan(c->parts[g]))
+            return SPMV_HIP_OK;
+    c->yfull2.assign(G, nullptr);
+    const size_t ybytes = (size_t) c->chunk * G * sizeof(double) + 64;
+    for (size_t g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(c->parts[g]->device));
+        HIP_TRY(hipMalloc((void **) &c->yfull2[g], ybytes));
+        HIP_TRY(hipMemsetAsync(c->yfull2[g], 0, ybytes, c->parts[g]->stream));
+        HIP_TRY(hipStreamSynchronize(c->parts[g]->stream));
+    }
+    c->pipeline = true;
+    return SPMV_HIP_OK;
+}
+
 int multi_upload_failed(spmv_hip_ctx * c, int rc)
 {
     std::string const keep = last_error_text();
@@ -166,6 +216,8 @@ int multi_upload_csr(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
     c->cols = cols;
     c->nnz = nnz;
     c->format = 1;
+    if ((rc = multi_after_upload(c)) != 0)
+        return multi_upload_failed(c, rc);
     return SPMV_HIP_OK;
 }
 
@@ -191,6 +243,8 @@ int multi_upload_ell(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t row_l
     c->cols = cols;
     c->nnz = (int32_t) ((long long) rows * row_length);
     c->format = 3;
+    if ((rc = multi_after_upload(c)) != 0)
+        return multi_upload_failed(c, rc);
     return SPMV_HIP_OK;
 }
 
@@ -252,6 +306,8 @@ int multi_upload_hybrid(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t ro
     c->nnz = (int32_t) ((long long) rows * row_length);
     c->nnz2 = ncoo;
     c->format = 4;
+    if ((rc = multi_after_upload(c)) != 0)
+        return multi_upload_failed(c, rc);
     return SPMV_HIP_OK;
 }
 
@@ -312,6 +368,8 @@ int multi_upload_coo(spmv_hip_ctx * c, int32_t rows, int32_t cols, int32_t nnz, 
     c->cols = cols;
     c->nnz = nnz;
     c->format = 2;
+    if ((rc = multi_after_upload(c)) != 0)
+        return multi_upload_failed(c, rc);
     return SPMV_HIP_OK;
 }
 
@@ -330,6 +388,8 @@ int multi_set_y(spmv_hip_ctx * c, const double * y)
     int rc0 = multi_sync(c); // a peer's push of an earlier run may still be writing into the vectors replaced here
     if (rc0 != 0)
         return rc0;
+    c->cur = 0; // (pipelined contexts: the given vector goes into the first copy, which is the current one from here on)
+    c->sent_recorded[0] = c->sent_recorded[1] = false;
     for (size_t g = 0; g < c->parts.size(); ++g) { // every device gets the whole y, as after a gather
         spmv_hip_ctx * part = c->parts[g];
         HIP_TRY(hipSetDevice(part->device));
@@ -348,19 +408,20 @@ int multi_set_y(spmv_hip_ctx * c, const double * y)
 
 int multi_get_y(spmv_hip_ctx * c, double * y)
 {
-    if (c->peer_gather) { // device 0's y is complete once every OTHER device's push has finished
+    if (c->peer_gather || c->pipeline) { // device 0's y is complete once every OTHER device's push (every gather stream) has finished
         int rc0 = multi_sync(c);
         if (rc0 != 0)
             return rc0;
     }
     spmv_hip_ctx * part = c->parts[0];
     HIP_TRY(hipSetDevice(part->device));
+    const int cur = c->pipeline ? c->cur : 0;
     if (c->rows > 0 && c->packed)
-        HIP_TRY(hipMemcpyAsync(y, c->yfull[0], (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, part->stream));
+        HIP_TRY(hipMemcpyAsync(y, ybuf(c, cur, 0), (size_t) c->rows * sizeof(double), hipMemcpyDeviceToHost, part->stream));
     for (size_t h = 0; h < c->parts.size() && !c->packed; ++h) {
         const int32_t b = c->row_begin[h], e = c->row_begin[h + 1];
         if (e > b)
-            HIP_TRY(hipMemcpyAsync(y + b, c->yfull[0] + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost,
+            HIP_TRY(hipMemcpyAsync(y + b, ybuf(c, cur, 0) + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost,
                                    part->stream));
     }
     HIP_TRY(hipStreamSynchronize(part->stream));
@@ -377,7 +438,7 @@ int multi_get_y(spmv_hip_ctx * c, double * y)
                 const int32_t b = c->row_begin[h], e = c->row_begin[h + 1];
                 if (e <= b)
                     continue;
-                HIP_TRY(hipMemcpy(other.data(), c->yfull[g] + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(other.data(), ybuf(c, cur, g) + h * (size_t) c->chunk, (size_t) (e - b) * sizeof(double), hipMemcpyDeviceToHost));
                 if (std::memcmp(other.data(), y + b, (size_t) (e - b) * sizeof(double)) != 0) {
                     char msg[160];
                     std::snprintf(msg, sizeof msg, "after the gather device %zu's copy of y differs from device 0's in the rows of block %zu", g, h);
@@ -414,7 +475,7 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const double * __restric
     }
 }
 
-int multi_peer_gather(spmv_hip_ctx * c)
+int multi_peer_gather(spmv_hip_ctx * c, int which /* copy of y */, bool on_comm_streams)
 {
     const int G = (int) c->parts.size();
     const size_t chunk = (size_t) c->chunk;
@@ -430,12 +491,12 @@ int multi_peer_gather(spmv_hip_ctx * c)
             t.n = 0;
             for (int h = h0; h < G && h < h0 + kPeerFanout; ++h)
                 if (h != g)
-                    t.dst[t.n++] = c->yfull[(size_t) h] + (size_t) g * chunk;
+                    t.dst[t.n++] = ybuf(c, which, (size_t) h) + (size_t) g * chunk;
             for (int k = t.n; k < kPeerFanout; ++k)
                 t.dst[k] = nullptr;
             if (t.n > 0)
-                hipLaunchKernelGGL(peer_push_kernel, dim3(blocks), dim3(256), 0, part->stream,
-                                   c->yfull[(size_t) g] + (size_t) g * chunk, t, pairs);
+                hipLaunchKernelGGL(peer_push_kernel, dim3(blocks), dim3(256), 0, on_comm_streams ? c->comm[(size_t) g] : part->stream,
+                                   ybuf(c, which, (size_t) g) + (size_t) g * chunk, t, pairs);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -464,9 +525,66 @@ int multi_enable_peers(spmv_hip_ctx * c)
     return SPMV_HIP_OK;
 }
 
+// the one collective of the path: every device sends its slot of copy `which` and receives the others', in place
+static int multi_rccl_gather(spmv_hip_ctx * c, int which, bool on_comm_streams)
+{
+    const int G = (int) c->parts.size();
+    ncclResult_t r = c->p_group_start();
+    if (r != ncclSuccess)
+        return multi_fail_nccl(c, r, "ncclGroupStart");
+    for (int g = 0; g < G && r == ncclSuccess; ++g)
+        r = c->p_all_gather(ybuf(c, which, (size_t) g) + (size_t) g * (size_t) c->chunk, ybuf(c, which, (size_t) g), (size_t) c->chunk, ncclDouble,
+                            c->comms[(size_t) g], on_comm_streams ? c->comm[(size_t) g] : c->parts[(size_t) g]->stream);
+    ncclResult_t r2 = c->p_group_end();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+        return multi_fail_nccl(c, r != ncclSuccess ? r : r2, "ncclAllGather");
+    return SPMV_HIP_OK;
+}
+
+// SPMV_HIP_FLAG_PIPELINE_GATHER.  Run k: every device multiplies y_out = y_in + A_g x with y_in = its slot of the current copy
+// and y_out = its slot of the OTHER copy, then the gather of that other copy goes to the device's second stream behind an
+// event -- so that run k + 1's multiply (which reads what run k wrote, on the same stream, and writes the copy run k read from)
+// runs beside gather k.  The one hazard: run k + 1 overwrites slot g of the copy that gather k - 1 may still be sending; its
+// multiply therefore waits for ev_sent of that copy (recorded behind gather k - 1 on the gather stream).  Remote writes of a
+// gather land in slots h != g of a copy on device g, which no multiply of device g ever touches.
+static int multi_run_pipelined(spmv_hip_ctx * c)
+{
+    const int G = (int) c->parts.size();
+    const int in = c->cur, out = c->cur ^ 1;
+    for (int g = 0; g < G; ++g) {
+        spmv_hip_ctx * part = c->parts[(size_t) g];
+        HIP_TRY(hipSetDevice(part->device));
+        if (c->sent_recorded[out])
+            HIP_TRY(hipStreamWaitEvent(part->stream, c->ev_sent[out][(size_t) g], 0));
+        part->y_in_override = ybuf(c, in, (size_t) g) + (size_t) g * (size_t) c->chunk;
+        part->d_y = ybuf(c, out, (size_t) g) + (size_t) g * (size_t) c->chunk;
+        int rc = spmv_hip_run(part);
+        part->y_in_override = nullptr;
+        if (rc != 0)
+            return rc;
+        HIP_TRY(hipEventRecord(c->ev_mul[(size_t) g], part->stream));
+        HIP_TRY(hipStreamWaitEvent(c->comm[(size_t) g], c->ev_mul[(size_t) g], 0));
+    }
+    int rc = c->peer_gather ? multi_peer_gather(c, out, true) : multi_rccl_gather(c, out, true);
+    if (rc != 0)
+        return rc;
+    for (int g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(c->parts[(size_t) g]->device));
+        HIP_TRY(hipEventRecord(c->ev_sent[out][(size_t) g], c->comm[(size_t) g]));
+        if (!(c->flags & SPMV_HIP_FLAG_NO_RUN_EVENTS))
+            HIP_TRY(hipEventRecord(c->ev_gather[(size_t) g], c->comm[(size_t) g]));
+    }
+    c->sent_recorded[out] = true;
+    c->cur = out;
+    c->timed = true;
+    return SPMV_HIP_OK;
+}
+
 int multi_run(spmv_hip_ctx * c)
 {
     const int G = (int) c->parts.size();
+    if (c->pipeline)
+        return multi_run_pipelined(c);
     for (spmv_hip_ctx * part : c->parts) { // every device multiplies its rows into its slot of its y
         int rc = spmv_hip_run(part);
         if (rc != 0)
@@ -475,20 +593,13 @@ int multi_run(spmv_hip_ctx * c)
     if (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) {
         // every part's run has delivered its rows already (spmv_hip_run of a part with peer_y)
     } else if (c->peer_gather) {
-        int rc = multi_peer_gather(c);
+        int rc = multi_peer_gather(c, 0, false);
         if (rc != 0)
             return rc;
     } else if (!c->comms.empty()) {
-        // the one collective of the path: every device sends its slot and receives the others', in place
-        ncclResult_t r = c->p_group_start();
-        if (r != ncclSuccess)
-            return multi_fail_nccl(c, r, "ncclGroupStart");
-        for (int g = 0; g < G && r == ncclSuccess; ++g)
-            r = c->p_all_gather(c->yfull[(size_t) g] + (size_t) g * (size_t) c->chunk, c->yfull[(size_t) g], (size_t) c->chunk, ncclDouble,
-                                c->comms[(size_t) g], c->parts[(size_t) g]->stream);
-        ncclResult_t r2 = c->p_group_end();
-        if (r != ncclSuccess || r2 != ncclSuccess)
-            return multi_fail_nccl(c, r != ncclSuccess ? r : r2, "ncclAllGather");
+        int rc = multi_rccl_gather(c, 0, false);
+        if (rc != 0)
+            return rc;
     }
     if (!(c->flags & SPMV_HIP_FLAG_NO_RUN_EVENTS)) {
         for (int g = 0; g < G; ++g) {
@@ -502,9 +613,12 @@ int multi_run(spmv_hip_ctx * c)
 
 int multi_sync(spmv_hip_ctx * c)
 {
-    for (spmv_hip_ctx * part : c->parts) {
+    for (size_t g = 0; g < c->parts.size(); ++g) {
+        spmv_hip_ctx * part = c->parts[g];
         HIP_TRY(hipSetDevice(part->device));
         HIP_TRY(hipStreamSynchronize(part->stream));
+        if (g < c->comm.size() && c->comm[g])
+            HIP_TRY(hipStreamSynchronize(c->comm[g]));
     }
     return SPMV_HIP_OK;
 }
@@ -572,6 +686,20 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
             if (hipEventCreate(&ev) != hipSuccess)
                 rc = fail(SPMV_HIP_ERR_HIP, "hipEventCreate");
             c->ev_gather.push_back(ev);
+        }
+    }
+    if (rc == SPMV_HIP_OK && (flags & SPMV_HIP_FLAG_PIPELINE_GATHER) && num_gpus > 1 && !(flags & SPMV_HIP_FLAG_FUSED_PEER_STORE)) {
+        for (int g = 0; g < num_gpus && rc == SPMV_HIP_OK; ++g) {
+            hipStream_t st = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+            if (hipSetDevice(c->parts[(size_t) g]->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess
+                || hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
+                rc = fail(SPMV_HIP_ERR_HIP, "stream / events of SPMV_HIP_FLAG_PIPELINE_GATHER");
+            c->comm.push_back(st);
+            c->ev_mul.push_back(e0);
+            c->ev_sent[0].push_back(e1);
+            c->ev_sent[1].push_back(e2);
         }
     }
     const char * force = std::getenv("SPMV_HIP_FORCE_RCCL");

@@ -1300,7 +1300,13 @@ int spmv_hip_plan_csr_repack(spmv_hip_plan * pl, const int32_t * d_row_ptr, cons
     // A value dictionary built BEFORE this call (compress, index_values, repack -- the header allows the order) describes the
     // tiling it was built on: when a stage below cuts the tiles anew it is dropped first and built again at the end.
     const double * reindex = nullptr;
+    const bool had_windows = pl->d_blocks || pl->d_segblocks;
     int rc = repack_stages(pl, d_row_ptr, d_column_index, d_value, stream, &reindex);
+    // ... and a dictionary that was ASKED FOR before this call but could not be built then -- the plan ran a window kernel, which
+    // has no dictionary variant -- is asked for again when a stage above gave the windows up (a structured grid whose boundary tiles
+    // became masked stencil tiles): both orders of the calls end in the same plan (tests/test_gpu_stenciltiles.py)
+    if (rc == SPMV_HIP_OK && !reindex && pl->values_wanted && pl->nvalues == 0 && had_windows && !pl->d_blocks && !pl->d_segblocks)
+        reindex = pl->values_wanted;
     if (rc == SPMV_HIP_OK && reindex && !pl->inner)
         rc = spmv_hip_plan_csr_index_values(pl, reindex, stream);
     return rc;
@@ -1855,6 +1861,7 @@ int spmv_hip_plan_csr_index_values(spmv_hip_plan * pl, const double * d_value, v
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t before = (pl->d_vidx ? (size_t) pl->nnz + 64 + spmv::kMaxIndexedValues * sizeof(double) : 0);
     drop_value_dictionary(pl);
+    pl->values_wanted = d_value;
     pl->meta_bytes -= std::min(pl->meta_bytes, before);
     // only the default kernel reads the dictionary (row-owned wave tiles with 16-bit-capable plans, x below 4 GiB)
     // (not with column panels, block windows or a majority of x-window tiles: those launches have their own variants)

@@ -399,7 +399,9 @@ protected:
               << ((options.hip_flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) ? "row blocks of equal stored entries over " : "static chunks of ceil(rows/G) rows over ")
               << info[16] << " devices, x replicated, 1 in-place all-gather(y) per run ("
               << ((options.hip_flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) ? "row sums stored into every device's y by the multiply itself"
-                  : (options.hip_flags & SPMV_HIP_FLAG_PEER_GATHER) ? "remote stores over xGMI" : "RCCL") << ")\"";
+                  : (options.hip_flags & SPMV_HIP_FLAG_PEER_GATHER) ? "remote stores over xGMI" : "RCCL")
+              << (((options.hip_flags & SPMV_HIP_FLAG_PIPELINE_GATHER) && !(options.hip_flags & SPMV_HIP_FLAG_FUSED_PEER_STORE))
+                      ? "; back-to-back runs pipelined: gather k beside multiply k + 1" : "") << ")\"";
         if (init_load_seconds > 0.0 || init_upload_seconds > 0.0)
             o << ", \"init_seconds\": {\"load_and_convert\": " << init_load_seconds << ", \"upload_and_plan\": " << init_upload_seconds << "}";
         o << "}";

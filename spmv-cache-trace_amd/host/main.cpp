@@ -83,6 +83,7 @@ enum Key
     key_exact_order,
     key_peer_gather,
     key_fused_peer_store,
+    key_pipeline_gather,
     key_balance_entries,
     key_threads,
     key_check,
@@ -171,6 +172,7 @@ error_t parse_option(int key, char * arg, argp_state * state)
     case key_exact_order: a.spmv.hip_flags |= SPMV_HIP_FLAG_EXACT_ORDER; break;
     case key_peer_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PEER_GATHER; break;
     case key_fused_peer_store: a.spmv.hip_flags |= SPMV_HIP_FLAG_FUSED_PEER_STORE; break;
+    case key_pipeline_gather: a.spmv.hip_flags |= SPMV_HIP_FLAG_PIPELINE_GATHER; break;
     case key_balance_entries: a.spmv.hip_flags |= SPMV_HIP_FLAG_BALANCE_ENTRIES; break;
     case key_threads:
         if (!parse_count(arg, n) || n < 0 || n > 4096)
@@ -290,6 +292,10 @@ int main(int argc, char ** argv)
         {"gpus", key_gpus, "G", 0,
          "hip-csr, hip-coo, hip-ell: partition the rows over devices 0..G-1 (the reference's static chunks, ceil(rows/G) rows each), "
          "x replicated, one RCCL all-gather of y per run", 3},
+        {"pipeline-gather", key_pipeline_gather, nullptr, 0,
+         "hip-* kernels with --gpus G > 1 (RCCL or --peer-gather): back-to-back runs overlap -- the gather of run k travels on a second "
+         "stream per device while run k + 1 multiplies (two alternating copies of y).  The timed loop of --profile waits for every "
+         "run, so its samples do not change; callers that enqueue several runs before they wait get max(multiply, gather) per run", 6},
         {"balance-entries", key_balance_entries, nullptr, 0,
          "with --gpus: cut the rows at equal shares of the stored entries instead of ceil(rows/G) rows per device", 3},
         {"peer-gather", key_peer_gather, nullptr, 0,

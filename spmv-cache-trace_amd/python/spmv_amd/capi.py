@@ -26,6 +26,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE, ERR_OVERFLOW, ERR_ALI
 CSR_AUTO, CSR_SCALAR, CSR_VECTOR, CSR_ADAPTIVE, CSR_WAVETILE = 0, 1, 2, 3, 4
 FLAG_XCD_REMAP, FLAG_EXACT_ORDER, FLAG_BIG_TILE, FLAG_NO_INDEX_COMPRESSION, FLAG_COO_KEEP_ORDER, FLAG_READ_ROW_PTR, FLAG_ROWS64, FLAG_ROWS128, FLAG_ELL_COLUMN_MAJOR = 0x1, 0x2, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 FLAG_NO_SHIFTED_TILES = 0x400
+FLAG_PIPELINE_GATHER = 0x4  # create_multi: gather k on a second stream beside multiply k + 1 (two alternating copies of y)
 FLAG_NO_X_WINDOW = 0x800
 FLAG_NO_COLUMN_PANELS = 0x1000
 FLAG_VERIFY_PLAN = 0x8000
@@ -285,11 +286,11 @@ class Context:
         return k.value, g.value
 
     def info(self):
-        out = np.zeros(18, dtype=np.int64)
-        check(self.lib.spmv_hip_ctx_info(self.h, out, 18))
+        out = np.zeros(20, dtype=np.int64)
+        check(self.lib.spmv_hip_ctx_info(self.h, out, 20))
         keys = ["format", "rows", "cols", "stored", "algorithm", "lanes_per_row", "workgroups",
                 "row_blocks", "long_blocks", "device_bytes", "narrow_tiles", "shifted_tiles", "xwin_tiles",
-                "blockwin_tiles", "panel_tiles", "streamed_bytes", "devices", "ell_path"]
+                "blockwin_tiles", "panel_tiles", "streamed_bytes", "devices", "ell_path", "rccl_ranks", "pipelined"]
         return dict(zip(keys, out.tolist()))
 
 

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported():
 
 def test_the_boundary_header_is_the_small_one():
     """include/spmv_hip.h is the SURVEY 8(b) surface -- the context functions an adapter binds, the error
-    codes and six flags -- and nothing of the plan API or the tuning switches; the adapter of INTEGRATION.md compiles against
+    codes and seven flags -- and nothing of the plan API or the tuning switches; the adapter of INTEGRATION.md compiles against
     a directory that holds that header ALONE."""
     import os
     import shutil
@@ -45,7 +45,7 @@ def test_the_boundary_header_is_the_small_one():
     text = open(capi.HEADER_PATH).read()
     flags = sorted(set(re.findall(r"#define (SPMV_HIP_FLAG_[A-Z0-9_]+)", text)))
     assert flags == ["SPMV_HIP_FLAG_BALANCE_ENTRIES", "SPMV_HIP_FLAG_COO_KEEP_ORDER", "SPMV_HIP_FLAG_EXACT_ORDER", "SPMV_HIP_FLAG_FUSED_PEER_STORE",
-                     "SPMV_HIP_FLAG_NO_RUN_EVENTS", "SPMV_HIP_FLAG_PEER_GATHER"], flags
+                     "SPMV_HIP_FLAG_NO_RUN_EVENTS", "SPMV_HIP_FLAG_PEER_GATHER", "SPMV_HIP_FLAG_PIPELINE_GATHER"], flags
     assert "spmv_hip_plan" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     # every header is plain C99 on its own
     root = os.path.dirname(os.path.dirname(capi.HEADER_PATH))

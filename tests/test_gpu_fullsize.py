@@ -354,7 +354,7 @@ def test_cli_synthetic_full_size_gpus_and_check():
     assert d["kernel"]["device"]["gpus"] == 4 and d["parity"]["pass"] is True and d["parity"]["max_relative_error"] <= 1e-10
 
 
-@pytest.mark.parametrize("gather", ["push", "fused"])
+@pytest.mark.parametrize("gather", ["push", "fused", "push-pipelined"])
 @pytest.mark.parametrize("parts,balance", [(2, False), (3, False), (8, False), (3, True), (8, True)])
 def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, balance, gather):
     """The G > 1 flow of spmv_hip_create_multi -- ceil(rows / G) row blocks (src/matrix/csr-matrix.cpp:77-95), one
@@ -363,7 +363,9 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
     two ranks on a device).  Rows are not a multiple of G, the last block is short, one block is empty of entries.
     balance: SPMV_HIP_FLAG_BALANCE_ENTRIES, blocks of equal stored entries (unequal rows, padded y slots).
     gather "fused": SPMV_HIP_FLAG_FUSED_PEER_STORE -- every part's run delivers its rows itself; on a 27-point stencil
-    (the default kernel: row sums forwarded by the multiply) and on power-law rows (balanced tiles: pushed behind it)."""
+    (the default kernel: row sums forwarded by the multiply) and on power-law rows (balanced tiles: pushed behind it).
+    gather "push-pipelined" (round 6): SPMV_HIP_FLAG_PIPELINE_GATHER -- two alternating copies of y per part, the push of run k on a
+    second stream beside the multiply of run k + 1; the same bits as the serial order."""
     import os
     if gather == "fused" and not balance:
         rows, cols, p, c, v = synth.stencil27_like(31, 29, 33)
@@ -384,7 +386,8 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
     scale = 3 * abs_products(rows, p, c, v, x) + np.abs(y0)
     os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
     try:
-        gflag = capi.FLAG_PEER_GATHER if gather == "push" else capi.FLAG_FUSED_PEER_STORE
+        gflag = {"push": capi.FLAG_PEER_GATHER, "fused": capi.FLAG_FUSED_PEER_STORE,
+                 "push-pipelined": capi.FLAG_PEER_GATHER | capi.FLAG_PIPELINE_GATHER}[gather]
         # VERIFY_PLAN on a multi-GPU context: get_y compares EVERY part's copy of y with part 0's, bit for bit
         with capi.Context(num_gpus=parts, flags=gflag | capi.FLAG_VERIFY_PLAN | (capi.FLAG_BALANCE_ENTRIES if balance else 0)) as ctx:
             ctx.upload_csr(rows, cols, p, c, v)
@@ -407,7 +410,47 @@ def test_multi_gpu_context_partition_rehearsed_on_one_device(oracle, parts, bala
         os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
 
 
-@pytest.mark.parametrize("spec,gather", [("synthetic:kkt:200", "fused"), ("synthetic:kkt:199", "fused"), ("synthetic:kkt:199", "push")])
+def test_pipelined_gather_gives_the_serial_bits(oracle):
+    """SPMV_HIP_FLAG_PIPELINE_GATHER over many back-to-back runs (the case it exists for: K runs, one sync): 5 row blocks of a
+    27-point stencil and of a COO upload (row-major tiles), 1 ... 9 runs from a given y, odd and even counts (the current copy of y
+    alternates), set_y in between, every part's copy compared under VERIFY_PLAN -- and the SAME BITS as the context without the
+    flag.  A hybrid upload that keeps its COO remainder apart has no y_in != y_out form: the flag is ignored, the serial order kept."""
+    import os
+    rows, cols, p, c, v = synth.stencil27_like(37, 23, 29)
+    x = synth.x_vector(cols, seed=5)
+    y0 = synth.x_vector(rows, seed=6)
+    i, j, a = synth.csr_to_coordinate(rows, p, c, v)
+    os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
+    try:
+        got = {}
+        for name, extra in (("serial", 0), ("pipelined", capi.FLAG_PIPELINE_GATHER)):
+            with capi.Context(num_gpus=5, flags=capi.FLAG_PEER_GATHER | capi.FLAG_VERIFY_PLAN | extra) as ctx:
+                ctx.upload_csr(rows, cols, p, c, v)
+                ctx.set_x(x)
+                out = []
+                for runs in (1, 2, 9, 4):
+                    ctx.set_y(y0)
+                    ctx.run(runs)
+                    out.append(ctx.get_y())
+                    ctx.run(3)  # ... and on from there without a set_y in between
+                    out.append(ctx.get_y())
+                ctx.upload_coo(rows, cols, i - 1, j - 1, a)
+                ctx.set_x(x)
+                ctx.set_y(y0)
+                ctx.run(7)
+                out.append(ctx.get_y())
+                got[name] = out
+        for k, (a_, b_) in enumerate(zip(got["serial"], got["pipelined"])):
+            assert_bitexact(b_, a_, "pipelined against serial, vector %d" % k)
+        for runs, y in zip((1, 4, 2, 5, 9, 12, 4, 7), got["pipelined"][:8]):
+            want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=runs)
+            assert_close(y, want, runs * abs_products(rows, p, c, v, x) + np.abs(y0), what="%d pipelined runs" % runs)
+    finally:
+        os.environ.pop("SPMV_HIP_SHARE_DEVICES", None)
+
+
+@pytest.mark.parametrize("spec,gather", [("synthetic:kkt:200", "fused"), ("synthetic:kkt:199", "fused"), ("synthetic:kkt:199", "push"),
+                                         ("synthetic:kkt:199", "push-pipelined")])
 def test_eight_row_blocks_of_the_kkt_matrix_on_one_device(oracle, spec, gather):
     """BASELINE configs[3] as the first 8-GPU run will see it -- nlpkkt200's stand-in in EIGHT row blocks (ceil(rows / 8) rows
     each, src/matrix/csr-matrix.cpp:77-95), eight plans, eight copies of y, the fused peer store / the push -- rehearsed with all
@@ -422,7 +465,7 @@ def test_eight_row_blocks_of_the_kkt_matrix_on_one_device(oracle, spec, gather):
     want = oracle.csr_spmv(rows, A.row_ptr, A.column_index, A.value, x, num_threads=THREADS, runs=2)
     os.environ["SPMV_HIP_SHARE_DEVICES"] = "1"
     try:
-        gflag = capi.FLAG_FUSED_PEER_STORE if gather == "fused" else capi.FLAG_PEER_GATHER
+        gflag = {"fused": capi.FLAG_FUSED_PEER_STORE, "push": capi.FLAG_PEER_GATHER, "push-pipelined": capi.FLAG_PEER_GATHER | capi.FLAG_PIPELINE_GATHER}[gather]
         with capi.Context(num_gpus=8, flags=gflag | capi.FLAG_VERIFY_PLAN) as ctx:
             ctx.upload_csr(rows, cols, A.row_ptr, A.column_index, A.value)
             ctx.set_x(x)
