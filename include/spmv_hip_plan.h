@@ -165,6 +165,14 @@ int spmv_hip_csr_spmv_out(const spmv_hip_plan *plan, const int32_t *d_row_ptr,
  * into this process (peer access between the devices must be possible; on this driver HSA_ENABLE_IPC_MODE_LEGACY=0
  * must be in the environment).  Close the mappings (spmv_hip_ipc_close) before their owner frees the memory
  * (spmv_hip_ipc_free).  The memory comes back zeroed. */
+/* THE row partition, in one place: row_begin[0 .. parts] receives the block boundaries of `rows` rows over `parts` devices or
+ * ranks -- the reference's static rule chunk = ceil(rows / parts), block g = [g * chunk, min(rows, (g + 1) * chunk))
+ * (src/matrix/csr-matrix.cpp:77-95, src/matrix/csr-matrix-spmv.cpp:154-161), or, with balance_entries != 0 and a host row_ptr
+ * (rows + 1 entries, any base), blocks of equal stored entries: boundary g = the first row whose row_ptr reaches g * nnz / parts
+ * (SPMV_HIP_FLAG_BALANCE_ENTRIES).  What spmv_hip_create_multi's uploads cut by and what the one-process-per-GPU operators
+ * (python/spmv_amd/partition.py) call: both process models share this one function.  No device needed. */
+int spmv_hip_partition_rows(int32_t rows, int parts, const int32_t *host_row_ptr, int balance_entries, int32_t *row_begin);
+
 int spmv_hip_ipc_alloc(void **d_ptr, size_t bytes, void *handle64);
 int spmv_hip_ipc_open(const void *handle64, void **d_ptr);
 int spmv_hip_ipc_close(void *d_ptr);

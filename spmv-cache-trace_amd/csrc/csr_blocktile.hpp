@@ -42,8 +42,13 @@ __host__ __device__ __forceinline__ int block_stream_index(int k0) { return k0 /
 // (7 or 8 of its 9 entries stored), a node with one or two unknowns that shifts the grid of column triples, rows of a triple
 // that differ in length.  Such a tile keeps one lane per block, but a block is now ANY three consecutive columns [c, c + 3) in
 // the tile's three-row strip together with a 9-bit mask of the entries that are stored, one 32-bit word per block:
-//     bits 0-15  c - the tile's smallest column      bits 16-24  mask (bit 3 a + b: row a of the triple has column c + b)
-//     bit 31     a block row begins here             bits 25-30  (first word of the tile only) number of blocks - 1
+//     bits 0-21  c - the tile's smallest column      bits 22-30  mask (bit 3 a + b: row a of the triple has column c + b)
+//     bit 31     a block row begins here             (a word with an empty mask ends the tile's list: fewer than 64 blocks)
+// (round 6: 22 bits of column instead of 16 -- the tile's columns may span 4 M, not 64 K -- so that a tile whose columns are too
+// far apart for 16-bit offsets can be a block tile too: an UNSTRUCTURED mesh numbered by reverse Cuthill-McKee has a band of
+// ~7 n^(2/3) nodes, and the Delaunay twin of the queen-like stand-in -- 700 K nodes, 2.1 M rows -- had 8 % narrow tiles, no block
+// tile and ran at 0.66 of the roofline: profiles/r06_zoo_delaunay_first.log.  Such a WIDE tile carries kTileMetaBlock3 |
+// kTileMetaBlock3Masked without kTileMetaNarrow, and its descriptor's .w is set to its smallest column by the mark kernel.)
 // The blocks of a block row are the greedy cover of the union of its three rows' columns (csr_block3m_mark_kernel): for dense
 // aligned blocks that is the blocks themselves, otherwise a cover that is merely a little less full.  Where a block's entries
 // lie in the value array follows from the masks in front of it: a prefix sum over the lanes of the three per-row counts
@@ -52,6 +57,8 @@ __host__ __device__ __forceinline__ int block_stream_index(int k0) { return k0 /
 // and aligned keep the 16-bit stream above (0.22 bytes per entry, no scan).
 constexpr int kTileMetaBlock3Masked = 1 << 29; // only together with kTileMetaBlock3 (a block tile has no x window: the window bits are free)
 constexpr unsigned kMaskedRowBegin = 0x80000000u;
+constexpr int kMaskedColBits = 22;
+constexpr unsigned kMaskedColMask = (1u << kMaskedColBits) - 1u;
 constexpr int kMaskedMinFill = 6; // entries per block a masked tile must reach to be worth it (and <= 64 blocks)
 __host__ __device__ __forceinline__ size_t mask_stream_offset(long long nnz_total) // in 16-bit units from d_col16; 128-byte aligned
 {
@@ -110,8 +117,9 @@ __device__ __forceinline__ void tile_rows_block3(
     unsigned e;
     int nblk;
     if (MASKED) {
-        e = reinterpret_cast<const unsigned *>(stream)[lane]; // (words past the tile's last block: allocated, never used)
-        nblk = (int) ((__builtin_amdgcn_readfirstlane(e) >> 25) & 63u) + 1;
+        e = reinterpret_cast<const unsigned *>(stream)[lane]; // (words past the tile's last block: allocated; the first of them is 0)
+        const unsigned long long none = __ballot(((e >> kMaskedColBits) & 0x1FFu) == 0u); // the terminator, or nothing: 64 blocks
+        nblk = none ? (int) __builtin_ctzll(none) : kWave;
     } else {
         nblk = __builtin_amdgcn_readfirstlane((k1 - k0) / 9); // 2 .. 56
     }
@@ -131,7 +139,7 @@ __device__ __forceinline__ void tile_rows_block3(
     unsigned mask = 0x1FFu;
     unsigned b0, b1, b2; // byte offsets of the three rows' pieces
     if (MASKED) {
-        mask = mine ? (e >> 16) & 0x1FFu : 0u;
+        mask = mine ? (e >> kMaskedColBits) & 0x1FFu : 0u;
         // stored entries of this block per row, three 10-bit fields; their prefix sums say where the block's values lie
         const int cnt = __builtin_popcount(mask & 7u) | (__builtin_popcount(mask & 0x38u) << 10) | (__builtin_popcount(mask & 0x1C0u) << 20);
         const int incl = wave_inclusive_scan(cnt);
@@ -157,7 +165,7 @@ __device__ __forceinline__ void tile_rows_block3(
     const double q1 = *reinterpret_cast<const double *>(va + b1 + 16);
     const v2d_u8 p2 = *reinterpret_cast<const v2d_u8 *>(va + b2);
     const double q2 = *reinterpret_cast<const double *>(va + b2 + 16);
-    const unsigned xo = MASKED ? (mine ? (e & 0xFFFFu) * 8u : 0u) : 3u * (e & 0x7FFFu) * 8u;
+    const unsigned xo = MASKED ? (mine ? (e & kMaskedColMask) * 8u : 0u) : 3u * (e & 0x7FFFu) * 8u;
     const v2d_u8 x01 = *reinterpret_cast<const v2d_u8 *>(reinterpret_cast<const char *>(xt) + xo);
     const double x2 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xt) + xo + 16);
     // (2) the row lanes: LPR lanes per row, old y requested now
@@ -244,10 +252,10 @@ __device__ __forceinline__ int block3_greedy_cover(const int * col, int (&pr)[3]
                 mask |= bit;
                 ++pr[a];
             }
-        if (cnt >= kWave || s < 0)
+        if (cnt >= kWave || s < 0 || s > (int) kMaskedColMask)
             ok = 0;
         else if (out)
-            out[cnt] = (unsigned) s | (mask << 16) | (cnt == 0 ? kMaskedRowBegin : 0u);
+            out[cnt] = (unsigned) s | (mask << kMaskedColBits) | (cnt == 0 ? kMaskedRowBegin : 0u);
         ++cnt;
     }
     *ok_out = ok;
@@ -329,17 +337,32 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     const int nrows = r1 - r0, n = k1 - k0;
     // (tiles marked for a block window are checked too: where block tiles turn out to be the majority the plan drops the windows)
     const int other = kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | (1 << 21) /* balanced tiles */;
-    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || !(meta & kTileMetaNarrow) || (meta & other)
+    // WIDE: the tile's columns span 64 K or more (no 16-bit columns; its descriptor's .w is free): a candidate for masked blocks
+    // with 22-bit columns -- unless a window kernel has claimed it
+    const bool wide = !(meta & kTileMetaNarrow);
+    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || (meta & other) || (wide && (!allow_masked || (meta & kTileMetaBlockWin)))
         || nrows < 3 || nrows > kBlockTileMaxRows || nrows % 3 != 0 || n < 18 || k1 - (k0 & ~3) > tile || tile > 512)
         return;
-    const int cmin = d0.w;
+    int cmin = d0.w;
+    if (wide) { // the compress pass kept no smallest column for it
+        cmin = 0x7FFFFFFF;
+        for (int k = k0 + lane; k < k1; k += kWave) {
+            const int c = j[k];
+            cmin = c < cmin ? c : cmin;
+        }
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_xor(cmin, d);
+            cmin = o < cmin ? o : cmin;
+        }
+    }
     // row starts in lanes 0 .. nrows (nrows <= 30)
     const int ps = p[r0 + (lane <= nrows ? lane : nrows)];
     const int len = __shfl_down(ps, 1) - ps; // lanes < nrows
     if (!__all(lane >= nrows || len > 16))
         return; // rows of up to 16 entries keep their one-lane-per-row, bit-exact path
     const int len0 = __shfl(len, lane - lane % 3);
-    int dense = n % 9 == 0 && n / 9 <= kWave && __all(lane >= nrows || (len == len0 && len % 3 == 0));
+    int dense = !wide && n % 9 == 0 && n / 9 <= kWave && __all(lane >= nrows || (len == len0 && len % 3 == 0));
     if (dense) {
         // row by row (the row number is wave-uniform: its bounds come out of lane r with a readlane, not a shuffle per entry --
         // the first version looked every entry's row up with a loop of shuffles: 38.8 ms for the queen-like matrix's 808 K tiles)
@@ -419,13 +442,14 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
             if (lane >= e1 - c1 && lane < e1)
                 word = word_all[wave][q][lane - (e1 - c1)];
         }
-        if (lane == 0)
-            word |= (unsigned) (total - 1) << 25;
-        if (lane < total)
-            mstream[mask_stream_index(k0) + lane] = word;
+        // the list ends with a word whose mask is empty (the tile's place in the stream holds n / 4 > total words)
+        if (lane <= total && lane < kWave)
+            mstream[mask_stream_index(k0) + lane] = lane < total ? word : 0u;
     }
     if (lane == 0) {
         desc[w].z = meta | kTileMetaBlock3 | (dense ? 0 : kTileMetaBlock3Masked);
+        if (wide)
+            desc[w].w = cmin; // what x + cbase of the multiply starts from (a tile without 16-bit columns has no other use for it)
         striped_add(count, 0, 1ull);
         striped_add(count, 1, (unsigned long long) n);
         if (!(meta & kTileMetaBlockWin)) {

@@ -101,6 +101,27 @@ void multi_free_matrix(spmv_hip_ctx * c)
     c->timed = false;
 }
 
+// THE row partition (spmv_hip_partition_rows; both process models cut by it): the reference's static rule, or blocks of
+// equal stored entries when the entries in front of every row are given.
+template <class T>
+static void partition_rows(int32_t rows, int G, const T * entries_before_row /* rows + 1, or null */, int32_t * row_begin /* G + 1 */)
+{
+    row_begin[0] = 0;
+    if (entries_before_row) {
+        const long long nnz = (long long) entries_before_row[rows] - (long long) entries_before_row[0];
+        for (int g = 1; g < G; ++g) {
+            const T target = (T) ((long long) entries_before_row[0] + (nnz * g) / G);
+            const int32_t r = (int32_t) (std::lower_bound(entries_before_row, entries_before_row + rows + 1, target) - entries_before_row);
+            row_begin[g] = std::max(row_begin[g - 1], std::min(r, rows));
+        }
+    } else {
+        const long long per = std::max<long long>(1, ((long long) rows + G - 1) / G); // ceil(rows / G): src/matrix/csr-matrix.cpp:77-95
+        for (int g = 1; g < G; ++g)
+            row_begin[g] = (int32_t) std::min<long long>(rows, g * per);
+    }
+    row_begin[G] = rows;
+}
+
 // Row blocks of a multi-GPU context and each device's copy of y.  row_ptr (rows + 1 entries, any base) gives the
 // stored entries in front of every row: the reference's static rule needs only `rows`, SPMV_HIP_FLAG_BALANCE_ENTRIES
 // cuts where the entries divide evenly (boundary g = the first row whose row_ptr reaches g * nnz / G).
@@ -109,19 +130,7 @@ int multi_layout(spmv_hip_ctx * c, int32_t rows, const long long * entries_befor
     multi_free_matrix(c);
     const int G = (int) c->parts.size();
     c->row_begin.assign((size_t) G + 1, 0);
-    if ((c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) && entries_before_row) {
-        const long long nnz = entries_before_row[rows] - entries_before_row[0];
-        for (int g = 1; g < G; ++g) {
-            const long long target = entries_before_row[0] + (nnz * g) / G;
-            const int32_t r = (int32_t) (std::lower_bound(entries_before_row, entries_before_row + rows + 1, target) - entries_before_row);
-            c->row_begin[(size_t) g] = std::max(c->row_begin[(size_t) g - 1], std::min(r, rows));
-        }
-    } else {
-        const long long per = std::max<long long>(1, ((long long) rows + G - 1) / G); // ceil(rows / G): src/matrix/csr-matrix.cpp:77-95
-        for (int g = 1; g < G; ++g)
-            c->row_begin[(size_t) g] = (int32_t) std::min<long long>(rows, g * per);
-    }
-    c->row_begin[(size_t) G] = rows;
+    partition_rows(rows, G, (c->flags & SPMV_HIP_FLAG_BALANCE_ENTRIES) ? entries_before_row : nullptr, c->row_begin.data());
     int32_t chunk = 1;
     for (int g = 0; g < G; ++g)
         chunk = std::max(chunk, c->row_begin[(size_t) g + 1] - c->row_begin[(size_t) g]);
@@ -649,6 +658,18 @@ int multi_times(spmv_hip_ctx * c, uint64_t * kernel_ns, uint64_t * gather_ns)
 } // namespace spmvi
 
 extern "C" {
+
+int spmv_hip_partition_rows(int32_t rows, int parts, const int32_t * host_row_ptr, int balance_entries, int32_t * row_begin)
+{
+    if (rows < 0 || parts < 1 || parts > 4096 || !row_begin || (balance_entries && !host_row_ptr))
+        return fail(SPMV_HIP_ERR_INVALID, "spmv_hip_partition_rows: rows >= 0, 1 <= parts <= 4096, row_begin[parts + 1]; row_ptr when the entries are to be balanced");
+    if (balance_entries)
+        for (int32_t r = 0; r < rows; ++r)
+            if (host_row_ptr[r + 1] < host_row_ptr[r])
+                return fail(SPMV_HIP_ERR_INVALID, "row_ptr must be non-decreasing");
+    partition_rows<int32_t>(rows, parts, balance_entries ? host_row_ptr : nullptr, row_begin);
+    return SPMV_HIP_OK;
+}
 
 int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
 {

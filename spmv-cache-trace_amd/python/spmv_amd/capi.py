@@ -85,6 +85,7 @@ SIGNATURES = {
     "spmv_hip_csr_spmv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_csr_spmv_out": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spmv_hip_csr_spmv_out_peers": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _vp]),
+    "spmv_hip_partition_rows": (C.c_int, [C.c_int32, C.c_int, _vp, C.c_int, _vp]),
     "spmv_hip_ipc_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t, C.c_char_p]),
     "spmv_hip_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "spmv_hip_ipc_close": (C.c_int, [_vp]),

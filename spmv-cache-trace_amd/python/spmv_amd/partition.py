@@ -5,31 +5,42 @@ The reference already cuts the rows into one contiguous block per OpenMP thread,
 ``Matrix::spmv_rows_per_thread``, src/matrix/csr-matrix.cpp:77-84).  Ranks take the
 place of threads here: rank g owns rows ``[g*chunk, min(rows, (g+1)*chunk))``, holds
 the full x, computes its y segment, and one all-gather assembles y.
+
+The rule itself lives in ONE place, the C library (spmv_hip_partition_rows, csrc/multi_gpu.hip): the drop-in's
+single-process context (spmv_hip_create_multi) and these one-process-per-GPU helpers cut by the same function.
 """
+import ctypes as C
+
 import numpy as np
 
 
+def _boundaries(rows, parts, row_ptr=None):
+    from . import capi
+    out = np.zeros(parts + 1, dtype=np.int32)
+    rp = None if row_ptr is None else np.ascontiguousarray(row_ptr, dtype=np.int32)
+    capi.check(capi.load().spmv_hip_partition_rows(int(rows), int(parts), None if rp is None else rp.ctypes.data_as(C.c_void_p),
+                                                   0 if rp is None else 1, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def row_chunk(rows, parts):
-    """ceil(rows / parts): the reference's chunk size."""
-    return (rows + parts - 1) // parts if parts > 0 else rows
+    """ceil(rows / parts): the reference's chunk size (the longest block of the static rule)."""
+    if parts <= 0:
+        return rows
+    b = _boundaries(rows, parts)
+    return max(1, int(np.max(np.diff(b)))) if rows > 0 else 0
 
 
 def row_range(rows, part, parts):
     """Rows [begin, end) of partition `part` under the reference's static rule."""
-    chunk = row_chunk(rows, parts)
-    return min(rows, part * chunk), min(rows, (part + 1) * chunk)
+    b = _boundaries(rows, parts)
+    return int(b[part]), int(b[part + 1])
 
 
 def nnz_balanced_ranges(row_ptr, parts):
     """Alternative split on row boundaries with ~equal stored entries per part:
-    boundaries[g] = first row whose row_ptr >= g*nnz/parts (binary search)."""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    rows = len(row_ptr) - 1
-    nnz = int(row_ptr[-1] - row_ptr[0])
-    targets = row_ptr[0] + (np.arange(parts + 1, dtype=np.int64) * nnz) // parts
-    b = np.searchsorted(row_ptr, targets, side="left")
-    b[0], b[-1] = 0, rows
-    b = np.maximum.accumulate(np.minimum(b, rows))
+    boundaries[g] = first row whose row_ptr >= g*nnz/parts."""
+    b = _boundaries(len(row_ptr) - 1, parts, row_ptr)
     return [(int(b[g]), int(b[g + 1])) for g in range(parts)]
 
 

@@ -200,3 +200,53 @@ def mesh_dofs(grid, d, seed=1, jitter_share=0.3):
     idx = np.repeat(starts - p[:-1], lens) + np.arange(int(p[-1]))
     c = seg[idx].astype(np.int32)
     return n * d, n * d, p.astype(np.int32), c, rng.uniform(-1, 1, size=len(c))
+
+
+def delaunay_mesh(npoints, d=3, seed=1, order="rcm", dim=3):
+    """An UNSTRUCTURED finite-element matrix with variable valence (round 6; VERDICT r05 item 4: a structure no generator of the
+    host library shaped): the Delaunay tetrahedra (dim = 3; triangles for dim = 2) of `npoints` uniformly random points of the unit
+    cube, one node per point, two nodes coupled where they share an element, `d` unknowns per node (dense d x d blocks, as a
+    vector-valued P1 discretisation assembles them), numbered by reverse Cuthill-McKee (order = "rcm", scipy's) -- or left in the
+    random order of the points (order = "random": the scattered class) -- unknown by unknown within a node.  A 3-D Delaunay node has
+    ~15.5 neighbours on average, between 4 and ~40: rows of 16.5 d entries on average, no two neighbourhoods alike, nothing
+    shifted, nothing periodic.  Values U(-1, 1) with a dominant diagonal; the structure is symmetric.  Returns CSR arrays with
+    ascending columns.  Needs scipy (test / tool infrastructure only)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    pts = rng.random((npoints, dim))
+    tri = Delaunay(pts)
+    simp = tri.simplices.astype(np.int64)
+    k = simp.shape[1]
+    a = np.concatenate([simp[:, i] for i in range(k) for j in range(k) if i != j])
+    b = np.concatenate([simp[:, j] for i in range(k) for j in range(k) if i != j])
+    del tri, simp
+    G = sp.coo_matrix((np.ones(len(a), dtype=np.int8), (a, b)), shape=(npoints, npoints)).tocsr()
+    del a, b
+    G.data[:] = 1  # (duplicates were summed)
+    G = (G + sp.identity(npoints, dtype=np.int8, format="csr")).tocsr()
+    if order == "rcm":
+        perm = reverse_cuthill_mckee(G, symmetric_mode=True)
+        G = G[perm][:, perm].tocsr()
+    G.sort_indices()
+    P, J = G.indptr.astype(np.int64), G.indices.astype(np.int64)
+    deg = np.diff(P)
+    if d == 1:
+        p, c = P, J
+    else:
+        # every node's column list, d columns per neighbour, repeated for each of its d rows
+        node_cols = (J[:, None] * d + np.arange(d)[None, :]).reshape(-1)          # node-major: d * deg(i) columns per node
+        starts = np.repeat(P[:-1] * d, d)                                           # where a row's node's list starts ...
+        lens = np.repeat(deg * d, d)                                                # ... and how long it is, for every row
+        p = np.zeros(npoints * d + 1, dtype=np.int64)
+        np.cumsum(lens, out=p[1:])
+        within = np.arange(int(p[-1]), dtype=np.int64) - np.repeat(p[:-1], lens)
+        c = node_cols[np.repeat(starts, lens) + within]
+    if int(p[-1]) > 2 ** 31 - 1:
+        raise ValueError("delaunay_mesh: more than 2^31 - 1 entries")
+    rows = npoints * d
+    v = rng.uniform(-1.0, 1.0, size=int(p[-1]))
+    r = np.repeat(np.arange(rows, dtype=np.int64), np.diff(p))
+    v[c == r] += 4.0 * d
+    return rows, rows, p.astype(np.int32), c.astype(np.int32), v

@@ -549,3 +549,64 @@ def test_confirm_blocks_before_compress_gives_the_same_plan(oracle):
     plan.confirm_blocks(tp2.data_ptr(), tc2.data_ptr(), p2, stream)
     assert plan.info()["row_blocks"] == before
     plan.close()
+
+
+# ---- round 6: WIDE block tiles -- a tile whose columns span 64 K or more (an unstructured mesh numbered by reverse Cuthill-McKee has
+# a band of ~7 n^(2/3) nodes; numbered at random, of the whole matrix) has no 16-bit columns, but its 3 x 3 blocks are blocks all the
+# same: masked block words carry 22 bits of column since round 6 --------------------------------------------------------------------
+def _scatter_nodes(rows, cols, p, c, v, factor, seed):
+    """The same blocks with their COLUMN nodes scattered over `factor` times as many nodes (a rectangular matrix: rows x factor * cols):
+    column node m -> a sorted random subset's m-th element, so that rows stay ascending and the triples stay aligned."""
+    rng = np.random.default_rng(seed)
+    nodes = cols // 3
+    pick = np.sort(rng.choice(nodes * factor, size=nodes, replace=False)).astype(np.int64)
+    c2 = (3 * pick[c // 3] + c % 3)
+    return rows, cols * factor, p, c2.astype(np.int32), v
+
+
+@pytest.mark.parametrize("name,make,expect_wide", [
+    ("delaunay 3 dof, 30 K points in random order", lambda: synth.delaunay_mesh(30000, 3, seed=5, order="random"), True),
+    ("delaunay 3 dof, 60 K points, rcm", lambda: synth.delaunay_mesh(60000, 3, seed=6), None),  # narrow and wide tiles side by side
+    ("fem3 with its column nodes spread over 3 M columns", lambda: _scatter_nodes(*fem3(6000, 20, 34, seed=9), factor=170, seed=1), True),
+    ("fem3 with its column nodes spread over 9 M columns", lambda: _scatter_nodes(*fem3(6000, 20, 34, seed=9), factor=500, seed=2), False)])
+def test_wide_block_tiles(oracle, name, make, expect_wide):
+    """Whole vector against the oracle; the tiles are block tiles although they have no 16-bit columns (masked words, 22 bits of
+    column) -- up to a span of 4 M columns, beyond which a tile keeps its 32-bit column indices (and the same y)."""
+    rows, cols, p, c, v = make()
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    # (the scattered twins have an x of 24 / 72 MB and columns all over it: the plan would multiply a column-panel copy, whose launch
+    # ignores the block marks -- the panels are switched off to get at the tiles this test is about)
+    base = capi.FLAG_NO_COLUMN_PANELS if name.startswith("fem3") else 0
+    got, info = run_plan(rows, cols, p, c, v, x, y0, flags=base, index_values=False)
+    assert info["panel_tiles"] == 0
+    assert_close(got, want, scale, what=name)
+    if expect_wide is True:
+        assert info["narrow_tiles"] < 0.2 * info["row_blocks"], info
+        assert info["masked_block_tiles"] > 0.8 * info["row_blocks"], (name, info["masked_block_tiles"], info["row_blocks"])
+    elif expect_wide is False:
+        assert info["block_tiles"] < 0.2 * info["row_blocks"], info  # spans beyond 22 bits: plain tiles with 32-bit columns
+    else:
+        assert info["block_tiles"] > 0.8 * info["row_blocks"], (name, info["block_tiles"], info["masked_block_tiles"], info["narrow_tiles"], info["row_blocks"])
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=base | capi.FLAG_NO_BLOCK_TILES, index_values=False)
+    assert info_n["block_tiles"] == 0
+    assert_close(got_n, want, scale, what=name + ", no block tiles")
+    if expect_wide is not False:
+        # (the scattered twin's x -- 24 MB, read once -- is most of what its launch streams)
+        assert info["streamed_bytes"] < (0.9 if name.startswith("fem3") else 0.85) * info_n["streamed_bytes"], (info["streamed_bytes"], info_n["streamed_bytes"])
+    got_e, _ = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER, index_values=False)
+    assert_bitexact(got_e, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=1), name + ", exact order")
+    got3, _ = run_plan(rows, cols, p, c, v, x, y0, flags=base, runs=3, index_values=False)
+    assert_close(got3, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=3), 3 * scale, what=name + ", three runs")
+    got_o, _ = run_plan(rows, cols, p, c, v, x, y0, flags=base, out_of_place=True, index_values=False)
+    assert_close(got_o, want, scale, what=name + ", y_out")
+    got_c, _ = run_plan(rows, cols, p, c, v, x, y0, flags=base, other_columns=True, index_values=False)
+    assert_close(got_c, want, scale, what=name + ", other column array")
+    with capi.Context(0) as ctx:  # the context API (what the adapters use) builds the same plan
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what=name + ", context upload")

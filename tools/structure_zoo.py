@@ -116,6 +116,15 @@ def zoo():
     out["mesh_4dof_100x80x60"] = lambda: synth.mesh_dofs((100, 80, 60), 4)
     out["mesh_5dof_80x60x60"] = lambda: synth.mesh_dofs((80, 60, 60), 5)
     out["mesh_6dof_80x60x50"] = lambda: synth.mesh_dofs((80, 60, 50), 6)
+    # round 6: unstructured meshes with VARIABLE valence -- Delaunay tetrahedra of random points, numbered by
+    # reverse Cuthill-McKee -- a structure that no generator of the host library shaped (4 ... ~40 neighbours per node, no two
+    # neighbourhoods alike); 3 unknowns per node = the honest twin of Queen_4147, 1 per node = the commonest SuiteSparse shape
+    out["delaunay_3dof_700k"] = lambda: synth.delaunay_mesh(700000, 3, seed=1)     # 104 M entries, ~49.5 per row
+    out["delaunay_1dof_2M"] = lambda: synth.delaunay_mesh(2000000, 1, seed=2)      # 33 M entries, ~16.5 per row
+    out["delaunay_1dof_6M"] = lambda: synth.delaunay_mesh(6200000, 1, seed=2)      # 102 M entries (minutes of qhull)
+    out["delaunay_2dof_1M"] = lambda: synth.delaunay_mesh(1000000, 2, seed=3)      # 66 M entries, ~33 per row
+    out["delaunay_2d_1dof_8M"] = lambda: synth.delaunay_mesh(8000000, 1, seed=4, dim=2)  # triangles: 7 per row, 56 M entries
+    out["delaunay_3dof_random_order"] = lambda: synth.delaunay_mesh(300000, 3, seed=5, order="random")  # the same mesh numbered at random
     out["ragged_1-8_near"] = lambda: ragged(8000000, 1, 8, 2000, 3)
     out["ragged_4-40_near"] = lambda: ragged(3000000, 4, 40, 5000, 4)
     out["ragged_20-100_near"] = lambda: ragged(1200000, 20, 100, 20000, 5)
