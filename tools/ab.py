@@ -34,8 +34,12 @@ def main():
     import torch
     from spmv_amd import capi, hostapi, synth
 
-    A = hostapi.load(args.matrix, "csr", expand_symmetric=args.expand_symmetric)
-    rows, cols, p, c, v = A.rows, A.cols, A.row_ptr, A.column_index, A.value
+    if args.matrix.startswith("delaunay:"):  # delaunay:<points>,<unknowns per node>[,seed[,rcm|random]] (python generator, scipy)
+        q = args.matrix[9:].split(",")
+        rows, cols, p, c, v = synth.delaunay_mesh(int(q[0]), int(q[1]), seed=int(q[2]) if len(q) > 2 else 1, order=q[3] if len(q) > 3 else "rcm")
+    else:
+        A = hostapi.load(args.matrix, "csr", expand_symmetric=args.expand_symmetric)
+        rows, cols, p, c, v = A.rows, A.cols, A.row_ptr, A.column_index, A.value
     nnz = int(p[-1])
     nbytes = synth.csr_bytes(rows, cols, nnz)
     dev = torch.device("cuda:0")
