@@ -1090,7 +1090,13 @@ int spmv_hip_plan_csr_compress(spmv_hip_plan * pl, const int32_t * d_column_inde
     if (e == hipSuccess) {
         hipLaunchKernelGGL(spmv::csr_tile_compress_kernel, dim3((pl->ntiles + 3) / 4), dim3(256), 0, s,
                            pl->ntiles, pl->tile, pl->d_tiles, d_column_index, pl->d_col16, d_count,
-                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp, std::max(1, (pl->cols + 7) / 8));
+                           (pl->flags & SPMV_HIP_FLAG_NO_SHIFTED_TILES) ? 0 : 1, d_fp,
+                           // "scattered" (counts[4]): a tile whose columns reach further than one column panel -- an eighth of the matrix --
+                           // AND further than an XCD's L2 holds of x beside the matrix streams (3 MB: the same figure as the matrix-level
+                           // test in repack).  Round 6: a mesh in RCM order has a band of ~7 n^(2/3) nodes, which for 0.3 ... 1 M nodes is
+                           // more than an eighth of the matrix and still only ~1 MB of x (the Delaunay twin with 300 K nodes was given
+                           // column panels and ran at 0.56 where 100 K and 500 K nodes ran at 0.90: profiles/r06_delaunay_panel_cliff.log)
+                           std::max(std::max(1, (pl->cols + 7) / 8), 3 * 1024 * 1024 / 8));
         e = hipGetLastError();
     }
     // patterns: the shifted tiles' shape fingerprints come back to the host, the most frequent
@@ -1657,7 +1663,10 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
     }
     // column panels pay when x does not fit one XCD's L2 and the columns are scattered; they cost
     // a copy of the matrix, one virtual row per (row, panel) and atomic y updates
-    const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles;
+    // (never where the tile classes that read no column index per entry -- block, group, masked stencil tiles -- are the majority:
+    // their launch streams 8.2 ... 9 bytes per entry at the triad's rate, a panel copy 12 with atomics at a quarter of it)
+    const bool scattered = 2 * (long long) pl->spread_tiles > pl->ntiles && 2 * (long long) pl->shifted_tiles < pl->ntiles
+        && 2 * ((long long) pl->block_tiles + pl->colshare_tiles + pl->stencil_mask_tiles) < pl->ntiles;
     if (pl->algorithm != SPMV_HIP_CSR_WAVETILE || pl->tile != 512 || pl->balanced || pl->nnz == 0 || pl->rows < 1024
         || (pl->flags & (SPMV_HIP_FLAG_EXACT_ORDER | SPMV_HIP_FLAG_NO_COLUMN_PANELS | SPMV_HIP_FLAG_XCD_REMAP))
         || !pl->d_col16 /* not compressed: the tile classes are unknown */

@@ -8,8 +8,10 @@ time in units of what the box's memory delivers.  Bandwidth-bound workloads fail
 table in those units (the old gate was x 1.15 over the slowest box ever seen in microseconds; x 1.07, tried first in
 round 5, failed twice on boxes of EQUAL triad whose launches were 7-8 % slower with identical code -- the table's
 "what" quotes the runs); the latency-bound ones (a web graph: 24 us) keep x 1.15; rows whose launch differs by
-8-10 % between such boxes (queen-like, kkt-like, a wave per long row) carry their own gate of 1.12.  The test takes
-the fastest of five rounds.
+8-10 % between such boxes (a wave per long row) carry their own gate of 1.12.  Round 6: the queen-like and kkt-like rows
+are uploaded three times in the process and the fastest copy counts (their launches move by 3-6 % with the physical pages
+the arrays get, tools/placement_probe.py) -- gate 1.06; Poisson 4096^2, which does not move, 1.04; and no row may be more
+than 20 % slower in microseconds than the table's box whatever the triads say.  The test takes the fastest of five rounds.
 """
 import json
 import os
@@ -47,5 +49,9 @@ def test_launch_time_within_the_floor(name):
     ratio = us * info["triad_gbs"] / (row["us"] * row["triad_gbs"])
     if us <= 1.02 * row["us"]:
         return  # not slower in microseconds than the table's box: no regression, whatever this box's triad says
+    #  beside the triad-normalised ratio an absolute ceiling in microseconds: a box with a low triad does not get to be
+    # 16 % slower
+    assert us <= perf_floor.ABSOLUTE_CEILING * row["us"], "%s: %.1f us per launch, the table has %.1f us: more than x %.2f slower in microseconds: %r" % (
+        name, us, row["us"], perf_floor.ABSOLUTE_CEILING, info)
     assert ratio <= allowed, "%s: %.1f us per launch at a triad of %.0f GB/s, the table has %.1f us at %.0f GB/s: x %.3f in units of the box's triad (x %.2f allowed): %r" % (
         name, us, info["triad_gbs"], row["us"], row["triad_gbs"], ratio, allowed, info)

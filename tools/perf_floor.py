@@ -54,6 +54,14 @@ WORKLOADS = {
     "poisson3d_256_csr": ("synthetic:poisson3d:256", "csr", 0x100000),   # grid lines of 256 cells: masked stencil tiles (round 5), values read
     "mesh_2dof_csr": ("synthetic:queen:100,80,70,3,0,0,2", "csr", 0),     # 2 / 4 unknowns per node: group tiles (end of round 5)
     "mesh_4dof_csr": ("synthetic:queen:100,80,60,3,0,0,4", "csr", 0),
+    # round 6: the stored lower triangles (what the reference multiplies from a symmetric file): masked block tiles with triangular
+    # diagonal blocks; half stencils and 8 M rows that hold their diagonal only
+    "queen_stored_csr": ("synthetic:queen:tril", "csr", 0),
+    "kkt125_stored_csr": ("synthetic:kkt:125:tril", "csr", 0),
+    # ... an UNSTRUCTURED mesh with variable valence (Delaunay tetrahedra, 3 unknowns per node, RCM order; python generator): WIDE block
+    # tiles -- 3 x 3 blocks in tiles whose columns span more than 64 K -- and the same mesh with one unknown per node (plain wide tiles)
+    "delaunay_3dof_csr": ("delaunay:300000,3,1", "csr", 0),
+    "delaunay_1dof_csr": ("delaunay:1000000,1,2", "csr", 0),
 }
 
 
@@ -63,8 +71,17 @@ TOLERANCE = {"bandwidth": 1.10, "latency": 1.15}  # (1.07 failed twice on the po
 # a wave per long row spreads more between boxes than the triad does (bands of 2001 per row: 0.76 ... 0.86 of the roofline on
 # five boxes of one afternoon, profiles/r05_results.md): these rows carry their own gate
 # ... and so do the queen-like and kkt-like launches (full size: 462 ... 510 us and 743 ... 803 us on boxes with the same triad)
-ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.12, "kkt125_csr": 1.12, "kkt125_jitter50_csr": 1.12,
-                 "mesh_2dof_csr": 1.15, "mesh_4dof_csr": 1.15}  # (the two mesh rows: one box measured so far, end of round 5)
+# Round 6: where the spread is NOT the kernel's it is taken out of the measurement instead of
+# being allowed for in the gate.  The queen-like and kkt-like launches move by 3-6 % with the physical pages their arrays get
+# (tools/placement_probe.py): such rows are uploaded REUPLOADS times in the process and the fastest copy counts, gate 1.06;
+# Poisson 4096^2 does not move (0.4 % over 16 uploads): gate 1.04; the mesh rows have been measured on several boxes now and
+# take the common gate.  A wave per long row keeps 1.12 (0.76 ... 0.86 of the roofline on five boxes of one afternoon).
+ROW_TOLERANCE = {"banded2001_csr": 1.12, "banded4001_ell": 1.12, "queen_full_csr": 1.06, "kkt125_csr": 1.06, "kkt125_jitter50_csr": 1.06,
+                 "queen_stored_csr": 1.06, "kkt125_stored_csr": 1.06, "poisson4096_csr_values": 1.04, "poisson4096_csr_dictionary": 1.04}
+REUPLOADS = {"queen_full_csr": 3, "kkt125_csr": 3, "kkt125_jitter50_csr": 3, "queen_stored_csr": 3, "kkt125_stored_csr": 3}
+# ... and beside the triad-normalised ratio an ABSOLUTE ceiling: no box may be more than this factor slower in microseconds than
+# the table's box, whatever its triad says (a box with a low triad could otherwise be 16 % slower and pass)
+ABSOLUTE_CEILING = 1.20
 
 
 _TRIAD = {}
@@ -99,65 +116,85 @@ def measure_triad(rounds=6, reps=20):
     return best
 
 
+class _PyMatrix:
+    """A matrix from the python generators (synth.delaunay_mesh) with the attributes measure() uses of a host-library matrix."""
+
+    def __init__(self, spec):
+        from spmv_amd import synth
+        q = spec.split(":", 1)[1].split(",")
+        self.rows, self.cols, self.row_ptr, self.column_index, self.value = synth.delaunay_mesh(int(q[0]), int(q[1]), seed=int(q[2]) if len(q) > 2 else 1)
+
+    def close(self):
+        pass
+
+
 def measure(name, rounds=5, reps=20):
-    """(min over rounds of the mean launch time in us, info dict); info["triad_gbs"] = the box's triad just before."""
+    """(min over rounds of the mean launch time in us, info dict); info["triad_gbs"] = the box's triad just before.
+    Rows in REUPLOADS: the device arrays are allocated and filled that many times, the fastest copy counts."""
     import torch
     from spmv_amd import capi, hostapi, synth
     spec, fmt, flags = WORKLOADS[name]
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     triad_gbs = measure_triad()
-    M = hostapi.load(spec, fmt)
+    M = _PyMatrix(spec) if spec.startswith("delaunay:") else hostapi.load(spec, fmt)
     x = synth.x_vector(M.cols, "uniform", seed=12345)
-    keep = []
-    if fmt == "csr":
-        plan = capi.CsrPlan(M.rows, M.cols, M.row_ptr, capi.CSR_AUTO, 0, flags)
-        tp, tc, tv = (torch.from_numpy(np.asarray(t)).to(dev) for t in (M.row_ptr, M.column_index, M.value))
-        tx = torch.from_numpy(x).to(dev)
-        ty = torch.zeros(M.rows, dtype=torch.float64, device=dev)
-        plan.compress(tc.data_ptr(), stream)
-        plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
-        plan.index_values(tv.data_ptr(), stream)
-        ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr())
+    best, info, per_upload = None, None, []
+    hold = []  # earlier copies stay allocated while the next one is made: a fresh upload gets OTHER physical pages
+    for upload in range(REUPLOADS.get(name, 1)):
+        keep = []
+        if fmt == "csr":
+            plan = capi.CsrPlan(M.rows, M.cols, M.row_ptr, capi.CSR_AUTO, 0, flags)
+            tp, tc, tv = (torch.from_numpy(np.asarray(t)).to(dev) for t in (M.row_ptr, M.column_index, M.value))
+            tx = torch.from_numpy(x).to(dev)
+            ty = torch.zeros(M.rows, dtype=torch.float64, device=dev)
+            plan.compress(tc.data_ptr(), stream)
+            plan.repack(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), stream)
+            plan.index_values(tv.data_ptr(), stream)
+            ptrs = (tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr())
 
-        def launch():
-            plan.spmv(*ptrs, stream)
-        info = plan.info()
-        keep = [plan, tp, tc, tv, tx, ty]
-    else:
-        ctx = capi.Context(0, flags | capi.FLAG_NO_RUN_EVENTS)
-        ctx.set_stream(stream)
-        if fmt == "coo":
-            ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
-        elif fmt == "ell":
-            ctx.upload_ell(M.rows, M.cols, M.row_length, M.column_index, M.value)
+            def launch():
+                plan.spmv(*ptrs, stream)
+            info = plan.info()
+            keep = [plan, tp, tc, tv, tx, ty]
         else:
-            ctx.upload_hybrid(M.rows, M.cols, M.row_length, M.column_index, M.value, M.coo_row_index, M.coo_column_index, M.coo_value)
-        ctx.set_x(x)
+            ctx = capi.Context(0, flags | capi.FLAG_NO_RUN_EVENTS)
+            ctx.set_stream(stream)
+            if fmt == "coo":
+                ctx.upload_coo(M.rows, M.cols, M.row_index, M.column_index, M.value)
+            elif fmt == "ell":
+                ctx.upload_ell(M.rows, M.cols, M.row_length, M.column_index, M.value)
+            else:
+                ctx.upload_hybrid(M.rows, M.cols, M.row_length, M.column_index, M.value, M.coo_row_index, M.coo_column_index, M.coo_value)
+            ctx.set_x(x)
 
-        def launch():
-            ctx.run(1, sync=False)
-        info = ctx.info()
-        keep = [ctx]
+            def launch():
+                ctx.run(1, sync=False)
+            info = ctx.info()
+            keep = [ctx]
+        this = None
+        for rnd in range(rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd > 0:  # round 0 warms up
+                us = e0.elapsed_time(e1) / reps * 1e3
+                this = us if this is None else min(this, us)
+        per_upload.append(round(this, 2))
+        best = this if best is None else min(best, this)
+        for k in keep:
+            if hasattr(k, "close"):
+                k.close()
+        hold.append([k for k in keep if not hasattr(k, "close")])
     M.close()
-    best = None
-    for rnd in range(rounds + 1):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            launch()
-        e1.record()
-        torch.cuda.synchronize()
-        if rnd > 0:  # round 0 warms up
-            us = e0.elapsed_time(e1) / reps * 1e3
-            best = us if best is None else min(best, us)
-    for k in keep:
-        if hasattr(k, "close"):
-            k.close()
-    del keep
+    del hold, keep
     torch.cuda.empty_cache()
     info = dict(info)
     info["triad_gbs"] = round(triad_gbs, 1)
+    info["us_per_upload"] = per_upload
     return best, info
 
 
