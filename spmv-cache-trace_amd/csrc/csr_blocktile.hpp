@@ -338,9 +338,11 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     // (tiles marked for a block window are checked too: where block tiles turn out to be the majority the plan drops the windows)
     const int other = kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | (1 << 21) /* balanced tiles */;
     // WIDE: the tile's columns span 64 K or more (no 16-bit columns; its descriptor's .w is free): a candidate for masked blocks
-    // with 22-bit columns -- unless a window kernel has claimed it
+    // with 22-bit columns
     const bool wide = !(meta & kTileMetaNarrow);
-    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || (meta & other) || (wide && (!allow_masked || (meta & kTileMetaBlockWin)))
+    // (a tile a window kernel has claimed is checked all the same: where block tiles turn out to be the majority the plan gives the
+    // windows up -- plan_csr.hip)
+    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || (meta & other) || (wide && !allow_masked)
         || nrows < 3 || nrows > kBlockTileMaxRows || nrows % 3 != 0 || n < 18 || k1 - (k0 & ~3) > tile || tile > 512)
         return;
     int cmin = d0.w;
@@ -359,8 +361,11 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
     // row starts in lanes 0 .. nrows (nrows <= 30)
     const int ps = p[r0 + (lane <= nrows ? lane : nrows)];
     const int len = __shfl_down(ps, 1) - ps; // lanes < nrows
-    if (!__all(lane >= nrows || len > 16))
-        return; // rows of up to 16 entries keep their one-lane-per-row, bit-exact path
+    // Rows of up to 16 entries keep their one-lane-per-row, bit-exact path: a tile of such rows only is never a block tile.  (Until
+    // round 6 EVERY row of a block tile had to be longer; but a short row that shares a plain tile with a longer one is added by that
+    // tile's several lanes per row anyway -- 1e-10 class -- and the stored triangle of a mesh matrix mixes rows of 1 ... 100 entries.)
+    if (!__any(lane < nrows && len > 16))
+        return;
     const int len0 = __shfl(len, lane - lane % 3);
     int dense = !wide && n % 9 == 0 && n / 9 <= kWave && __all(lane >= nrows || (len == len0 && len % 3 == 0));
     if (dense) {

@@ -134,7 +134,10 @@ struct spmv_hip_plan {
     int multi_window_tiles = 0; // tiles of several long rows walked in windows of 512 entries
     int block_hint = 0;   // 3: rows in triples (3 x 3 blocks); 2 or 4: rows in groups of that many equally long rows (group tiles)
     int block_offset = 0; // the row (0 ... block_hint - 1) at which the grid of triples / groups starts
-    int hints_tried = 0;  // bit 0: the triples read from row_ptr were wrong (repack found no blocks), bit 1: the groups of 2 / 4 were
+    bool block_skewed = false; // block_hint == 3 read from rows whose lengths go (m + 1, m + 2, m + 3) or back: the stored triangle of a matrix of
+                               // 3 x 3 blocks (a `symmetric` Matrix Market file, multiplied as stored) -- row lengths grow with the neighbours
+                               // numbered in front of a node, so tiles are cut by the block tile's limits, not by the lanes a plain tile needs
+    int hints_tried = 0;  // bit 2: the triangular triples were wrong; bit 0: the triples read from row_ptr were wrong (repack found no blocks), bit 1: the groups of 2 / 4 were
     bool hint_from_bits = false; // block_hint stands on row groups found in the columns (group_bits), not on row_ptr alone
     int colshare_tiles = 0; // group tiles (csr_blocktile.hpp): tiles whose rows share one column list per group of block_hint rows
     long long colshare_entries = 0;

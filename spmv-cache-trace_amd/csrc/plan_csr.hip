@@ -352,7 +352,20 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     const uint32_t * const gb = pl->group_bits; // bit r: row r begins a group of rows with the same columns (repack's second cut only)
     auto group_start = [gb, rows](int32_t q) { return q >= rows || ((gb[q >> 5] >> (q & 31)) & 1u) != 0; };
     auto triple_at = [&](int32_t q) { return q + 3 <= rows && group_start(q) && !group_start(q + 1) && !group_start(q + 2) && group_start(q + 3); };
+    // ... and the STORED TRIANGLE of such a matrix (round 6) -- what a `symmetric` Matrix Market file holds and the reference multiplies
+    // as it stands (src/matrix/matrix-market.cpp:530-555): the rows of a node are (m + 1, m + 2, m + 3) entries long with m a multiple
+    // of 3 (lower triangle: m / 3 whole blocks and the node's own triangular one; upper triangle: the lengths run the other way).
+    // Row lengths then grow with the number of neighbours numbered in front of a node -- in an unstructured mesh anything from
+    // 1 to ~100 -- which a plain tile takes badly (its longest row fixes the lanes per row: 39 % full, and the plan fell back to
+    // balanced tiles at 0.57 of the roofline, profiles/r06_structure_zoo.log) and a block tile does not mind (a lane per block).
+    auto skewed_triple = [p, rows](int32_t q) {
+        if (q < 0 || q + 3 > rows)
+            return false;
+        const int l0 = p[q + 1] - p[q], l1 = p[q + 2] - p[q + 1], l2 = p[q + 3] - p[q + 2];
+        return (l0 % 3 == 1 && l1 == l0 + 1 && l2 == l0 + 2) || (l2 % 3 == 1 && l1 == l2 + 1 && l0 == l2 + 2);
+    };
     pl->block_candidate = 0;
+    pl->block_skewed = false;
     pl->hint_from_bits = gb != nullptr;
     if (gb) {
         pl->block_hint = 3;
@@ -360,7 +373,25 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     } else {
         pl->block_hint = 0;
         pl->block_offset = 0;
-        if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
+        if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & (SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS))) {
+            for (int o = 0; o < 3 && !pl->block_hint && !(pl->hints_tried & 4); ++o) {
+                const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
+                long long good = 0, bad = 0, entries = 0;
+                for (int32_t q = o; q + 2 < rows && bad <= allowed_bad; q += 3) {
+                    const bool ok = skewed_triple(q);
+                    good += ok;
+                    bad += !ok;
+                    entries += ok ? p[q + 3] - p[q] : 0;
+                }
+                // (on average more than two blocks per block row: a tridiagonal matrix, whose interior rows "go" 2, 3, 3, is not one)
+                if (bad <= allowed_bad && good * 5 >= triples * 4 && entries >= 24 * good) {
+                    pl->block_hint = 3;
+                    pl->block_offset = o;
+                    pl->block_skewed = true;
+                }
+            }
+        }
+        if (!pl->block_hint && !exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & SPMV_HIP_FLAG_NO_BLOCK_TILES)) {
             // (pl->hints_tried: a hint that repack found wrong is not taken again when the tiles are cut anew -- the next one gets its turn)
             for (int o = 0; o < 3 && !pl->block_hint && !(pl->hints_tried & 1); ++o) {
                 // (an offset is given up as soon as a fifth of all triples have failed: a matrix without blocks -- most -- pays for a
@@ -456,9 +487,9 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     ++q;
                 row_limit = q;
             }
-        } else if (pl->block_hint == 3 && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !similar_triple(r)) {
+        } else if (pl->block_hint == 3 && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !(pl->block_skewed ? skewed_triple(r) : similar_triple(r))) {
             for (int d = 1; d <= 2; ++d)
-                if (similar_triple(r + d) && similar_triple(r + d + 3)) {
+                if (pl->block_skewed ? (skewed_triple(r + d) && skewed_triple(r + d + 3)) : (similar_triple(r + d) && similar_triple(r + d + 3))) {
                     phase = (r + d) % 3;
                     row_limit = r + d;
                     break;
@@ -515,11 +546,16 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                         break;
                 }
             }
-            if (!exact && r1 > r) {
+            if (!exact && r1 > r && !pl->block_skewed) {
                 const int l = lanes_for(std::max(maxlen, len));
                 if (l > 0 && ((r1 - r + 1) << l) > 64)
                     break;
             }
+            // (stored-triangle plans: the tile is cut by the block tile's limits below -- 30 rows, a lane per block; should the
+            // columns not bear the blocks out, the plain path adds its rows with the lanes the wave has: fewer than 16 entries per
+            // lane would want, correct all the same)
+            if (pl->block_skewed && r1 - r >= 64)
+                break;
             maxlen = std::max(maxlen, len);
             minlen = std::min(minlen, len);
             ++r1;
@@ -543,9 +579,10 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             }
         }
         // block hint: a tile of long rows ends on a triple boundary and holds at most kBlockTileMaxRows rows
-        if (pl->block_hint && maxlen > 16 && r1 > r + 1) {
+        if (pl->block_hint && (maxlen > 16 || pl->block_skewed) && r1 > r + 1) {
             const int d = pl->block_hint; // 3, or the rows per group of a group-tile plan
-            int32_t cut = std::min(r1, r + spmv::kBlockTileMaxRows - spmv::kBlockTileMaxRows % d);
+            // (a stored-triangle plan's tile of short rows only -- no block tile -- still ends on the grid of triples, for its successor's sake)
+            int32_t cut = maxlen > 16 ? std::min(r1, r + spmv::kBlockTileMaxRows - spmv::kBlockTileMaxRows % d) : r1;
             if (cut < ce)
                 cut -= ((cut - phase) % d + d) % d;
             if (cut > r && cut < r1) {
@@ -668,7 +705,9 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
             r1 = r + 1;
         } else {
             // one lane per row (rows of <= 16 entries) keeps the reference's summation order
-            const int lanes_log2 = multi_lanes_log2 >= 0 ? multi_lanes_log2 : (exact ? 0 : lanes_for(maxlen));
+            int lanes_log2 = multi_lanes_log2 >= 0 ? multi_lanes_log2 : (exact ? 0 : lanes_for(maxlen));
+            while (multi_lanes_log2 < 0 && lanes_log2 > 0 && ((r1 - r) << lanes_log2) > 64)
+                --lanes_log2; // (only in stored-triangle plans: more rows than the longest row's lanes leave room for)
             o.longest_tile_row = std::max(o.longest_tile_row, (int) maxlen);
             // "fast": non-empty, and 16-byte loads of its last quad stay inside the arrays
             const bool fast = p[r1] > p[r] && (((long long) p[r1] - 1) | 3) < (long long) p[rows];
@@ -1326,6 +1365,7 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
 {
     const bool with_blocks = group_bits != nullptr;
     const int wrong_hint = pl->block_hint;
+    const bool wrong_skewed = pl->block_skewed;
     const bool wrong_from_bits = pl->hint_from_bits;
     const bool was_compressed = pl->d_col16 != nullptr; // (a plan that has not been classified yet is not classified here either)
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1363,7 +1403,7 @@ static int rebuild_tiles(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
         if (wrong_from_bits || wrong_hint == 0)
             pl->flags |= SPMV_HIP_FLAG_NO_BLOCK_TILES;
         else
-            pl->hints_tried |= wrong_hint == 3 ? 1 : 2;
+            pl->hints_tried |= wrong_hint == 3 ? (wrong_skewed ? 4 : 1) : 2;
     }
     pl->group_bits = group_bits;
     int rc = build_wave_tiles(pl, host_row_ptr, pl->flags, pl->break_rows, kSplitThreshold, kSplitChunk);
@@ -1477,6 +1517,27 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
             pl->d_blocks = nullptr;
             pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nblocks16 * sizeof(int2));
             pl->nblocks16 = 0;
+            pl->blockwin_tiles = 0;
+            if (pl->d_rest_tiles) {
+                (void) hipFree(pl->d_rest_tiles);
+                pl->d_rest_tiles = nullptr;
+                pl->nrest_tiles = 0;
+            }
+            pl->block_tiles = (int) count[0];
+            pl->block_entries = (long long) count[1];
+        }
+        // ... and likewise the segment windows (x staged through LDS per block of 32 tiles; their tiles' 16-bit stream holds window
+        // slots, so whichever of them is no block tile goes back to its 32-bit columns).  Round 6: the Delaunay mesh with 6 unknowns
+        // per node -- every tile a block tile, more than half of them claimed by segment windows first -- ran at 0.62 of the
+        // roofline with the block hint declared wrong (profiles/r06_structure_zoo.log)
+        if (pl->d_segblocks && 2 * (long long) count[0] > pl->ntiles) {
+            hipLaunchKernelGGL(spmv::csr_clear_segwin_kernel, dim3((unsigned) ((pl->ntiles + 255) / 256)), dim3(256), 0, s, pl->ntiles, pl->d_tiles);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            (void) hipFree(pl->d_segblocks);
+            pl->d_segblocks = nullptr;
+            pl->meta_bytes -= std::min(pl->meta_bytes, (size_t) pl->nsegblocks * sizeof(spmv::SegWinBlock));
+            pl->nsegblocks = pl->segwin_tiles = pl->segwin_slots = 0;
             pl->blockwin_tiles = 0;
             if (pl->d_rest_tiles) {
                 (void) hipFree(pl->d_rest_tiles);

@@ -611,3 +611,76 @@ def test_wide_block_tiles(oracle, name, make, expect_wide):
         ctx.set_y(y0)
         ctx.run()
         assert_close(ctx.get_y(), want, scale, what=name + ", context upload")
+
+
+def _tril(rows, cols, p, c, v):
+    import scipy.sparse as sp
+    A = sp.tril(sp.csr_matrix((v, c, p), shape=(rows, cols)), format="csr")
+    A.sort_indices()
+    return rows, cols, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+
+
+def _triu(rows, cols, p, c, v):
+    import scipy.sparse as sp
+    A = sp.triu(sp.csr_matrix((v, c, p), shape=(rows, cols)), format="csr")
+    A.sort_indices()
+    return rows, cols, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+
+
+@pytest.mark.parametrize("name,make", [
+    ("delaunay 3 dof, 60 K points, rcm, lower triangle", lambda: _tril(*synth.delaunay_mesh(60000, 3, seed=6))),
+    ("delaunay 3 dof, 60 K points, rcm, upper triangle", lambda: _triu(*synth.delaunay_mesh(60000, 3, seed=6))),
+    ("delaunay 3 dof, 30 K points, random order, lower triangle", lambda: _tril(*synth.delaunay_mesh(30000, 3, seed=5, order="random"))),
+    ("queen-like 30 x 24 x 20, lower triangle", lambda: (lambda M: (M.rows, M.cols, np.array(M.row_ptr), np.array(M.column_index), np.array(M.value)))(
+        hostapi.load("synthetic:queen:30,24,20:tril", "csr"))),
+    ("delaunay 6 dof, 25 K points", lambda: synth.delaunay_mesh(25000, 6, seed=7))])
+def test_stored_triangles_of_unstructured_block_matrices(oracle, name, make):
+    """Round 6: the STORED TRIANGLE of a matrix of 3 x 3 blocks -- what the reference multiplies from a `symmetric` file
+    (src/matrix/matrix-market.cpp:530-555) -- for an unstructured mesh: the rows of a node are (m + 1, m + 2, m + 3) entries long, m
+    anything from 0 to ~100.  spmv_hip_plan_csr reads that off row_ptr (the skewed-triple hint), cuts its tiles by the block tile's
+    limits instead of falling back to balanced tiles, and repack marks them as masked block tiles (triangular diagonal blocks, rows of
+    1 ... 16 entries beside longer ones).  Whole vector against the oracle; and the meshes with 6 unknowns per node (6 x 6 blocks are
+    3 x 3 blocks) that segment windows used to claim first."""
+    rows, cols, p, c, v = make()
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0, index_values=False)
+    assert_close(got, want, scale, what=name)
+    assert info["balanced"] == 0, info
+    assert info["block_tiles"] > 0.7 * info["row_blocks"], (name, info["block_tiles"], info["masked_block_tiles"], info["row_blocks"])
+    assert info["block_entries"] > 0.9 * int(p[-1]), (name, info["block_entries"], int(p[-1]))
+    got_n, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES, index_values=False)
+    assert info_n["block_tiles"] == 0
+    assert_close(got_n, want, scale, what=name + ", no block tiles")
+    got_e, _ = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER, index_values=False)
+    assert_bitexact(got_e, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=1), name + ", exact order")
+    got3, _ = run_plan(rows, cols, p, c, v, x, y0, runs=3, index_values=False)
+    assert_close(got3, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=3), 3 * scale, what=name + ", three runs")
+    with capi.Context(0) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what=name + ", context upload")
+
+
+def test_skewed_triples_that_are_no_blocks_fall_back(oracle):
+    """Row lengths that go (m + 1, m + 2, m + 3) without any block structure behind them (random columns): the hint is taken, repack
+    finds no blocks, the tiles are cut anew without it -- and y is the oracle's either way."""
+    rng = np.random.default_rng(11)
+    nodes = 4000
+    m = 3 * rng.integers(2, 30, size=nodes)
+    lens = (m[:, None] + np.arange(1, 4)[None, :]).ravel()
+    rows = cols = 3 * nodes
+    p = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    c = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) for n in lens]).astype(np.int32)
+    v = rng.uniform(-1, 1, size=len(c))
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    got, info = run_plan(rows, cols, p.astype(np.int32), c, v, x, y0, index_values=False)
+    assert info["block_tiles"] == 0
+    assert_close(got, oracle.csr_spmv(rows, p.astype(np.int32), c, v, x, y=y0, num_threads=4), abs_products(rows, p.astype(np.int32), c, v, x) + np.abs(y0),
+                 what="skewed triples without blocks")

@@ -122,7 +122,9 @@ def test_baseline_configs_full_size_whole_vector(oracle, spec, min_rows, min_nnz
         # at least the tiles of short rows only must be exact: most rows
         short = lens <= 16
         same = (y.view(np.uint64) == want.view(np.uint64))
-        if info["panel_tiles"] == 0:
+        # (where short rows are a population of their own -- the kkt-like matrix's control rows, a web graph -- not the three corner
+        # rows of a mesh, which share their tiles with long rows and, since round 6, may sit in a block tile)
+        if info["panel_tiles"] == 0 and short.mean() > 0.01:
             assert same[short].mean() > 0.5, (spec, same[short].mean())
     A.close()
 

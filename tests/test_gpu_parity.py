@@ -922,6 +922,53 @@ def test_ell_whole_long_rows_one_wave_each(oracle, kind, L):
         c2.close()
 
 
+@pytest.mark.parametrize("rows,L", [(300, 9001), (120, 20000), (64, 32767), (2000, 2049)])
+def test_ell_few_very_long_rows_are_split_and_stay_within_the_bound(oracle, rows, L):
+    """a SMALL ELLPACK matrix with very long rows (up to the 32767 entries a band of half-width 16383 has).  By
+    default such rows are cut into chunks -- one wave each, one fp64 atomic per chunk -- so y is not reproducible from run to run:
+    every one of several runs must stay inside SURVEY 8(d)'s bound (1e-10; src/matrix/ell-matrix.cpp:243-258 is the loop restated by
+    the oracle); SPMV_HIP_FLAG_EXACT_ORDER and SPMV_HIP_FLAG_ELL_COLUMN_MAJOR give the reference's bits, run after run."""
+    rng = np.random.default_rng(rows + L)
+    cols = L + 3000
+    start = rng.integers(0, cols - L - 1, size=rows)
+    lens = np.full(rows, L)
+    lens[rng.integers(0, rows, size=rows // 3)] = rng.integers(1, L, size=rows // 3)  # ragged: padding behind the shorter rows
+    lens[0] = L
+    ec = np.zeros((rows, L), dtype=np.int32)
+    ev = np.zeros((rows, L))
+    for r in range(rows):
+        n = int(lens[r])
+        ec[r, :n] = start[r] + np.arange(n)
+        ec[r, n:] = ec[r, n - 1]  # the reference's padding: the row's last real column, value 0 (src/matrix/ell-matrix.cpp:227-229)
+        ev[r, :n] = rng.uniform(-1, 1, size=n)
+    ec, ev = np.ascontiguousarray(ec.reshape(-1)), np.ascontiguousarray(ev.reshape(-1))
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.ell_spmv(rows, L, ec, ev, x, y=y0, runs=2)
+    for flags in (0, capi.FLAG_EXACT_ORDER, capi.FLAG_ELL_COLUMN_MAJOR):
+        c2 = capi.Context(0, flags=flags)
+        try:
+            c2.upload_ell(rows, cols, L, ec, ev)
+            info = c2.info()
+            if flags == 0:
+                assert info["ell_path"] == 1, info
+                if rows * L >= 8192 * 1024:
+                    assert info["row_blocks"] > rows, info  # rows in chunks: more tiles than rows
+            ys = []
+            for _ in range(4):
+                c2.set_x(x)
+                c2.set_y(y0)
+                c2.run()
+                c2.run()
+                ys.append(c2.get_y())
+                assert_ell(ys[-1], want, L, flags, ec, ev, x, y0, 2, "few long ell rows %d x %d flags %x, repeat %d" % (rows, L, flags, len(ys)))
+            if flags:
+                for y in ys[1:]:
+                    assert np.array_equal(y.view(np.uint64), ys[0].view(np.uint64))
+        finally:
+            c2.close()
+
+
 @pytest.mark.parametrize("name", ["band31", "band81", "band200", "tridiagonal", "poisson2d", "ragged_band", "stencil27", "stencil7"])
 def test_x_window_variant_bit_identical(name):
     """Staging x through LDS (the default when most tiles' columns span < 256) changes where x is

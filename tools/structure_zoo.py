@@ -120,6 +120,15 @@ def zoo():
     # reverse Cuthill-McKee -- a structure that no generator of the host library shaped (4 ... ~40 neighbours per node, no two
     # neighbourhoods alike); 3 unknowns per node = the honest twin of Queen_4147, 1 per node = the commonest SuiteSparse shape
     out["delaunay_3dof_700k"] = lambda: synth.delaunay_mesh(700000, 3, seed=1)     # 104 M entries, ~49.5 per row
+    def tril(make):
+        # the stored lower triangle of a symmetric matrix (what the reference multiplies from a `symmetric` Matrix Market file)
+        import scipy.sparse as sp
+        rows, cols, p, c, v = make()
+        A = sp.tril(sp.csr_matrix((v, c, p), shape=(rows, cols)), format="csr")
+        A.sort_indices()
+        return rows, cols, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+    out["delaunay_3dof_700k_tril"] = lambda: tril(lambda: synth.delaunay_mesh(700000, 3, seed=1))  # ... as a symmetric file stores it: 53 M entries
+    out["delaunay_6dof_250k"] = lambda: synth.delaunay_mesh(250000, 6, seed=6)     # shells: 6 x 6 blocks = 3 x 3 blocks, 148 M entries, ~99 per row
     out["delaunay_1dof_2M"] = lambda: synth.delaunay_mesh(2000000, 1, seed=2)      # 33 M entries, ~16.5 per row
     out["delaunay_1dof_6M"] = lambda: synth.delaunay_mesh(6200000, 1, seed=2)      # 102 M entries (minutes of qhull)
     out["delaunay_2dof_1M"] = lambda: synth.delaunay_mesh(1000000, 2, seed=3)      # 66 M entries, ~33 per row
