@@ -476,11 +476,15 @@ static __global__ __launch_bounds__(256) void csr_block3_mark_kernel(
 // readlanes, no memory access.  Then: two 16-bit columns from the group stream, two x, D pairs of values (16-byte loads,
 // consecutive across the lanes of a group row -- the load mix of tile_products_narrow with 1 / D of its gathers) and D pairs of
 // products into the wave's LDS slice at the entries' own places.
+// WIDE group tiles (round 6): a tile whose columns span 64 K or more has no 16-bit columns -- and no use for its slots in the 16-bit
+// column stream, which therefore hold its group columns as 32-bit ABSOLUTE columns (`wide`: gt points at them, xt = x, limit =
+// cols - 1).  The slots hold n / 2 words: enough for one column per pair of adjacent columns (any D) or per column with D = 4.
+// An unstructured mesh with 2 unknowns per node in RCM order (Delaunay, 1 M nodes) ran at 0.65 of the roofline in plain 32-bit tiles.
 template <int D>
 __device__ __forceinline__ void tile_products_grouped(
     double * prod, const uint16_t * __restrict__ gt /* the tile's group stream */, const double * __restrict__ at /* a + kb */,
     const double * __restrict__ xt /* x + tile base */, unsigned limit, int ps_rel, int row_len, int lanes_log2, int nrows, int first_rel /* k0 - kb */,
-    int entries, int lane, bool adjacent /* every pair is (c, c + 1): kTileMetaGroupPairs */)
+    int entries, int lane, bool adjacent /* every pair is (c, c + 1): kTileMetaGroupPairs */, bool wide = false)
 {
     static_assert(D == 2 || D == 4, "row groups of 2 or 4");
     constexpr int STEPS = 4 / D; // a tile holds at most 512 / D group entries = 256 / D pairs: D = 2: 2 x 64, D = 4: 1 x 64
@@ -509,8 +513,14 @@ __device__ __forceinline__ void tile_products_grouped(
     for (int i = 0; i < STEPS; ++i) {
         int t = lane + 64 * i;
         t = t < pairs ? t : pairs - 1; // idle lanes repeat the last pair's loads and store nothing
-        c0[i] = adjacent ? gt[t] : gt[2 * t]; // (adjacent pairs: the stream holds the first column of every pair only)
-        c1[i] = adjacent ? 0u : gt[2 * t + 1];
+        if (wide) { // (wave-uniform)
+            const uint32_t * g32 = reinterpret_cast<const uint32_t *>(gt);
+            c0[i] = adjacent ? g32[t] : g32[2 * t];
+            c1[i] = adjacent ? 0u : g32[2 * t + 1];
+        } else {
+            c0[i] = adjacent ? gt[t] : gt[2 * t]; // (adjacent pairs: the stream holds the first column of every pair only)
+            c1[i] = adjacent ? 0u : gt[2 * t + 1];
+        }
 #pragma unroll
         for (int a = 0; a < D; ++a)
             v[i][a] = *reinterpret_cast<const v2d_u8 *>(at + 2 * t + off[i] + a * len[i]);
@@ -546,9 +556,12 @@ __device__ __forceinline__ void tile_products_grouped(
 // groups of D equally long rows with the same columns, entry by entry; the first row's columns (offsets from the tile's smallest
 // column) are then copied to the group stream and the tile marked.  Counts as csr_block3_mark_kernel's: count[0], [1] tiles and
 // entries, count[2], [3] those no block window has claimed.
+// where a WIDE group tile keeps its 32-bit group columns: its own slots of the 16-bit column stream, from the first even one on
+__host__ __device__ __forceinline__ int wide_group_first_slot(int k0) { return (k0 + 1) & ~1; }
+
 static __global__ __launch_bounds__(256) void csr_group_mark_kernel(
     int ntiles, int tile, int d, int4 * __restrict__ desc, const int32_t * __restrict__ p, const int32_t * __restrict__ j,
-    uint16_t * __restrict__ gstream, unsigned long long * __restrict__ count)
+    uint16_t * __restrict__ gstream, unsigned long long * __restrict__ count, uint16_t * __restrict__ j16 = nullptr, int cols = 0)
 {
     const int wave = (int) threadIdx.x >> 6;
     const int lane = (int) __lane_id();
@@ -562,10 +575,13 @@ static __global__ __launch_bounds__(256) void csr_group_mark_kernel(
     const int meta = d0.z;
     const int nrows = r1 - r0, n = k1 - k0;
     const int other = kTileMetaShifted | kTileMetaXWin | kTileMetaXSeg | kTileMetaPattern | (1 << 21) /* balanced tiles */;
-    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || !(meta & kTileMetaNarrow) || (meta & other)
+    // WIDE: no 16-bit columns (the tile's columns span 64 K or more): its group columns go, 32 bits each and absolute, into its own
+    // unused slots of the 16-bit stream -- unless a window kernel has claimed the tile (segment windows keep their slots there)
+    const bool wide = !(meta & kTileMetaNarrow);
+    if ((d0.x & kTileFlagPartial) || !(meta & kTileMetaFast) || (meta & other) || (wide && (!j16 || (meta & kTileMetaBlockWin) || cols >= (1 << 29)))
         || nrows < d || nrows > kBlockTileMaxRows || nrows % d != 0 || k1 - (k0 & ~3) > tile || tile > 512 || (d != 2 && d != 4))
         return;
-    const int cmin = d0.w;
+    const int cmin = wide ? 0 : d0.w;
     const int ps = p[r0 + (lane <= nrows ? lane : nrows)]; // row starts in lanes 0 .. nrows (nrows <= 30)
     const int len = __shfl_down(ps, 1) - ps;                // lanes < nrows
     const int len0 = __shfl(len, lane - lane % d);
@@ -590,17 +606,32 @@ static __global__ __launch_bounds__(256) void csr_group_mark_kernel(
             adjacent &= j[start + q] == j[start + q - 1] + 1;
     }
     adjacent = __all(adjacent);
+    uint32_t * g32 = nullptr;
+    if (wide) { // room for one 32-bit column per group column (or per pair) in the tile's own 16-bit slots?
+        const int first = wide_group_first_slot(k0), words = ((k1 & ~1) - first) / 2, need = adjacent ? n / (2 * d) : n / d;
+        if (need > words)
+            return;
+        g32 = reinterpret_cast<uint32_t *>(j16 + first);
+    }
     // the group stream: the first rows' columns, group after group -- every column, or (adjacent pairs) the first of each pair
     const int base = group_stream_index(k0, d);
     for (int r = 0; r < nrows; r += d) {
         const int start = __shfl(ps, r), rl = __shfl(len, r);
         const int g0 = (start - k0) / d; // what the groups in front of this one hold (even: row lengths are)
         if (adjacent) {
-            for (int q = 2 * lane; q < rl; q += 2 * kWave)
-                gstream[base + (g0 + q) / 2] = (uint16_t) (j[start + q] - cmin);
+            for (int q = 2 * lane; q < rl; q += 2 * kWave) {
+                if (wide)
+                    g32[(g0 + q) / 2] = (uint32_t) j[start + q];
+                else
+                    gstream[base + (g0 + q) / 2] = (uint16_t) (j[start + q] - cmin);
+            }
         } else {
-            for (int q = lane; q < rl; q += kWave)
-                gstream[base + g0 + q] = (uint16_t) (j[start + q] - cmin);
+            for (int q = lane; q < rl; q += kWave) {
+                if (wide)
+                    g32[g0 + q] = (uint32_t) j[start + q];
+                else
+                    gstream[base + g0 + q] = (uint16_t) (j[start + q] - cmin);
+            }
         }
     }
     if (lane == 0) {

@@ -846,11 +846,15 @@ __global__ __launch_bounds__(256, (TILE <= 512 ? 8 : 4)) void csr_wavetile_kerne
                  && (group_rows == 2 || group_rows == 4)) {
             // rows in groups of 2 or 4 with the same columns (csr_blocktile.hpp): one column list and one x per group; the row
             // sums below are the plain tile's
-            const uint16_t * gt = j16 + block_stream_offset(nnz_total) + group_stream_index(k0, group_rows);
+            // (a WIDE group tile -- no 16-bit columns -- keeps 32-bit absolute group columns in its own slots of the 16-bit stream)
+            const bool gwide = !(meta & kTileMetaNarrow);
+            const uint16_t * gt = gwide ? j16 + wide_group_first_slot(k0) : j16 + block_stream_offset(nnz_total) + group_stream_index(k0, group_rows);
+            const double * gx = gwide ? x : x + cbase;
+            const unsigned glimit = (unsigned) (cols - 1 - (gwide ? 0 : cbase));
             if (group_rows == 2)
-                tile_products_grouped<2>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0);
+                tile_products_grouped<2>(prod, gt, a + kb, gx, glimit, ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0, gwide);
             else
-                tile_products_grouped<4>(prod, gt, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0);
+                tile_products_grouped<4>(prod, gt, a + kb, gx, glimit, ps - kb, pe - ps, lanes_log2, nrows, k0 - kb, k1 - k0, lane, (meta & kTileMetaGroupPairs) != 0, gwide);
         }
         else if (C16 && (meta & kTileMetaNarrow))
             tile_products_narrow<QUADS, ABL, VI>(prod, j16 + kb, a + kb, x + cbase, (unsigned) (cols - 1 - cbase), last, lane, vidx + kb, vtab);

@@ -169,7 +169,9 @@ int plan_account(spmv_hip_plan * pl, bool compressed)
         }
         if (block3 && (meta & spmv::kTileMetaGroupRows)) { // group tile: one 16-bit column per column of a group of block_hint rows; row_ptr read
             pl->narrow_entries += entries;
-            bytes += 8 * entries + ((meta & spmv::kTileMetaGroupPairs) ? 1 : 2) * (entries / std::max(1, pl->block_hint)) + 16 + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
+            // (a wide group tile's columns are 32-bit ones)
+            bytes += 8 * entries + ((meta & spmv::kTileMetaGroupPairs) ? 1 : 2) * ((meta & spmv::kTileMetaNarrow) ? 1 : 2) * (entries / std::max(1, pl->block_hint)) + 16
+                + 16 * rows + (uniform ? 0 : 4 * (rows + 1));
             if (uniform)
                 pl->uniform_rows += rows;
             continue;
@@ -1491,7 +1493,8 @@ static int repack_stages(spmv_hip_plan * pl, const int32_t * d_row_ptr, const in
         if (e == hipSuccess) {
             if (groups)
                 hipLaunchKernelGGL(spmv::csr_group_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
-                                   pl->block_hint, pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count);
+                                   pl->block_hint, pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz), d_count,
+                                   pl->d_col16, pl->cols);
             else
                 hipLaunchKernelGGL(spmv::csr_block3_mark_kernel, dim3((unsigned) ((pl->ntiles + 3) / 4)), dim3(256), 0, s, pl->ntiles, pl->tile,
                                    pl->d_tiles, d_row_ptr, d_column_index, pl->d_col16 + spmv::block_stream_offset(pl->nnz),

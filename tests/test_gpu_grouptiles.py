@@ -177,3 +177,44 @@ def test_a_value_dictionary_takes_precedence_and_context_uploads(oracle):
         ctx.set_x(x)
         ctx.run()
         assert_close(ctx.get_y(), want0, scale, what="coo upload", nterms=100)
+
+
+@pytest.mark.parametrize("name,make,d", [
+    ("delaunay 2 dof, 40 K points in random order (every tile wide)", lambda: synth.delaunay_mesh(40000, 2, seed=8, order="random"), 2),
+    ("delaunay 2 dof, 120 K points, rcm (narrow and wide tiles)", lambda: synth.delaunay_mesh(120000, 2, seed=9), 2),
+    ("delaunay 4 dof, 25 K points in random order", lambda: synth.delaunay_mesh(25000, 4, seed=10, order="random"), 4),
+    ("delaunay 2-d triangles, 2 dof, 60 K points in random order", lambda: synth.delaunay_mesh(60000, 2, seed=11, order="random", dim=2), 2)])
+def test_wide_group_tiles(oracle, name, make, d):
+    """Round 6: a tile whose columns span 64 K or more has no 16-bit columns -- its group columns are kept as 32-bit absolute columns
+    in the tile's own (unused) slots of the 16-bit stream.  Unstructured meshes with 2 / 4 unknowns per node (dense 2 x 2 / 4 x 4
+    blocks: one column per pair of adjacent columns): whole vector against the oracle, variants of one plan bitwise."""
+    rows, cols, p, c, v = make()
+    x = synth.x_vector(cols, seed=3)
+    y0 = synth.x_vector(rows, seed=4)
+    want = oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4)
+    scale = abs_products(rows, p, c, v, x) + np.abs(y0)
+    got, info = run_plan(rows, cols, p, c, v, x, y0)
+    assert_close(got, want, scale, what=name)
+    if "2-d triangles" not in name:  # (7 neighbours per node: rows of 14 entries, mostly below the 16 a group tile starts at)
+        assert info["group_rows"] == d and info["group_tiles"] > 0.7 * info["row_blocks"], (name, info["group_tiles"], info["narrow_tiles"], info["row_blocks"])
+        if "random order" in name:
+            assert info["narrow_tiles"] < 0.2 * info["row_blocks"], info
+    plain, info_n = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_NO_BLOCK_TILES)
+    assert info_n["group_tiles"] == 0
+    assert_close(plain, want, scale, what=name + ", no group tiles")
+    if info["group_tiles"] > 0.7 * info["row_blocks"]:
+        assert info["streamed_bytes"] < 0.92 * info_n["streamed_bytes"], (info["streamed_bytes"], info_n["streamed_bytes"])
+    got3, _ = run_plan(rows, cols, p, c, v, x, y0, runs=3)
+    assert_close(got3, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=3), 3 * scale, what=name + ", three runs")
+    got_o, _ = run_plan(rows, cols, p, c, v, x, y0, out_of_place=True)
+    same_bits(got_o, got, name + ", y_out")
+    got_c, _ = run_plan(rows, cols, p, c, v, x, y0, other_columns=True)
+    assert_close(got_c, want, scale, what=name + ", other column array")
+    got_e, _ = run_plan(rows, cols, p, c, v, x, y0, flags=capi.FLAG_EXACT_ORDER)
+    same_bits(got_e, oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=1), name + ", exact order")
+    with capi.Context(0) as ctx:
+        ctx.upload_csr(rows, cols, p, c, v)
+        ctx.set_x(x)
+        ctx.set_y(y0)
+        ctx.run()
+        assert_close(ctx.get_y(), want, scale, what=name + ", context upload")
