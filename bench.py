@@ -31,7 +31,11 @@ building the plan cost, stage by stage) and `compressed`: the launch the product
 its own us, GFLOP/s, streamed bytes, cold time and plan cost; `--headline product` makes that launch the timed one).
 Companions on the default workload (never part of `value`): `config2_queen`, `config3_kkt`, `config4_webbase` -- the
 stand-ins of BASELINE configs[2..4] at full size, each with ms per step, the section-8(d) fraction and a whole-vector
-parity check against the CPU kernel.  `cpu_baseline` (rank 0, N = 1 only) times the reference's own OpenMP kernel
+parity check against the CPU kernel; `config2_queen_stored`, `config3_kkt_stored` -- the same two matrices as the reference
+multiplies their FILES (the stored lower triangle of a `symmetric` Matrix Market file, nothing mirrored).
+`drop_in_multi_gpu` (every N): the same workload through the drop-in's own multi-GPU path -- spmv_hip_create_multi, ONE process
+over N devices, timed by a fresh child process of rank 0 (t_local / t_allgather / t_total per gather scheme, the RCCL rank count,
+the speed-up bound at the measured link rate); `value` for N > 1 is the one-process-per-GPU path the bench contract launches.  `cpu_baseline` (rank 0, N = 1 only) times the reference's own OpenMP kernel
 (oracle/_ref, kind "reference") or the C oracle (kind "port") on the host cores; the same leg is the parity gate.
 """
 import argparse
