@@ -186,6 +186,10 @@ def parse_args():
                     help="rehearsal: every rank uses device 0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     ap.add_argument("--reject-scheme", default=None, choices=["peer-fused", "peer-push"],
                     help="rehearsal: treat this gather scheme as if its gathered y had failed the check against RCCL's")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc passes -- FETCH_SIZE, WRITE_SIZE -- over a child "
+                         "that launches the timed plan a few times); the figure then comes from a committed profile of the same device sources")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: this process IS the profiled child
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the `drop_in_multi_gpu` leg: the same workload through spmv_hip_create_multi in ONE fresh process over "
                          "N devices -- the path the reference-side adapter binds (the reference is one process, src/profile-kernel.cpp:227)")
@@ -980,6 +984,93 @@ def drop_in_leg(args, torch, dist, rank, world, use_dist, specs, timeout_s=420):
     return result
 
 
+def pmc_child(args):
+    """`bench.py --pmc-child` (under `rocprofv3 --pmc <counter> -- python3 bench.py --pmc-child ...`): the headline workload's timed
+    plan -- the same flags, the same planning calls as the timed region's -- launched a few times on device 0, nothing else.  No
+    checker library, no timing; the counters are read by the parent from rocprofv3's CSV."""
+    import torch
+    from spmv_amd import capi, hostapi, synth
+    spec, _ = workload_spec(args)
+    A = hostapi.load(spec, "csr", expand_symmetric=args.expand_symmetric)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    stream = torch.cuda.current_stream().cuda_stream
+    algo = {"auto": capi.CSR_AUTO, "scalar": capi.CSR_SCALAR, "vector": capi.CSR_VECTOR, "adaptive": capi.CSR_ADAPTIVE, "wavetile": capi.CSR_WAVETILE}[args.algorithm]
+    flags = (capi.FLAG_XCD_REMAP if args.xcd_remap else 0) | args.flags | (capi.FLAG_NO_VALUE_INDEX if args.headline == "general" else 0)
+    x = synth.x_vector(A.cols, "uniform", seed=12345)
+    tp, tc, tv, tx = (torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (A.row_ptr, A.column_index, A.value, x))
+    ty = torch.zeros(A.rows, dtype=torch.float64, device=device)
+    plan, _ = build_plan_timed(torch, capi, A.rows, A.cols, A.row_ptr, tp, tc, tv, algo, args.lanes, flags, stream)
+    for _ in range(max(1, args.steps) + max(0, args.warmup)):
+        plan.spmv(tp.data_ptr(), tc.data_ptr(), tv.data_ptr(), tx.data_ptr(), ty.data_ptr(), stream)
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_child": True, "streamed_bytes_per_launch": int(plan.info()["streamed_bytes"]), "launches": max(1, args.steps) + max(0, args.warmup)}), flush=True)
+    plan.close()
+    return 0
+
+
+def live_pmc_traffic(args, kernel_names, streamed_bytes, timeout_s=100):
+    """roofline.traffic MEASURED IN THIS RUN (VERDICT r05 weak point 5): HBM-side bytes per launch of the dominant kernel from the PMC
+    counters, collected exactly as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes
+    (the TCC block cannot hold both), no trace domain beside them, KiB units, FETCH_SIZE doubled (gfx950 counts a 128-byte request as
+    64) -- over a child process that launches the timed plan ten times (pmc_child).  rocprofv3 stands directly in front of the python
+    interpreter (no env / shell hop).  Returns a dict for the line, or {"error": ...}: the caller then falls back to the committed
+    profile of the same device sources."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "8", "--warmup", "2", "--headline", args.headline,
+             "--workload", args.workload, "--grid", str(args.grid), "--kkt-grid", str(args.kkt_grid), "--algorithm", args.algorithm,
+             "--lanes", str(args.lanes), "--flags", hex(args.flags)]
+    if args.matrix:
+        child += ["--matrix", args.matrix]
+    if args.expand_symmetric:
+        child.append("--expand-symmetric")
+    if args.xcd_remap:
+        child.append("--xcd-remap")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got, took = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        outdir = tempfile.mkdtemp(prefix="spmv_pmc_", dir="/tmp")
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", outdir, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return {"error": "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])}
+            info = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "pmc_child" in l]
+            if not info or info[-1]["streamed_bytes_per_launch"] != int(streamed_bytes):
+                return {"error": "the profiled child built another plan than the timed one (streamed bytes %s against %s)" % (
+                    info[-1]["streamed_bytes_per_launch"] if info else None, int(streamed_bytes))}
+            vals = []
+            for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and any(n in row.get("Kernel_Name", "") for n in kernel_names):
+                        vals.append(float(row["Counter_Value"]))
+            if len(vals) < 4:
+                return {"error": "rocprofv3 --pmc %s: %d dispatches of the multiply kernel in its output" % (counter, len(vals))}
+            got[counter] = float(np.median(vals))  # KiB per launch
+            got[counter + "_launches"] = len(vals)
+        except subprocess.TimeoutExpired:
+            return {"error": "rocprofv3 --pmc %s did not finish within %d s" % (counter, timeout_s)}
+        except (OSError, ValueError, KeyError) as e:
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        finally:
+            took[counter] = round(time.perf_counter() - t0, 1)
+            shutil.rmtree(outdir, ignore_errors=True)
+    traffic = int(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    return {"traffic": traffic, "FETCH_SIZE_KiB_per_launch": round(got["FETCH_SIZE"], 1), "WRITE_SIZE_KiB_per_launch": round(got["WRITE_SIZE"], 1),
+            "launches_counted": [got["FETCH_SIZE_launches"], got["WRITE_SIZE_launches"]], "pass_seconds": took,
+            "how": "two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) over a child process that launches the timed plan 10 times; "
+                   "per launch: median over the multiply kernel's dispatches; bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950) + WRITE_SIZE KiB x 1024"}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` typed plainly (no launcher): start the N ranks as FRESH child processes -- one
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` with this command line -- before this process has imported
@@ -1002,6 +1093,8 @@ def main():
     args = parse_args()
     if args.drop_in_child > 0:
         sys.exit(drop_in_child(args))
+    if args.pmc_child:
+        sys.exit(pmc_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -1715,7 +1808,25 @@ def main():
                 code, message = 1, "bench.py: gathered y does not match the owning rank's rows"
         out["build"] = build
         tr = pmc_traffic(kernel_name, wname, int(local_bytes), out["roofline"].get("streamed_bytes_per_launch"), build, kern_s * 1e6)
-        if tr:
+        live = None
+        under_profiler = any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ)  # (this run is itself a rocprofv3 child: no nesting)
+        if world == 1 and not use_dist and fmt == "csr" and spec is not None and not args.no_live_pmc and code == 0 and not under_profiler:
+            live = live_pmc_traffic(args, MULTIPLY_KERNELS, streamed)
+        if live is not None and "traffic" in live:
+            # measured in THIS run, on THIS box, with the library that was just timed; the committed profile (another run, another
+            # box, the same device sources) stands beside it as a cross-check
+            out["roofline"]["traffic"] = live["traffic"]
+            out["roofline"]["traffic_measured_in_this_run"] = True
+            out["roofline"]["traffic_over_bytes"] = round(live["traffic"] / max(1, int(streamed)), 3)
+            out["roofline"]["traffic_over_algorithmic_bytes"] = round(live["traffic"] / max(1, int(local_bytes)), 3)
+            out["roofline"]["frac_traffic"] = round(live["traffic"] / kern_s / 1e9 / HBM_PEAK_GBS, 4)
+            out["roofline"]["traffic_source"] = live["how"]
+            out["roofline"]["traffic_live"] = {k: live[k] for k in ("FETCH_SIZE_KiB_per_launch", "WRITE_SIZE_KiB_per_launch", "launches_counted", "pass_seconds")}
+            if tr:
+                out["roofline"]["traffic_committed_profile"] = {"bytes": tr[0], "file": "profiles/" + tr[1], "over_live": round(tr[0] / live["traffic"], 4)}
+        elif tr:
+            if live is not None:
+                out["roofline"]["traffic_live"] = live  # why the live measurement did not happen
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_over_bytes"] = round(tr[0] / max(1, int(streamed)), 3)
             out["roofline"]["frac_traffic"] = round(tr[0] / kern_s / 1e9 / HBM_PEAK_GBS, 4)
@@ -1729,6 +1840,8 @@ def main():
                     compressed["traffic"] = tg[0]
                     compressed["traffic_over_streamed_bytes"] = round(tg[0] / max(1, compressed["streamed_bytes_per_launch"]), 3)
         else:
+            if live is not None:
+                out["roofline"]["traffic_live"] = live
             out["roofline"]["traffic_source"] = ("none: no committed profiles/*_summary.json of this workload was taken with device "
                                                  "sources %s" % build["source_sha256"])
         if world == 1 and not use_dist and not args.no_cpu_baseline:

@@ -4,7 +4,7 @@
 TAG=${1:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-run() { name=$1; shift; python3 bench.py --steps 50 --warmup 10 --cpu-seconds 4 --no-companions --no-config3 "$@" > gpurun_out/${TAG}_$name.log 2> gpurun_out/${TAG}_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/${TAG}_$name.err; }; python3 - gpurun_out/${TAG}_$name.log $name <<'PY'
+run() { name=$1; shift; python3 bench.py --steps 50 --warmup 10 --cpu-seconds 4 --no-companions --no-config3 --no-drop-in ${LIVE_PMC:---no-live-pmc} "$@" > gpurun_out/${TAG}_$name.log 2> gpurun_out/${TAG}_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/${TAG}_$name.err; }; python3 - gpurun_out/${TAG}_$name.log $name <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])

@@ -11,7 +11,7 @@ TAG=${1:-prof}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
-ARGS="--steps ${PROFILE_STEPS:-40} --warmup 5 --no-cpu-baseline --no-reference-protocol $*"
+ARGS="--steps ${PROFILE_STEPS:-40} --warmup 5 --no-cpu-baseline --no-reference-protocol --no-live-pmc $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1 || { tail -20 "$OUT/pmc_fetch.log"; exit 1; }
