@@ -579,7 +579,13 @@ def reference_protocol(args, fmt, runs, flush=False):
            "execution_time_ns": {k: et[k] for k in ("samples", "min", "median", "mean", "max")},
            "gflops_median": round(flops / et["median"], 2) if et["median"] else None,
            "device_ns_last_run": d.get("kernel", {}).get("device", {}).get("last_run_device_ns"),
-           "parity": d.get("parity"), "wall_s": round(time.perf_counter() - t0, 1)}
+           "parity": d.get("parity"), "wall_s": round(time.perf_counter() - t0, 1),
+           # (VERDICT r05 weak point 11: this and the headline are two different launches)
+           "plan": "the library's DEFAULT plan through the adapter's context API -- a value dictionary where the matrix has <= 128 distinct values "
+                   "(Poisson: two): NOT the value-reading launch that `value` / `roofline` time; compare with roofline.compressed",
+           "init_seconds": d.get("kernel", {}).get("device", {}).get("init_seconds"),
+           "init_note": "Kernel::init (load / generate, upload over PCIe, plan) is outside the reference's timed window (src/profile-kernel.cpp:262-266) "
+                        "but costs the equivalent of ~190 runs for Poisson 4096^2: a --profile=10 session never amortises it"}
     return out
 
 
