@@ -125,7 +125,7 @@ def test_other_formats_and_errors_through_the_host_abi(tmp_path):
 
 
 @pytest.mark.parametrize("spec,suffix", [("synthetic:kkt:12", ".mtx"), ("synthetic:webbase:20000,62000,300,75", ".mtx.gz"),
-                                         ("synthetic:queen:6,5,7", ".mtx")])
+                                         ("synthetic:queen:6,5,7", ".mtx"), ("synthetic:queen:6,5,7:tril", ".mtx")])
 def test_write_mtx_reads_back_bit_for_bit(tmp_path, spec, suffix):
     """--write-mtx: a generated matrix written as a Matrix Market file (plain or gzip) and read back through the
     loader gives the same CSR arrays, the values bit for bit (shortest round-trip decimals)."""
@@ -140,6 +140,12 @@ def test_write_mtx_reads_back_bit_for_bit(tmp_path, spec, suffix):
     assert np.array_equal(np.asarray(a.row_ptr), np.asarray(b.row_ptr))
     assert np.array_equal(np.asarray(a.column_index), np.asarray(b.column_index))
     assert np.array_equal(np.asarray(a.value).view(np.uint64), np.asarray(b.value).view(np.uint64))
+    if spec.endswith(":tril"):
+        # a stored triangle is written as the `symmetric` file it stands for, and mirrored on request like any such file
+        assert open(path).readline().split()[-1] == "symmetric"
+        full, mirrored = hostapi.load(spec[:-5], "csr"), hostapi.load(path, "csr", expand_symmetric=True)
+        assert np.array_equal(np.asarray(full.row_ptr), np.asarray(mirrored.row_ptr))
+        assert np.array_equal(np.asarray(full.column_index), np.asarray(mirrored.column_index))
     # needs a matrix; refuses an unwritable path with one line on stderr
     code, out, err = hostlib.run_cli("--write-mtx", path)
     assert code != 0
@@ -253,3 +259,51 @@ def test_poisson3d_family():
     A.close()
     with pytest.raises(hostapi.HostError):
         hostapi.load("synthetic:poisson3d:5000")
+
+
+@pytest.mark.parametrize("spec", ["synthetic:queen:9,8,7", "synthetic:kkt:7", "synthetic:poisson2d:13", "synthetic:banded:500,6,3",
+                                  "synthetic:queen:9,8,7,3,100,13"])
+def test_stored_triangle_modifier(spec, tmp_path):
+    """`<spec>:tril` (round 6): the stored lower triangle of the generated matrix -- what a `symmetric` Matrix Market file holds
+    and the reference multiplies as it stands (src/matrix/matrix-market.cpp:396-414 parses the word, :530-555 keeps the entries as
+    read; README.md:106).  Entries with column <= row, in place; as coordinate entries the matrix carries the `symmetric` header
+    word, so SPMV_HOST_EXPAND_SYMMETRIC gives the whole (structurally symmetric) matrix back; row ranges are slices of it; a
+    written file reads back as the same triangle."""
+    F = hostapi.load(spec, "csr")
+    T = hostapi.load(spec + ":tril", "csr")
+    fp, fc, fv = np.array(F.row_ptr), np.array(F.column_index), np.array(F.value)
+    tp, tc, tv = np.array(T.row_ptr), np.array(T.column_index), np.array(T.value)
+    r = np.repeat(np.arange(F.rows), np.diff(fp))
+    keep = fc <= r
+    assert (T.rows, T.cols) == (F.rows, F.cols) and T.num_entries == int(keep.sum())
+    assert np.array_equal(tc, fc[keep]) and np.array_equal(tv, fv[keep])
+    assert np.array_equal(np.diff(tp), np.bincount(r[keep], minlength=F.rows))
+    # a row range of the triangle = the rows of the triangle
+    b, e = F.rows // 3, 2 * F.rows // 3 + 1
+    S = hostapi.load_csr_rows(spec + ":tril", b, e)
+    assert S.rows_total == F.rows and np.array_equal(np.array(S.row_ptr), tp[b:e + 1] - tp[b])
+    assert np.array_equal(np.array(S.column_index), tc[tp[b]:tp[e]])
+    # mirrored again: the whole matrix, where its structure is symmetric (dropped entries of the broken twin are not)
+    E = hostapi.load(spec + ":tril", "csr", expand_symmetric=True)
+    assert E.expanded
+    if ",100," not in spec:
+        assert np.array_equal(np.array(E.row_ptr), fp) and np.array_equal(np.array(E.column_index), fc)
+    # COO keeps the triangle too (the converters see a symmetric header and mirror nothing)
+    Ccoo = hostapi.load(spec + ":tril", "coo")
+    assert Ccoo.num_entries == T.num_entries
+    for m in (F, T, S, E, Ccoo):
+        m.close()
+
+
+def test_stored_triangle_of_the_block_matrices_has_the_rows_the_plan_looks_for():
+    """queen:tril / kkt:tril at a small size: the rows of a node are 3 k + 1, 3 k + 2, 3 k + 3 entries long (what spmv_hip_plan_csr's
+    skewed-triple hint reads off row_ptr), the KKT states and controls hold their diagonal only."""
+    T = hostapi.load("synthetic:queen:10,9,8:tril", "csr")
+    l = np.diff(np.array(T.row_ptr)).reshape(-1, 3)
+    assert np.all(l[:, 0] % 3 == 1) and np.all(l[:, 1] == l[:, 0] + 1) and np.all(l[:, 2] == l[:, 0] + 2)
+    T.close()
+    K = hostapi.load("synthetic:kkt:8:tril", "csr")
+    l = np.diff(np.array(K.row_ptr))
+    ny, nu = 8 ** 3, 6 * 8 ** 2
+    assert np.all(l[:ny + nu] == 1) and l[ny + nu:].min() >= 8 and l[ny + nu:].max() <= 27 + 3
+    K.close()
