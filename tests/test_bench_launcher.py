@@ -22,8 +22,8 @@ def _env():
 
 
 def test_plain_gpus_n_starts_its_own_ranks_before_touching_a_device():
-    """Without a GPU every rank must stop at 'no GPU visible' (there is no CPU fallback) -- which proves that N ranks were
-    started and that each went through the launcher's environment.  The parent leaves with the children's failure."""
+    """Without a GPU every rank must stop at 'no GPU visible' (there is no CPU fallback) -- which proves that the ranks were
+    started and went through the launcher's environment.  The parent leaves with the children's failure."""
     import torch
     if torch.cuda.device_count() > 0:
         pytest.skip("a GPU is visible: test_gpu_three_ranks_on_one_device covers the launch")
@@ -31,7 +31,8 @@ def test_plain_gpus_n_starts_its_own_ranks_before_touching_a_device():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_env(), timeout=300)
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
-    assert r.stderr.count("no GPU visible; this benchmark has no CPU fallback") == 2, r.stderr[-3000:]
+    # (every rank stops there; the launcher may end the second one before its line is out once the first has failed: one or two)
+    assert 1 <= r.stderr.count("no GPU visible; this benchmark has no CPU fallback") <= 2, r.stderr[-3000:]
     assert "needs torch.distributed.run" not in r.stderr
 
 
