@@ -172,7 +172,9 @@ static int multi_after_upload(spmv_hip_ctx * c)
     c->pipeline = false;
     c->cur = 0;
     c->sent_recorded[0] = c->sent_recorded[1] = false;
-    if (!(c->flags & SPMV_HIP_FLAG_PIPELINE_GATHER) || G < 2 || (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) || c->comm.size() != G)
+    // (one device: only in the rehearsal that forces the collective, SPMV_HIP_FORCE_RCCL=1 -- the comm streams exist only then)
+    if (!(c->flags & SPMV_HIP_FLAG_PIPELINE_GATHER) || (c->flags & SPMV_HIP_FLAG_FUSED_PEER_STORE) || c->comm.size() != G || G < 1
+        || (G < 2 && c->comms.empty()))
         return SPMV_HIP_OK;
     for (size_t g = 0; g < G; ++g)
         if (c->parts[g]->rows > 0 && !part_runs_csr_plan(c->parts[g]))
@@ -709,7 +711,9 @@ int spmv_hip_create_multi(spmv_hip_ctx ** out, int num_gpus, unsigned flags)
             c->ev_gather.push_back(ev);
         }
     }
-    if (rc == SPMV_HIP_OK && (flags & SPMV_HIP_FLAG_PIPELINE_GATHER) && num_gpus > 1 && !(flags & SPMV_HIP_FLAG_FUSED_PEER_STORE)) {
+    const char * force_env = std::getenv("SPMV_HIP_FORCE_RCCL");
+    const bool force_one = num_gpus == 1 && force_env && force_env[0] == '1' && !(flags & SPMV_HIP_FLAG_PEER_GATHER);
+    if (rc == SPMV_HIP_OK && (flags & SPMV_HIP_FLAG_PIPELINE_GATHER) && (num_gpus > 1 || force_one) && !(flags & SPMV_HIP_FLAG_FUSED_PEER_STORE)) {
         for (int g = 0; g < num_gpus && rc == SPMV_HIP_OK; ++g) {
             hipStream_t st = nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;

@@ -326,6 +326,37 @@ def test_multi_gpu_context_with_one_device(oracle):
     with pytest.raises(capi.SpmvHipError) as e:
         capi.Context(num_gpus=capi.device_count() + 1)
     assert e.value.code == capi.ERR_INVALID
+    # round 6: the PIPELINED RCCL gather -- ncclAllGather on the second stream, behind an event, beside the next run's multiply -- with
+    # the one device this box has (only under SPMV_HIP_FORCE_RCCL=1; otherwise one device never pipelines): the serial order's bits
+    os.environ["SPMV_HIP_FORCE_RCCL"] = "1"
+    try:
+        # (a 27-point stencil: row-owned tiles, no atomics -- the same bits on every run; the power-law matrix above has rows whose
+        # chunks meet in atomics and is compared within the tolerance)
+        srows, scols, sp, sc, sv = synth.stencil27_like(29, 31, 23)
+        sx, sy0 = synth.x_vector(scols, seed=5), synth.x_vector(srows, seed=6)
+        ys = {}
+        for name, extra in (("serial", 0), ("pipelined", capi.FLAG_PIPELINE_GATHER)):
+            with capi.Context(num_gpus=1, flags=extra) as ctx:
+                ctx.upload_csr(srows, scols, sp, sc, sv)
+                ctx.set_x(sx)
+                ctx.set_y(sy0)
+                ctx.run(5)
+                ys[name] = ctx.get_y()
+                info = ctx.info()
+                assert info["pipelined"] == (1 if extra else 0) and info["rccl_ranks"] == 1, info
+                ctx.upload_csr(rows, cols, p, c, v)
+                ctx.set_x(x)
+                ctx.set_y(y0)
+                ctx.run(2)
+                assert_close(ctx.get_y(), oracle.csr_spmv(rows, p, c, v, x, y=y0, num_threads=4, runs=2), scale, what="%s rccl, G=1, power-law rows" % name)
+        assert_bitexact(ys["pipelined"], ys["serial"], "pipelined RCCL gather with one device")
+        assert_close(ys["pipelined"], oracle.csr_spmv(srows, sp, sc, sv, sx, y=sy0, num_threads=4, runs=5), 5 * abs_products(srows, sp, sc, sv, sx) + np.abs(sy0),
+                     what="pipelined rccl, G=1, five runs")
+    finally:
+        os.environ.pop("SPMV_HIP_FORCE_RCCL", None)
+    with capi.Context(num_gpus=1, flags=capi.FLAG_PIPELINE_GATHER) as ctx:  # without the forced collective: nothing to pipeline
+        ctx.upload_csr(rows, cols, p, c, v)
+        assert ctx.info()["pipelined"] == 0
 
 
 def test_cli_synthetic_full_size_gpus_and_check():
