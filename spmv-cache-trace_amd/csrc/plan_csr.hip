@@ -375,18 +375,39 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
     } else {
         pl->block_hint = 0;
         pl->block_offset = 0;
-        if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & (SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS))) {
-            for (int o = 0; o < 3 && !pl->block_hint && !(pl->hints_tried & 4); ++o) {
-                const long long triples = (rows - o) / 3, allowed_bad = triples / 5;
-                long long good = 0, bad = 0, entries = 0;
-                for (int32_t q = o; q + 2 < rows && bad <= allowed_bad; q += 3) {
-                    const bool ok = skewed_triple(q);
-                    good += ok;
-                    bad += !ok;
-                    entries += ok ? p[q + 3] - p[q] : 0;
+        if (!exact && tile == 512 && break_rows == 0 && rows >= 192 && !(flags & (SPMV_HIP_FLAG_NO_BLOCK_TILES | SPMV_HIP_FLAG_NO_MASKED_BLOCKS))
+            && !(pl->hints_tried & 4)) {
+            // Real files drop explicit zeros: with 0.5 % of the entries gone only two thirds of the triples still go EXACTLY
+            // (m + 1, m + 2, m + 3), with 2 % a fifth (the Delaunay stored triangle fell from 0.99 to 0.67 with 0.5 % dropped:
+            // balanced tiles).  What survives is the PEAK: at the right offset a tenth of the triples or more are exact, at the two
+            // wrong ones next to none (an exact triple wants 3 | m at that very offset), and nearly all triples are LOOSE ones --
+            // each row -2 ... +4 entries longer than the one above.  A glance (1024 triples per offset, spread over the matrix)
+            // finds the offset, one pass over row_ptr at that offset confirms; a matrix without the peak -- scalar meshes: 0.7 % of
+            // the triples exact at every offset, stencils: none -- pays for the glance only.
+            auto loose = [p](int32_t q) {
+                const int l0 = p[q + 1] - p[q], d1 = (p[q + 2] - p[q + 1]) - l0, d2 = (p[q + 3] - p[q + 2]) - (p[q + 2] - p[q + 1]);
+                return l0 >= 1 && d1 >= -2 && d1 <= 4 && d2 >= -2 && d2 <= 4;
+            };
+            int glance[3] = {0, 0, 0};
+            const long long triples_all = (rows - 2) / 3;
+            for (int o = 0; o < 3; ++o)
+                for (int t = 0; t < 1024; ++t) {
+                    const int32_t q = o + 3 * (int32_t) ((triples_all - 1) * t / 1023);
+                    glance[o] += skewed_triple(q) ? 1 : 0;
+                }
+            const int o = glance[0] >= glance[1] && glance[0] >= glance[2] ? 0 : (glance[1] >= glance[2] ? 1 : 2);
+            const int other = std::max(glance[(o + 1) % 3], glance[(o + 2) % 3]);
+            if (glance[o] >= 80 && glance[o] >= 4 * other) {
+                const long long triples = (rows - o) / 3;
+                long long exact3 = 0, near3 = 0, entries = 0;
+                for (int32_t q = o; q + 2 < rows; q += 3) {
+                    const bool e3 = skewed_triple(q), n3 = e3 || loose(q);
+                    exact3 += e3;
+                    near3 += n3;
+                    entries += n3 ? p[q + 3] - p[q] : 0;
                 }
                 // (on average more than two blocks per block row: a tridiagonal matrix, whose interior rows "go" 2, 3, 3, is not one)
-                if (bad <= allowed_bad && good * 5 >= triples * 4 && entries >= 24 * good) {
+                if (exact3 * 10 >= triples && near3 * 5 >= triples * 4 && entries >= 24 * near3) {
                     pl->block_hint = 3;
                     pl->block_offset = o;
                     pl->block_skewed = true;
@@ -489,7 +510,8 @@ static int build_wave_tiles(spmv_hip_plan * pl, const int32_t * p, unsigned flag
                     ++q;
                 row_limit = q;
             }
-        } else if (pl->block_hint == 3 && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce && !(pl->block_skewed ? skewed_triple(r) : similar_triple(r))) {
+        } else if (pl->block_hint == 3 && ((r - phase) % 3 + 3) % 3 == 0 && r + 8 <= ce
+                   && !(pl->block_skewed ? (skewed_triple(r) || skewed_triple(r + 3)) : similar_triple(r))) {
             for (int d = 1; d <= 2; ++d)
                 if (pl->block_skewed ? (skewed_triple(r + d) && skewed_triple(r + d + 3)) : (similar_triple(r + d) && similar_triple(r + d + 3))) {
                     phase = (r + d) % 3;

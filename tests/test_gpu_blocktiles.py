@@ -620,6 +620,18 @@ def _tril(rows, cols, p, c, v):
     return rows, cols, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
 
 
+def _tril_dropped(rows, cols, p, c, v, drop, seed=1):
+    """the stored lower triangle with a share of its off-diagonal entries missing (explicit zeros the assembly left out)"""
+    import scipy.sparse as sp
+    A = sp.tril(sp.csr_matrix((v, c, p), shape=(rows, cols)), format="csr")
+    A.sort_indices()
+    r = np.repeat(np.arange(rows), np.diff(A.indptr))
+    keep = (A.indices == r) | (np.random.default_rng(seed).random(len(A.data)) >= drop)
+    B = sp.csr_matrix((A.data[keep], (r[keep], A.indices[keep])), shape=(rows, cols))
+    B.sort_indices()
+    return rows, cols, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data
+
+
 def _triu(rows, cols, p, c, v):
     import scipy.sparse as sp
     A = sp.triu(sp.csr_matrix((v, c, p), shape=(rows, cols)), format="csr")
@@ -631,6 +643,9 @@ def _triu(rows, cols, p, c, v):
     ("delaunay 3 dof, 60 K points, rcm, lower triangle", lambda: _tril(*synth.delaunay_mesh(60000, 3, seed=6))),
     ("delaunay 3 dof, 60 K points, rcm, upper triangle", lambda: _triu(*synth.delaunay_mesh(60000, 3, seed=6))),
     ("delaunay 3 dof, 30 K points, random order, lower triangle", lambda: _tril(*synth.delaunay_mesh(30000, 3, seed=5, order="random"))),
+    # real files drop explicit zeros: a fifth to two thirds of the triples still go exactly (m + 1, m + 2, m + 3) -- the hint's peak
+    ("delaunay 3 dof, 60 K points, rcm, lower triangle, 0.5 % dropped", lambda: _tril_dropped(*synth.delaunay_mesh(60000, 3, seed=6), 0.005)),
+    ("delaunay 3 dof, 60 K points, rcm, lower triangle, 2 % dropped", lambda: _tril_dropped(*synth.delaunay_mesh(60000, 3, seed=6), 0.02)),
     ("queen-like 30 x 24 x 20, lower triangle", lambda: (lambda M: (M.rows, M.cols, np.array(M.row_ptr), np.array(M.column_index), np.array(M.value)))(
         hostapi.load("synthetic:queen:30,24,20:tril", "csr"))),
     ("delaunay 6 dof, 25 K points", lambda: synth.delaunay_mesh(25000, 6, seed=7))])

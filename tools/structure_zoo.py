@@ -128,6 +128,17 @@ def zoo():
         A.sort_indices()
         return rows, cols, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
     out["delaunay_3dof_700k_tril"] = lambda: tril(lambda: synth.delaunay_mesh(700000, 3, seed=1))  # ... as a symmetric file stores it: 53 M entries
+    def tril_dropped(make, drop):
+        # ... with a share of its off-diagonal entries missing (explicit zeros the assembly left out)
+        import scipy.sparse as sp
+        rows, cols, p, c, v = tril(make)
+        r = np.repeat(np.arange(rows), np.diff(p))
+        keep = (c == r) | (np.random.default_rng(1).random(len(c)) >= drop)
+        B = sp.csr_matrix((v[keep], (r[keep], c[keep])), shape=(rows, cols))
+        B.sort_indices()
+        return rows, cols, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data
+    out["delaunay_3dof_700k_tril_drop2pct"] = lambda: tril_dropped(lambda: synth.delaunay_mesh(700000, 3, seed=1), 0.02)
+    out["delaunay_3dof_700k_tril_drop10pct"] = lambda: tril_dropped(lambda: synth.delaunay_mesh(700000, 3, seed=1), 0.10)
     out["delaunay_6dof_250k"] = lambda: synth.delaunay_mesh(250000, 6, seed=6)     # shells: 6 x 6 blocks = 3 x 3 blocks, 148 M entries, ~99 per row
     out["delaunay_1dof_2M"] = lambda: synth.delaunay_mesh(2000000, 1, seed=2)      # 33 M entries, ~16.5 per row
     out["delaunay_1dof_6M"] = lambda: synth.delaunay_mesh(6200000, 1, seed=2)      # 102 M entries (minutes of qhull)
